@@ -1,0 +1,764 @@
+// engine.cpp — host control flow of the CP ALS sweep engine (dimension tree + pairwise
+// perturbation) over abstract device ops. Mirrors the reference's orchestration:
+//   Construct_Dimension_Tree  common.cxx:225-270     -> build_tree
+//   mttkrp_map_DT             common.cxx:20-133      -> compute_node (fused per node, no s^(N-1)R
+//                                                       intermediate, no copy of V)
+//   alsCP_DT                  als_CP.cxx:127-320     -> run_dt / sweep_dt
+//   Build_mttkrp_map          als_CP.cxx:352-409     -> pp_get
+//   alsCP_DT_sub / PP_sub     als_CP.cxx:418-833     -> dt_sub / pp_sub
+//   alsCP_PP                  als_CP.cxx:1082-1137   -> run_pp
+// Multi-GPU: V is block-partitioned along mode 0; factors are replicated; each
+// mode update reduce-scatters the s x R partial MTTKRP rows, solves its row block, all-gathers.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+namespace ppals {
+
+static double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ============================================================================ tensor helpers
+int tensor_create(Ops &ops, Comm &comm, int order, const int64_t *glens, int dtype,
+                  TensorDesc *out, std::string *err) {
+  if (order < 2 || order > MAX_ORDER) {
+    *err = "tensor order must be in [2, 8]";
+    return -1;
+  }
+  TensorDesc t;
+  t.order = order;
+  t.dtype = dtype;
+  int64_t rest = 1;
+  for (int i = 0; i < order; i++) {
+    if (glens[i] <= 0) {
+      *err = "tensor extents must be positive";
+      return -1;
+    }
+    t.glens[i] = glens[i];
+    t.llens[i] = glens[i];
+    if (i > 0) rest *= glens[i];
+  }
+  const int P = comm.size();
+  const int64_t blk = block_rows(glens[0], P);
+  t.row0 = blk * comm.rank();
+  t.llens[0] = std::max<int64_t>(0, std::min(blk, glens[0] - t.row0));
+  if (t.llens[0] <= 0) {
+    *err = "leading mode too short for this many ranks (a rank would own no rows)";
+    return -1;
+  }
+  t.nloc = t.llens[0] * rest;
+  t.data = ops.alloc((size_t)t.nloc * dtype_size(dtype));
+  *out = t;
+  return 0;
+}
+
+static int64_t rest_of(const TensorDesc &V) {
+  int64_t r = 1;
+  for (int i = 1; i < V.order; i++) r *= V.glens[i];
+  return r;
+}
+
+// device Khatri-Rao operands of the two halves of the mode set: Q over modes [0,h), P over [h,N)
+static void split_krp(Ops &ops, const TensorDesc &V, int R, double *const *W, double *Q, double *P,
+                      int64_t *M, int64_t *K) {
+  const int N = V.order, h = N / 2;
+  FactorRef fq[MAX_ORDER], fp[MAX_ORDER];
+  int64_t m = 1, k = 1;
+  for (int i = 0; i < h; i++) {
+    fq[i].ptr = W[i] + (i == 0 ? V.row0 : 0);
+    fq[i].rows = V.llens[i];
+    fq[i].ld = V.glens[i];
+    m *= V.llens[i];
+  }
+  for (int i = h; i < N; i++) {
+    fp[i - h].ptr = W[i];
+    fp[i - h].rows = V.glens[i];
+    fp[i - h].ld = V.glens[i];
+    k *= V.glens[i];
+  }
+  ops.krp(Q, fq, h, 0, R);
+  ops.krp(P, fp, N - h, 0, R);
+  *M = m;
+  *K = k;
+}
+static void split_sizes(const TensorDesc &V, int64_t *M, int64_t *K) {
+  const int N = V.order, h = N / 2;
+  int64_t m = 1, k = 1;
+  for (int i = 0; i < h; i++) m *= V.llens[i];
+  for (int i = h; i < N; i++) k *= V.glens[i];
+  *M = m;
+  *K = k;
+}
+
+// `-tensor r` (test_ALS.cxx:275-286): V = [[W_true]], built on the device
+void tensor_fill_cp(Ops &ops, const TensorDesc &V, int R, const double *Wtrue_flat) {
+  const int N = V.order;
+  std::vector<double *> W(N);
+  const double *src = Wtrue_flat;
+  for (int i = 0; i < N; i++) {
+    size_t n = (size_t)V.glens[i] * R;
+    W[i] = (double *)ops.alloc(n * sizeof(double));
+    ops.h2d(W[i], src, n * sizeof(double));
+    src += n;
+  }
+  int64_t M, K;
+  split_sizes(V, &M, &K);
+  double *Q = (double *)ops.alloc(sizeof(double) * M * R);
+  double *Pm = (double *)ops.alloc(sizeof(double) * K * R);
+  split_krp(ops, V, R, W.data(), Q, Pm, &M, &K);
+  ops.fill_rank(V.data, V.dtype, M, K, Q, Pm, R);
+  ops.sync();
+  ops.free(Q);
+  ops.free(Pm);
+  for (auto p : W) ops.free(p);
+}
+void tensor_fill_uniform(Ops &ops, const TensorDesc &V, uint64_t seed, double lo, double hi) {
+  ops.fill_uniform(V.data, V.dtype, V.llens[0], V.glens[0], V.row0, rest_of(V), seed, lo, hi);
+  ops.sync();
+}
+void tensor_upload(Ops &ops, const TensorDesc &V, const double *host_full) {
+  ops.upload_shard(V.data, V.dtype, host_full, V.llens[0], V.glens[0], V.row0, rest_of(V));
+}
+double tensor_norm(Ops &ops, Comm &comm, const TensorDesc &V) {
+  int64_t M, K;
+  split_sizes(V, &M, &K);
+  double *d = (double *)ops.alloc(sizeof(double));
+  ops.residual_sq(V.data, V.dtype, M, K, nullptr, nullptr, 0, d);
+  if (comm.size() > 1) comm.allreduce_sum(d, 1);
+  double h = 0;
+  ops.d2h(&h, d, sizeof(double));
+  ops.free(d);
+  return std::sqrt(h);
+}
+
+// ============================================================================ CpEngine
+CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
+    : ops_(ops), comm_(comm), V_(V), N_(V.order), R_(R), P_(comm.size()), rank_(comm.rank()) {
+  if (R <= 0) throw std::runtime_error("ppals: rank must be positive");
+  W_.resize(N_);
+  gradW_.resize(N_);
+  Wprev_.assign(N_, nullptr);
+  Winit_.assign(N_, nullptr);
+  dW_.assign(N_, nullptr);
+  for (int i = 0; i < N_; i++) {
+    size_t n = (size_t)V_.glens[i] * R_ * sizeof(double);
+    W_[i] = (double *)ops_.alloc(n);
+    gradW_[i] = (double *)ops_.alloc(n);
+    ops_.zero(W_[i], n);
+    ops_.zero(gradW_[i], n);
+    maxs_ = std::max(maxs_, V_.glens[i]);
+    maxblk_ = std::max(maxblk_, block_rows(V_.glens[i], P_));
+  }
+  G_ = (double *)ops_.alloc(sizeof(double) * N_ * R_ * R_);
+  S_ = (double *)ops_.alloc(sizeof(double) * R_ * R_);
+  Sinv_ = (double *)ops_.alloc(sizeof(double) * R_ * R_);
+  gradsq_ = (double *)ops_.alloc(sizeof(double) * MAX_ORDER);
+  scal_ = (double *)ops_.alloc(sizeof(double) * 4 * MAX_ORDER);
+  ops_.zero(gradsq_, sizeof(double) * MAX_ORDER);
+  if (P_ > 1) {
+    size_t n = sizeof(double) * (size_t)maxblk_ * P_ * R_;
+    sendbuf_ = (double *)ops_.alloc(n);
+    recvbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxblk_ * R_);
+    gatherbuf_ = (double *)ops_.alloc(n);
+    ops_.zero(sendbuf_, n);
+    ops_.zero(gatherbuf_, n);
+  }
+  build_tree(0, N_ - 1, -1);
+  leaf_.assign(N_, -1);
+  for (size_t k = 0; k < nodes_.size(); k++)
+    if (nodes_[k].lo == nodes_[k].hi) leaf_[nodes_[k].lo] = (int)k;
+}
+
+CpEngine::~CpEngine() {
+  try {
+    ops_.sync();
+  } catch (...) {
+  }
+  for (auto p : W_) ops_.free(p);
+  for (auto p : gradW_) ops_.free(p);
+  for (auto p : Wprev_) ops_.free(p);
+  for (auto p : Winit_) ops_.free(p);
+  for (auto p : dW_) ops_.free(p);
+  for (auto &n : nodes_) ops_.free(n.buf);
+  pp_clear();
+  ops_.free(G_);
+  ops_.free(S_);
+  ops_.free(Sinv_);
+  ops_.free(gradsq_);
+  ops_.free(scal_);
+  ops_.free(sendbuf_);
+  ops_.free(recvbuf_);
+  ops_.free(gatherbuf_);
+  ops_.free(Mbuf_);
+  ops_.free(Qbuf_);
+  ops_.free(Pbuf_);
+}
+
+FactorRef CpEngine::fref(int m, double *const *W) const {
+  FactorRef f;
+  f.ptr = W[m] + (m == 0 ? V_.row0 : 0);
+  f.rows = ext(m);
+  f.ld = V_.glens[m];
+  return f;
+}
+int64_t CpEngine::prod_ext(int lo, int hi) const {
+  int64_t p = 1;
+  for (int m = lo; m <= hi; m++) p *= ext(m);
+  return p;
+}
+
+// Construct_Dimension_Tree (common.cxx:225-270): split [lo,hi] at (lo+hi)/2; every non-root range
+// becomes a node that knows its parent and its sibling range.
+void CpEngine::build_tree(int lo, int hi, int parent) {
+  if (hi <= lo) return;
+  const int mid = (lo + hi) / 2;
+  const int ranges[2][2] = {{lo, mid}, {mid + 1, hi}};
+  int idx[2];
+  for (int c = 0; c < 2; c++) {
+    Node n;
+    n.lo = ranges[c][0];
+    n.hi = ranges[c][1];
+    n.parent = parent;
+    n.slo = ranges[1 - c][0];
+    n.shi = ranges[1 - c][1];
+    n.elems = 0;
+    nodes_.push_back(n);
+    idx[c] = (int)nodes_.size() - 1;
+  }
+  build_tree(lo, mid, idx[0]);
+  build_tree(mid + 1, hi, idx[1]);
+}
+int CpEngine::find_node(int lo, int hi) const {
+  for (size_t k = 0; k < nodes_.size(); k++)
+    if (nodes_[k].lo == lo && nodes_[k].hi == hi) return (int)k;
+  return -1;
+}
+
+// mttkrp_map_DT (common.cxx:20-133). A node whose parent is the root scans V once with the
+// Khatri-Rao product of ALL sibling modes (K1: sibling is a suffix, K2: a prefix); deeper nodes
+// contract the cached parent tensor, which already carries the rank index.
+void CpEngine::compute_node(int idx) {
+  Node &n = nodes_[idx];
+  if (n.valid) return;
+  n.elems = prod_ext(n.lo, n.hi);
+  if (!n.buf) n.buf = (double *)ops_.alloc(sizeof(double) * (size_t)n.elems * R_);
+  FactorRef f[MAX_ORDER];
+  int nf = 0;
+  for (int m = n.slo; m <= n.shi; m++) f[nf++] = fref(m, W_.data());
+  const int64_t J = prod_ext(n.slo, n.shi);
+  const bool sib_is_suffix = n.slo > n.hi;
+  if (n.parent < 0) {
+    if (sib_is_suffix)
+      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, n.elems);
+    else
+      ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, n.elems);
+  } else {
+    compute_node(n.parent);
+    const Node &p = nodes_[n.parent];
+    if (sib_is_suffix)
+      ops_.mttv(p.buf, n.elems, J, 1, f, nf, R_, n.buf, n.elems, 0);
+    else
+      ops_.mttv(p.buf, 1, J, n.elems, f, nf, R_, n.buf, n.elems, 0);
+  }
+  n.valid = true;
+}
+
+void CpEngine::refresh_grams() {
+  for (int i = 0; i < N_; i++)
+    ops_.gram(W_[i], V_.glens[i], V_.glens[i], R_, G_ + (size_t)i * R_ * R_);
+}
+
+void CpEngine::set_factors(const double *Wflat, const double *gradWflat) {
+  const double *w = Wflat, *g = gradWflat;
+  double gs = 0;
+  for (int i = 0; i < N_; i++) {
+    size_t n = (size_t)V_.glens[i] * R_;
+    ops_.h2d(W_[i], w, n * sizeof(double));
+    w += n;
+    if (g) {
+      ops_.h2d(gradW_[i], g, n * sizeof(double));
+      for (size_t e = 0; e < n; e++) gs += g[e] * g[e];
+      g += n;
+    }
+  }
+  // iter-0 [gradnorm] is the norm of the caller's initial grad_W (test_ALS.cxx:338,
+  // als_CP.cxx:174-181)
+  init_gradnorm_ = std::sqrt(gs);
+  grad_from_sweep_ = false;
+  refresh_grams();
+  for (auto &n : nodes_) n.valid = false;
+}
+
+void CpEngine::get_factors(double *Wflat, double *gradWflat) {
+  double *w = Wflat, *g = gradWflat;
+  for (int i = 0; i < N_; i++) {
+    size_t n = (size_t)V_.glens[i] * R_;
+    if (w) {
+      ops_.d2h(w, W_[i], n * sizeof(double));
+      w += n;
+    }
+    if (g) {
+      if (P_ > 1 && grad_from_sweep_) {
+        // every rank holds only its own row block of grad_W: gather it
+        const int64_t blk = block_rows(V_.glens[i], P_);
+        ops_.pack_blocks(gradW_[i], V_.glens[i], V_.glens[i], R_, blk, P_, gatherbuf_);
+        comm_.allgather(gatherbuf_ + (size_t)rank_ * blk * R_, gatherbuf_, blk * R_);
+        ops_.unpack_blocks(gatherbuf_, V_.glens[i], V_.glens[i], R_, blk, P_, gradW_[i]);
+      }
+      ops_.d2h(g, gradW_[i], n * sizeof(double));
+      g += n;
+    }
+  }
+}
+
+// one mode update: K4 (S), K5 (gradient with the pre-update W), K6 (solve), Gram refresh;
+// with P > 1 ranks: C1 reduce-scatter of the partial rows, C2 all-gather of the updated rows.
+void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, bool pp,
+                           double ratio) {
+  const int64_t s = V_.glens[i];
+  double *Gi = G_ + (size_t)i * R_ * R_;
+  ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
+  if (P_ == 1) {
+    ops_.cp_update(M, ldm, W_[i], s, W_[i], s, gradW_[i], s, s, R_, S_, Sinv_, gradsq_ + i,
+                   pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio);
+  } else {
+    const int64_t blk = block_rows(s, P_);
+    const int64_t r0 = blk * rank_;
+    const int64_t nr = std::max<int64_t>(0, std::min(blk, s - r0));
+    const double *Mblk;
+    int64_t ldb;
+    if (i == 0) {  // rows of mode 0 are complete on their owner
+      Mblk = M;
+      ldb = ldm;
+    } else {
+      ops_.pack_blocks(M, s, ldm, R_, blk, P_, sendbuf_);
+      comm_.reduce_scatter_sum(sendbuf_, recvbuf_, blk * R_);
+      Mblk = recvbuf_;
+      ldb = blk;
+    }
+    double *mine = gatherbuf_ + (size_t)rank_ * blk * R_;
+    ops_.cp_update(Mblk, ldb, W_[i] + r0, s, mine, blk, gradW_[i] + r0, s, nr, R_, S_, Sinv_,
+                   gradsq_ + i, nullptr, 0, nullptr, 0, 1.0);
+    comm_.allgather(mine, gatherbuf_, blk * R_);
+    ops_.unpack_blocks(gatherbuf_, s, s, R_, blk, P_, W_[i]);
+    if (pp) {
+      // SVD_solve_mod tail (common.cxx:753-756) on the gathered factor
+      double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
+      int64_t n[1] = {s * R_};
+      if (ratio != 1.0)
+        throw std::runtime_error("ppals: -magni != 1 is not supported on more than one GPU yet");
+      ops_.diff_norms(A, B, n, 1, 1, D, 0, scal_ + 2 * MAX_ORDER);
+    }
+  }
+  ops_.gram(W_[i], s, s, R_, Gi);
+}
+
+void CpEngine::normalize() {
+  int64_t rows[MAX_ORDER];
+  for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
+  ops_.normalize(W_.data(), rows, N_, R_, G_);
+}
+
+void CpEngine::sweep_dt(double lambda) {
+  for (auto &n : nodes_) n.valid = false;  // mttkrp_map.clear(), als_CP.cxx:215
+  for (int i = 0; i < N_; i++) {
+    compute_node(leaf_[i]);
+    const Node &lf = nodes_[leaf_[i]];
+    mode_update(i, lf.buf, ext(i), lambda, false, 1.0);
+    // every cached node that does NOT contain mode i stays valid; nodes containing mode i were
+    // built from W_j, j != i only, so they stay valid too until the cache is cleared.
+  }
+  normalize();
+  grad_from_sweep_ = true;
+}
+
+double CpEngine::allreduce_scalar(double x) {
+  if (P_ == 1) return x;
+  ops_.h2d(scal_, &x, sizeof(double));
+  comm_.allreduce_sum(scal_, 1);
+  double y = 0;
+  ops_.d2h(&y, scal_, sizeof(double));
+  return y;
+}
+
+double CpEngine::gradnorm() {
+  if (!grad_from_sweep_) return init_gradnorm_;
+  double h[MAX_ORDER];
+  ops_.d2h(h, gradsq_, sizeof(double) * N_);
+  double s = 0;
+  for (int i = 0; i < N_; i++) s += h[i];
+  return std::sqrt(allreduce_scalar(s));
+}
+
+double CpEngine::residual() {
+  int64_t M, K;
+  split_sizes(V_, &M, &K);
+  if (!Qbuf_) Qbuf_ = (double *)ops_.alloc(sizeof(double) * M * R_);
+  if (!Pbuf_) Pbuf_ = (double *)ops_.alloc(sizeof(double) * K * R_);
+  split_krp(ops_, V_, R_, W_.data(), Qbuf_, Pbuf_, &M, &K);
+  ops_.residual_sq(V_.data, V_.dtype, M, K, Qbuf_, Pbuf_, R_, scal_);
+  if (P_ > 1) comm_.allreduce_sum(scal_, 1);
+  double h = 0;
+  ops_.d2h(&h, scal_, sizeof(double));
+  return std::sqrt(h);
+}
+
+// ---------------------------------------------------------------------------- kernel-level access
+static bool parse_range(const std::string &key, int N, int *lo, int *hi) {
+  if (key.empty()) return false;
+  *lo = key[0] - 'a';
+  *hi = key.back() - 'a';
+  if (*lo < 0 || *hi >= N || *hi - *lo + 1 != (int)key.size()) return false;
+  for (size_t k = 0; k < key.size(); k++)
+    if (key[k] != 'a' + *lo + (int)k) return false;
+  return true;
+}
+int64_t CpEngine::tree_node(const std::string &key, double *out_host) {
+  int lo, hi;
+  if (!parse_range(key, N_, &lo, &hi)) return -1;
+  int idx = find_node(lo, hi);
+  if (idx < 0) return -1;
+  for (auto &n : nodes_) n.valid = false;
+  compute_node(idx);
+  const Node &n = nodes_[idx];
+  if (out_host) ops_.d2h(out_host, n.buf, sizeof(double) * (size_t)n.elems * R_);
+  return n.elems * R_;
+}
+void CpEngine::mttkrp(int mode, double *M_host) {
+  for (auto &n : nodes_) n.valid = false;
+  compute_node(leaf_[mode]);
+  const Node &lf = nodes_[leaf_[mode]];
+  const int64_t s = V_.glens[mode];
+  if (P_ == 1) {
+    ops_.d2h(M_host, lf.buf, sizeof(double) * s * R_);
+    return;
+  }
+  const int64_t blk = block_rows(s, P_);
+  if (mode == 0) {
+    ops_.zero(sendbuf_, sizeof(double) * blk * P_ * R_);
+    // place the owner's complete rows into its block, then sum (other blocks are zero)
+    double *mine = sendbuf_ + (size_t)rank_ * blk * R_;
+    for (int r = 0; r < R_; r++)
+      ops_.d2d(mine + (size_t)r * blk, lf.buf + (size_t)r * ext(0), sizeof(double) * ext(0));
+  } else {
+    ops_.pack_blocks(lf.buf, s, s, R_, blk, P_, sendbuf_);
+  }
+  comm_.allreduce_sum(sendbuf_, blk * P_ * R_);
+  double *nat = (double *)ops_.alloc(sizeof(double) * s * R_);
+  ops_.unpack_blocks(sendbuf_, s, s, R_, blk, P_, nat);
+  ops_.d2h(M_host, nat, sizeof(double) * s * R_);
+  ops_.free(nat);
+}
+void CpEngine::gram_system(int mode, double lambda, double *S_host, double *Sinv_host) {
+  ops_.gram_system(G_, N_, mode, R_, lambda, S_, Sinv_);
+  ops_.d2h(S_host, S_, sizeof(double) * R_ * R_);
+  ops_.d2h(Sinv_host, Sinv_, sizeof(double) * R_ * R_);
+}
+
+// ---------------------------------------------------------------------------- PP operators
+// Build_mttkrp_map (als_CP.cxx:352-409): key = contracted modes in ascending order; built by
+// dropping the last contracted mode. Level 1 scans V (K8), deeper levels contract the cache.
+const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
+  auto it = pp_.find(seq);
+  if (it != pp_.end()) return it->second;
+  const int mode = seq.back() - 'a';
+  PPOp op;
+  FactorRef f = fref(mode, W_.data());
+  if (seq.size() == 1) {
+    int64_t L = 1, T = 1;
+    for (int m = 0; m < N_; m++) {
+      if (m < mode) L *= ext(m);
+      if (m > mode) T *= ext(m);
+      if (m != mode) op.modes.push_back(m);
+    }
+    op.elems = L * T;
+    op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
+    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, op.elems);
+  } else {
+    const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
+    int64_t L = 1, T = 1;
+    for (int m : par.modes) {
+      if (m < mode) L *= ext(m);
+      if (m > mode) T *= ext(m);
+      if (m != mode) op.modes.push_back(m);
+    }
+    op.elems = L * T;
+    op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
+    ops_.mttv(par.buf, L, ext(mode), T, &f, 1, R_, op.buf, op.elems, 0);
+  }
+  pp_[seq] = op;
+  return pp_[seq];
+}
+void CpEngine::pp_clear() {
+  for (auto &kv : pp_) ops_.free(kv.second.buf);
+  pp_.clear();
+}
+static std::string all_but(int N, int i, int j = -1) {
+  std::string s;
+  for (int m = 0; m < N; m++)
+    if (m != i && m != j) s.push_back((char)('a' + m));
+  return s;
+}
+// als_CP.cxx:678-694: all pair operators, then all N full MTTKRPs
+void CpEngine::pp_build_all() {
+  pp_clear();
+  for (int ii = 0; ii < N_; ii++)
+    for (int jj = ii + 1; jj < N_; jj++) pp_get(all_but(N_, ii, jj));
+  for (int ii = 0; ii < N_; ii++) pp_get(all_but(N_, ii));
+}
+int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
+  for (size_t k = 0; k < contracted.size(); k++) {
+    int m = contracted[k] - 'a';
+    if (m < 0 || m >= N_ || (k > 0 && contracted[k] <= contracted[k - 1])) return -1;
+  }
+  if (contracted.empty() || (int)contracted.size() >= N_) return -1;
+  pp_clear();
+  const PPOp &op = pp_get(contracted);
+  if (out_host) ops_.d2h(out_host, op.buf, sizeof(double) * (size_t)op.elems * R_);
+  int64_t n = op.elems * R_;
+  pp_clear();
+  return n;
+}
+
+// one approximate sweep: als_CP.cxx:754-825
+void CpEngine::sweep_pp(double lambda, double ratio) {
+  if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+  for (int i = 0; i < N_; i++) {
+    const int64_t si = ext(i);
+    const PPOp &M0 = pp_get(all_but(N_, i));
+    ops_.d2d(Mbuf_, M0.buf, sizeof(double) * si * R_);
+    for (int ii = 0; ii < N_; ii++) {
+      if (ii == i) continue;
+      const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
+      FactorRef f = fref(ii, dW_.data());
+      if (ii < i)  // T[ii, i, r]   (als_CP.cxx:785)
+        ops_.mttv(T.buf, 1, ext(ii), si, &f, 1, R_, Mbuf_, si, 1);
+      else  // T[i, ii, r]   (als_CP.cxx:793)
+        ops_.mttv(T.buf, si, ext(ii), 1, &f, 1, R_, Mbuf_, si, 1);
+    }
+    mode_update(i, Mbuf_, si, lambda, true, ratio);
+  }
+  normalize();
+  grad_from_sweep_ = true;
+}
+
+// ---------------------------------------------------------------------------- drivers
+static void csv_row(std::ofstream *csv, int64_t dim, int iter, double gradnorm, double tol, int pp,
+                    double diffV, double dtime) {
+  if (!csv) return;
+  (*csv) << dim << "," << iter << "," << gradnorm << "," << tol << "," << pp << "," << diffV << ","
+         << dtime << "\n";
+  if (iter % 100 == 0 && iter != 0) (*csv) << std::endl;  // als_CP.cxx:199-201
+}
+
+// print block: als_CP.cxx:166-213 / :457-498 / :697-752. Its own duration is subtracted from the
+// elapsed time exactly as the reference does (st_time += ...).
+bool CpEngine::print_block(const CpOpts &o, int iter, int pp_flag, double &projnorm, double &diffV,
+                           std::ofstream *csv) {
+  ops_.sync();  // the sweeps enqueued so far belong to [dtime]
+  const double st_time1 = now();
+  projnorm = gradnorm();
+  diffV = residual();
+  st_time_ += now() - st_time1;
+  const double dtime = now() - st_time_;
+  if (rank_ == 0) {
+    if (o.verbose) {
+      std::cout.precision(13);
+      std::cout << "  [dim]=  " << V_.glens[0] << "  [iter]=  " << iter << "  [gradnorm]  "
+                << projnorm << "  [tol]  " << o.tol << "  [pp_update]  " << pp_flag
+                << "  [diffV]  " << diffV << "  [dtime]  " << dtime << "\n";
+    }
+    csv_row(csv, V_.glens[0], iter, projnorm, o.tol, pp_flag, diffV, dtime);
+  }
+  return (projnorm < o.tol) || (now() - st_time_ > o.timelimit);
+}
+
+int CpEngine::run_dt(const CpOpts &o, int *iters) {
+  std::ofstream csv;
+  std::ofstream *pcsv = nullptr;
+  if (rank_ == 0 && !o.csv_path.empty()) {
+    csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
+    pcsv = &csv;
+    if (!o.bench) csv << "[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]\n";
+  }
+  st_time_ = now();
+  double projnorm = 0, diffV = 1000;
+  int iter;
+  for (iter = 0; iter <= o.maxiter; iter++) {
+    if (iter % o.resprint == 0 || iter == o.maxiter) {
+      if (!o.bench) {
+        if (print_block(o, iter, 0, projnorm, diffV, pcsv)) break;
+      } else {
+        // pp_bench mode (als_CP.cxx:203-209): only the elapsed time of the sweep is reported
+        ops_.sync();
+        const double st_time1 = now();
+        projnorm = gradnorm();
+        diffV = residual();
+        st_time_ += now() - st_time1;
+        const double dtime = now() - st_time_;
+        if (rank_ == 0 && iter != 0) {
+          if (o.verbose) std::cout << "  [dimension tree step time]  " << dtime << "\n";
+          if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
+        }
+        if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+      }
+    }
+    sweep_dt(o.lambda);
+    if (iter % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+  ops_.sync();
+  if (rank_ == 0 && o.verbose) {
+    printf("\nIter = %d Final proj-grad norm %E \n", iter, projnorm);
+    printf("tf took %lf seconds\n", now() - st_time_);
+  }
+  if (pcsv) csv.close();
+  if (iters) *iters = iter;
+  return iter == o.maxiter + 1 ? 0 : 1;
+}
+
+// ||dW_i||^2 and ||W_i||^2 for all modes. dt_phase: dW = W - W_prev, W_prev = W (als_CP.cxx:594-
+// 603); otherwise dW as left by the PP updates (als_CP.cxx:659-663).
+void CpEngine::read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw) {
+  int64_t n[MAX_ORDER];
+  for (int i = 0; i < N_; i++) n[i] = V_.glens[i] * R_;
+  if (dt_phase)
+    ops_.diff_norms(W_.data(), Wprev_.data(), n, N_, 1, dW_.data(), 1, scal_);
+  else
+    ops_.diff_norms(W_.data(), nullptr, n, N_, 0, dW_.data(), 0, scal_);
+  double h[2 * MAX_ORDER];
+  ops_.d2h(h, scal_, sizeof(double) * 2 * N_);
+  nd.resize(N_);
+  nw.resize(N_);
+  for (int i = 0; i < N_; i++) {
+    nd[i] = std::sqrt(h[2 * i]);
+    nw[i] = std::sqrt(h[2 * i + 1]);
+  }
+}
+
+double CpEngine::dt_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv) {
+  double diffV = 1000;
+  for (int i = 0; i < N_; i++)  // W_prev starts at zero (als_CP.cxx:428-431)
+    ops_.zero(Wprev_[i], sizeof(double) * V_.glens[i] * R_);
+  std::vector<double> nd, nw;
+  for (; iter <= o.maxiter; iter++) {
+    if (iter % o.resprint == 0 || iter == o.maxiter) {
+      if (print_block(o, iter, 0, projnorm, diffV, csv)) break;
+    }
+    sweep_dt(o.lambda);
+    read_norms(true, nd, nw);
+    int num_dw_break = 0;
+    for (int i = 0; i < N_; i++)
+      if (std::fabs(nd[i] / nw[i]) < o.tol_init) num_dw_break++;
+    if (num_dw_break == N_) return diffV;  // iter is NOT incremented (als_CP.cxx:604-605)
+    if (iter % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+  return diffV;
+}
+
+double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv) {
+  const int init_iter = iter;
+  double diffV = 1000;
+  double dtime_first = 0;
+  std::vector<double> nd, nw;
+  for (; iter <= o.maxiter; iter++) {
+    int num_dw_break = 0;
+    if (!o.bench) {
+      read_norms(false, nd, nw);
+      for (int i = 0; i < N_; i++)
+        if (std::fabs(nd[i] / nw[i]) > o.tol_init) num_dw_break++;
+    }
+    if ((iter - init_iter) % 15 == 0 || num_dw_break > 0) {
+      if (num_dw_break > 0 || iter != init_iter) return diffV;
+      for (int j = 0; j < N_; j++) {  // W_init = W, dW = 0 (als_CP.cxx:672-675)
+        size_t n = sizeof(double) * V_.glens[j] * R_;
+        ops_.d2d(Winit_[j], W_[j], n);
+        ops_.zero(dW_[j], n);
+      }
+      pp_build_all();
+    }
+    if (iter % o.resprint == 0 || iter == o.maxiter || iter == init_iter) {
+      if (!o.bench) {
+        if (print_block(o, iter, 1, projnorm, diffV, csv)) break;
+      } else {
+        // pp_bench mode (als_CP.cxx:735-748)
+        ops_.sync();
+        const double st_time1 = now();
+        projnorm = gradnorm();
+        diffV = residual();
+        st_time_ += now() - st_time1;
+        const double dtime = now() - st_time_;
+        if (iter != o.maxiter) {
+          dtime_first = dtime;
+          st_time_ = now();
+        } else {
+          dtime_first = dtime_first + dtime;
+          if (rank_ == 0) {
+            if (o.verbose) {
+              std::cout << "  [PP first time]  " << dtime_first << "\n";
+              std::cout << "  [PP second time]  " << dtime << "\n";
+            }
+            if (csv) {
+              (*csv) << "  [PPfirst]  " << "," << dtime_first << "\n";
+              (*csv) << "  [PPsecond]  " << "," << dtime << "\n";
+            }
+          }
+        }
+        if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+      }
+    }
+    sweep_pp(o.lambda, o.ratio_step);
+    if (iter % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+  if (o.bench) iter++;
+  return diffV;
+}
+
+int CpEngine::run_pp(const CpOpts &o, int *iters) {
+  std::ofstream csv;
+  std::ofstream *pcsv = nullptr;
+  if (rank_ == 0 && !o.csv_path.empty()) {
+    csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
+    pcsv = &csv;
+    if (!o.bench) csv << "[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]\n";
+  }
+  for (int i = 0; i < N_; i++) {
+    size_t n = sizeof(double) * V_.glens[i] * R_;
+    if (!Wprev_[i]) Wprev_[i] = (double *)ops_.alloc(n);
+    if (!Winit_[i]) Winit_[i] = (double *)ops_.alloc(n);
+    if (!dW_[i]) dW_[i] = (double *)ops_.alloc(n);
+    ops_.zero(dW_[i], n);
+  }
+  st_time_ = now();
+  int iter = 0;
+  double gradnorm_v = 10.;
+  while (gradnorm_v > o.tol && iter <= o.maxiter) {
+    if (!o.bench) {
+      if (rank_ == 0 && o.verbose) printf("DT starts from %d\n", iter);
+      dt_sub(o, gradnorm_v, iter, pcsv);
+    }
+    if (rank_ == 0 && o.verbose) printf("pairwise perturbation starts from %d\n", iter);
+    pp_sub(o, gradnorm_v, iter, pcsv);
+    // deviation from the reference: a timelimit hit terminates instead of looping forever
+    // (als_CP.cxx:1105 with breaks at :496 and :750)
+    if (now() - st_time_ > o.timelimit) break;
+  }
+  ops_.sync();
+  pp_clear();
+  if (rank_ == 0 && o.verbose) {
+    printf("\nIter = %d Final grad norm %E \n", iter, gradnorm_v);
+    printf("tf took %lf seconds\n", now() - st_time_);
+  }
+  if (pcsv) csv.close();
+  if (iters) *iters = iter;
+  return iter == o.maxiter + 1 ? 0 : 1;
+}
+
+}  // namespace ppals

@@ -1,0 +1,129 @@
+// engine.h — ALS sweep engine for CP (dimension tree + pairwise perturbation) written against the
+// abstract Ops/Comm interfaces (ops.h). Pure host control flow: which contraction, which cache,
+// which collective, when to restart — the part the reference implements in als_CP.cxx.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ops.h"
+
+namespace ppals {
+
+struct TensorDesc {
+  int order = 0;
+  int64_t glens[MAX_ORDER];  // global extents
+  int64_t llens[MAX_ORDER];  // local extents (differs from glens only in mode 0)
+  int64_t row0 = 0;          // first leading-mode row owned by this rank
+  int dtype = F32;
+  void *data = nullptr;
+  int64_t nloc = 0;
+};
+
+// leading-mode block partition shared by the tensor shard and the factor-matrix row blocks
+inline int64_t block_rows(int64_t s, int P) { return (s + P - 1) / P; }
+
+int tensor_create(Ops &ops, Comm &comm, int order, const int64_t *glens, int dtype,
+                  TensorDesc *out, std::string *err);
+void tensor_fill_cp(Ops &ops, const TensorDesc &V, int R, const double *Wtrue_flat);
+void tensor_fill_uniform(Ops &ops, const TensorDesc &V, uint64_t seed, double lo, double hi);
+void tensor_upload(Ops &ops, const TensorDesc &V, const double *host_full);
+double tensor_norm(Ops &ops, Comm &comm, const TensorDesc &V);
+
+struct CpOpts {
+  double tol = 0, timelimit = 5e3;
+  int maxiter = 0;
+  double lambda = 0;
+  int resprint = 10;
+  int bench = 0;
+  double tol_init = 1e-2, ratio_step = 1.0;
+  std::string csv_path;
+  bool csv_append = false;
+  bool verbose = false;
+};
+
+class CpEngine {
+ public:
+  CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R);
+  ~CpEngine();
+
+  void set_factors(const double *Wflat, const double *gradWflat);
+  void get_factors(double *Wflat, double *gradWflat);
+
+  // body of the reference's sweep loop: als_CP.cxx:215-303 (clear cache, N mode updates,
+  // Normalize). Asynchronous on the Ops stream.
+  void sweep_dt(double lambda);
+  double gradnorm();  // sqrt(sum_i ||grad_W[i]||^2), als_CP.cxx:174-181; synchronises
+  double residual();  // ||V - [[W]]||_F, als_CP.cxx:183-187; synchronises
+
+  // kernel-level access for parity tests
+  int64_t tree_node(const std::string &key, double *out_host);
+  void mttkrp(int mode, double *M_host);
+  int64_t pp_operator(const std::string &contracted, double *out_host);
+  void gram_system(int mode, double lambda, double *S_host, double *Sinv_host);
+
+  // drivers
+  int run_dt(const CpOpts &o, int *iters);  // alsCP_DT, als_CP.cxx:127-320
+  int run_pp(const CpOpts &o, int *iters);  // alsCP_PP, als_CP.cxx:1082-1137
+
+  int order() const { return N_; }
+  int rank_r() const { return R_; }
+
+ private:
+  struct Node {
+    int lo, hi;
+    int parent = -1;   // index into nodes_, -1: parent is the root
+    int slo, shi;      // sibling range
+    double *buf = nullptr;
+    int64_t elems = 0;  // without the rank index
+    bool valid = false;
+  };
+  struct PPOp {
+    double *buf = nullptr;
+    int64_t elems = 0;
+    std::vector<int> modes;  // remaining modes (ascending)
+  };
+
+  int64_t ext(int m) const { return m == 0 ? V_.llens[0] : V_.glens[m]; }
+  FactorRef fref(int m, double *const *W) const;
+  int64_t prod_ext(int lo, int hi) const;
+  void build_tree(int lo, int hi, int parent);
+  int find_node(int lo, int hi) const;
+  void compute_node(int idx);
+  void refresh_grams();
+  void mode_update(int i, const double *M, int64_t ldm, double lambda, bool pp, double ratio);
+  void normalize();
+  const PPOp &pp_get(const std::string &seq);
+  void pp_clear();
+  void pp_build_all();
+  void sweep_pp(double lambda, double ratio);
+  double allreduce_scalar(double x);
+  void read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw);
+  bool print_block(const CpOpts &o, int iter, int pp_flag, double &projnorm, double &diffV,
+                   std::ofstream *csv);
+  double dt_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv);
+  double pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv);
+
+  Ops &ops_;
+  Comm &comm_;
+  TensorDesc V_;
+  int N_, R_, P_, rank_;
+  std::vector<double *> W_, gradW_, Wprev_, Winit_, dW_;
+  double *G_ = nullptr;       // N Gram matrices, R*R each
+  double *S_ = nullptr, *Sinv_ = nullptr;
+  double *gradsq_ = nullptr;  // per-mode local sum of grad^2 (device)
+  double *scal_ = nullptr;    // small device scalar scratch (>= 4*MAX_ORDER)
+  double *sendbuf_ = nullptr, *recvbuf_ = nullptr, *gatherbuf_ = nullptr;
+  double *Mbuf_ = nullptr;    // PP: M_i^0 + corrections
+  double *Qbuf_ = nullptr, *Pbuf_ = nullptr;  // residual KRP operands
+  int64_t maxs_ = 0, maxblk_ = 0;
+  std::vector<Node> nodes_;
+  std::vector<int> leaf_;  // node index of each leaf
+  std::map<std::string, PPOp> pp_;
+  bool grad_from_sweep_ = false;
+  double init_gradnorm_ = 0;
+  double st_time_ = 0;
+};
+
+}  // namespace ppals

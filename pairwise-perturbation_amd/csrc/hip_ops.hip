@@ -1,0 +1,508 @@
+// hip_ops.hip — the product implementation of ppals::Ops: hand-written HIP kernels for gfx950,
+// launched on one engine-owned stream. No CPU fallback: construction throws without a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hip_ops.h"
+#include "kernels_scan.hip.h"
+#include "kernels_small.hip.h"
+
+namespace ppals {
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + \
+                               __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");  \
+  } while (0)
+
+static inline int grid_for(int64_t n, int block, int cap = 4096) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+class HipOps : public Ops {
+ public:
+  explicit HipOps(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      throw std::runtime_error(
+          "ppals: no HIP device available (the engine has no CPU fallback; hipGetDeviceCount: " +
+          std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+    if (device < 0 || device >= ndev)
+      throw std::runtime_error("ppals: device index out of range");
+    dev_ = device;
+    HIP_CHECK(hipSetDevice(dev_));
+    HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
+    ncu_ = prop.multiProcessorCount;
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  }
+  ~HipOps() override {
+    hipSetDevice(dev_);
+    hipStreamSynchronize(st_);
+    for (auto &ev : events_) {
+      hipEventDestroy(ev.a);
+      hipEventDestroy(ev.b);
+    }
+    if (ws_pack_) hipFree(ws_pack_);
+    if (ws_slab_) hipFree(ws_slab_);
+    if (ws_krp_) hipFree(ws_krp_);
+    if (ws_part_) hipFree(ws_part_);
+    if (ws_small_) hipFree(ws_small_);
+    hipStreamDestroy(st_);
+  }
+
+  void *alloc(size_t bytes) override {
+    void *p = nullptr;
+    HIP_CHECK(hipSetDevice(dev_));
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+    return p;
+  }
+  void free(void *p) override {
+    if (p) {
+      hipStreamSynchronize(st_);
+      hipFree(p);
+    }
+  }
+  void h2d(void *dst, const void *src, size_t bytes) override {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  void d2h(void *dst, const void *src, size_t bytes) override {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  void d2d(void *dst, const void *src, size_t bytes) override {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st_));
+  }
+  void zero(void *p, size_t bytes) override { HIP_CHECK(hipMemsetAsync(p, 0, bytes, st_)); }
+  void sync() override { HIP_CHECK(hipStreamSynchronize(st_)); }
+  void *stream() override { return (void *)st_; }
+
+  // ------------------------------------------------------------------ generation / norms
+  void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                    uint64_t seed, double lo, double hi) override {
+    int64_t n = l0 * rest;
+    int g = grid_for(n, 256, 16384);
+    if (dt == F32)
+      hipLaunchKernelGGL(k_fill_uniform<float>, dim3(g), dim3(256), 0, st_, (float *)V, l0, g0,
+                         row0, rest, seed, lo, hi);
+    else
+      hipLaunchKernelGGL(k_fill_uniform<double>, dim3(g), dim3(256), 0, st_, (double *)V, l0, g0,
+                         row0, rest, seed, lo, hi);
+    HIP_CHECK(hipGetLastError());
+  }
+
+  template <typename TV, int MODE>
+  void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
+                   double *out) {
+    if (R > 64)
+      throw std::runtime_error("ppals: fill_rank/residual support R <= 64 in this version");
+    int kch = 32;
+    while ((K + kch - 1) / kch > 65535) kch *= 2;
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((K + kch - 1) / kch));
+    double *part = nullptr;
+    int64_t npart = (int64_t)grid.x * grid.y;
+    if (MODE != 0) part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
+    TV *v = (TV *)V;
+    if (R <= 16)
+      hipLaunchKernelGGL((k_rank_stream<TV, 16, MODE>), grid, dim3(256), 0, st_, v, M, K, Q, P, R,
+                         kch, part);
+    else if (R <= 32)
+      hipLaunchKernelGGL((k_rank_stream<TV, 32, MODE>), grid, dim3(256), 0, st_, v, M, K, Q, P, R,
+                         kch, part);
+    else
+      hipLaunchKernelGGL((k_rank_stream<TV, 64, MODE>), grid, dim3(256), 0, st_, v, M, K, Q, P, R,
+                         kch, part);
+    HIP_CHECK(hipGetLastError());
+    if (MODE != 0) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, (int)npart, out);
+      HIP_CHECK(hipGetLastError());
+    }
+  }
+  void fill_rank(void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
+                 int R) override {
+    if (dt == F32)
+      rank_stream<float, 0>(V, M, K, Q, P, R, nullptr);
+    else
+      rank_stream<double, 0>(V, M, K, Q, P, R, nullptr);
+  }
+  void residual_sq(const void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
+                   int R, double *out) override {
+    void *v = const_cast<void *>(V);
+    if (Q == nullptr) {
+      if (dt == F32)
+        rank_stream<float, 2>(v, M, K, nullptr, nullptr, 0, out);
+      else
+        rank_stream<double, 2>(v, M, K, nullptr, nullptr, 0, out);
+    } else {
+      if (dt == F32)
+        rank_stream<float, 1>(v, M, K, Q, P, R, out);
+      else
+        rank_stream<double, 1>(v, M, K, Q, P, R, out);
+    }
+  }
+  void upload_shard(void *V, int dt, const double *host_full, int64_t l0, int64_t g0,
+                    int64_t row0, int64_t rest) override {
+    // stage `chunk` columns (each l0 contiguous rows of the shard) at a time through a device
+    // fp64 buffer, converting to the tensor's storage type on the device
+    const int64_t chunk_cols = std::max<int64_t>(1, (int64_t)(64 << 20) / (8 * l0));
+    std::vector<double> host((size_t)(chunk_cols * l0));
+    double *stage = (double *)alloc(sizeof(double) * chunk_cols * l0);
+    for (int64_t c0 = 0; c0 < rest; c0 += chunk_cols) {
+      int64_t nc = std::min(chunk_cols, rest - c0);
+      for (int64_t c = 0; c < nc; c++)
+        std::copy(host_full + (c0 + c) * g0 + row0, host_full + (c0 + c) * g0 + row0 + l0,
+                  host.begin() + c * l0);
+      h2d(stage, host.data(), sizeof(double) * nc * l0);
+      int64_t n = nc * l0;
+      if (dt == F32)
+        hipLaunchKernelGGL(k_convert_rows<float>, dim3(grid_for(n, 256)), dim3(256), 0, st_,
+                           (float *)V + c0 * l0, stage, n);
+      else
+        hipLaunchKernelGGL(k_convert_rows<double>, dim3(grid_for(n, 256)), dim3(256), 0, st_,
+                           (double *)V + c0 * l0, stage, n);
+      HIP_CHECK(hipGetLastError());
+      sync();
+    }
+    free(stage);
+  }
+
+  // ------------------------------------------------------------------ KRP
+  static KrpArgs krp_args(const FactorRef *f, int nf, int64_t *J) {
+    KrpArgs a;
+    int64_t j = 1;
+    if (nf > MAX_ORDER) throw std::runtime_error("ppals: too many Khatri-Rao factors");
+    for (int i = 0; i < nf; i++) {
+      a.ptr[i] = f[i].ptr;
+      a.rows[i] = f[i].rows;
+      a.ld[i] = f[i].ld;
+      j *= f[i].rows;
+    }
+    a.nf = nf;
+    *J = j;
+    return a;
+  }
+  void krp(double *out, const FactorRef *f, int nf, int col0, int ncols) override {
+    int64_t J;
+    KrpArgs a = krp_args(f, nf, &J);
+    hipLaunchKernelGGL(k_krp, dim3(grid_for(J * ncols, 256)), dim3(256), 0, st_, out, a, J, col0,
+                       ncols);
+    HIP_CHECK(hipGetLastError());
+  }
+
+  // ------------------------------------------------------------------ scans
+  template <typename TV>
+  void scan_t(const TV *V, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
+              double *out, int64_t out_rstride) {
+    constexpr int VEC = ScanTraits<TV>::VEC;
+    int64_t Jc;
+    KrpArgs a = krp_args(f, nf, &Jc);
+    if (Jc != J) throw std::runtime_error("ppals: scan_contract factor extents do not match J");
+    const bool aligned_base = (((uintptr_t)V) & 15) == 0;
+    for (int col0 = 0; col0 < R; col0 += 64) {
+      const int ncols = std::min(64, R - col0);
+      const int NT = ncols <= 16 ? 1 : (ncols <= 32 ? 2 : 4);
+      const int64_t nblk64 = (J + 4 * VEC - 1) / (4 * VEC);
+      if (nblk64 > 0x7fffffff) throw std::runtime_error("ppals: contraction extent too large");
+      const int nblk = (int)nblk64;
+      const size_t pack_bytes = (size_t)nblk * NT * 4 * 16 * VEC * sizeof(TV);
+      TV *P = (TV *)ensure(ws_pack_, ws_pack_sz_, pack_bytes);
+      const bool prefix = (L == 1);
+      hipLaunchKernelGGL(k_krp_pack<TV>, dim3(grid_for((int64_t)nblk * NT * 64 * VEC, 256)),
+                         dim3(256), 0, st_, P, nblk, NT, prefix ? 1 : 0, a, J, col0, ncols);
+      HIP_CHECK(hipGetLastError());
+      double *o = out + (int64_t)col0 * out_rstride;
+      const double bytes = (double)L * (double)J * (double)T * sizeof(TV);
+      if (prefix) {
+        // out[t + rs*n] = sum_j V[j + J*t] * B[j,n]      (M = J rows reduced, K = T columns)
+        const int64_t M = J, K = T;
+        const bool al = aligned_base && (M % VEC == 0);
+        const int64_t ncolgrp = (K + 63) / 64;
+        int nsplit = 1;
+        const int target = ncu_ * 4;
+        if (ncolgrp < target) nsplit = (int)std::min<int64_t>((target + ncolgrp - 1) / ncolgrp,
+                                                              std::max(1, nblk / 64));
+        if (nsplit < 1) nsplit = 1;
+        const int per = (nblk + nsplit - 1) / nsplit;
+        nsplit = (nblk + per - 1) / per;
+        double *dst = o;
+        int64_t dst_ns = out_rstride, dst_ss = 0;
+        if (nsplit > 1) {
+          dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * K);
+          dst_ns = K;
+          dst_ss = (int64_t)ncols * K;
+        }
+        dim3 grid((unsigned)ncolgrp, (unsigned)nsplit);
+        prof_begin(0, bytes);
+#define LAUNCH_PREFIX(NTv, ALv)                                                               \
+  hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
+                     nblk, dst, dst_ns, dst_ss, ncols)
+        if (al) {
+          if (NT == 1) LAUNCH_PREFIX(1, true);
+          else if (NT == 2) LAUNCH_PREFIX(2, true);
+          else LAUNCH_PREFIX(4, true);
+        } else {
+          if (NT == 1) LAUNCH_PREFIX(1, false);
+          else if (NT == 2) LAUNCH_PREFIX(2, false);
+          else LAUNCH_PREFIX(4, false);
+        }
+#undef LAUNCH_PREFIX
+        prof_end();
+        HIP_CHECK(hipGetLastError());
+        if (nsplit > 1) {
+          hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(K * ncols, 256)), dim3(256), 0, st_, dst,
+                             nsplit, dst_ss, K, ncols, o, out_rstride);
+          HIP_CHECK(hipGetLastError());
+        }
+      } else {
+        // out[l + L*t + rs*n] = sum_j V[l + L*(j + J*t)] * B[j,n]   (M = L rows kept, K = J)
+        const int64_t M = L, K = J;
+        const bool al = aligned_base && (M % VEC == 0);
+        const int64_t n_mtiles64 = (M + 64 * VEC - 1) / (64 * VEC);
+        const int n_mtiles = (int)n_mtiles64;
+        int nsplit = 1;
+        const int target = ncu_ * 8;
+        if (T == 1 && n_mtiles < target)
+          nsplit = (int)std::min<int64_t>((target + n_mtiles - 1) / n_mtiles,
+                                          std::max(1, nblk / 32));
+        if (nsplit < 1) nsplit = 1;
+        const int per = (nblk + nsplit - 1) / nsplit;
+        nsplit = (nblk + per - 1) / per;
+        double *dst = o;
+        int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = L;
+        if (nsplit > 1) {
+          dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M);
+          dst_ns = M;
+          dst_ss = (int64_t)ncols * M;
+          dst_bs = 0;
+        }
+        const int64_t nblocks = (int64_t)n_mtiles * nsplit * T;
+        if (nblocks > 0x7fffffff) throw std::runtime_error("ppals: scan grid too large");
+        dim3 grid((unsigned)nblocks);
+        prof_begin(0, bytes);
+#define LAUNCH_SUFFIX(NTv, ALv)                                                                  \
+  hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+        if (al) {
+          if (NT == 1) LAUNCH_SUFFIX(1, true);
+          else if (NT == 2) LAUNCH_SUFFIX(2, true);
+          else LAUNCH_SUFFIX(4, true);
+        } else {
+          if (NT == 1) LAUNCH_SUFFIX(1, false);
+          else if (NT == 2) LAUNCH_SUFFIX(2, false);
+          else LAUNCH_SUFFIX(4, false);
+        }
+#undef LAUNCH_SUFFIX
+        prof_end();
+        HIP_CHECK(hipGetLastError());
+        if (nsplit > 1) {
+          hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256)), dim3(256), 0, st_, dst,
+                             nsplit, dst_ss, M, ncols, o, out_rstride);
+          HIP_CHECK(hipGetLastError());
+        }
+      }
+    }
+  }
+  void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
+                     int nf, int R, double *out, int64_t out_rstride) override {
+    if (dt == F32)
+      scan_t<float>((const float *)V, L, J, T, f, nf, R, out, out_rstride);
+    else
+      scan_t<double>((const double *)V, L, J, T, f, nf, R, out, out_rstride);
+  }
+
+  void ttm_keep(const void *, int, int64_t, int64_t, int64_t, const double *, int64_t, int,
+                double *) override {
+    throw std::runtime_error("ppals: Tucker ttm_keep not implemented in this build");
+  }
+
+  // ------------------------------------------------------------------ mttv
+  void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
+            double *out, int64_t out_rstride, int accumulate) override {
+    const double *B;
+    int64_t ldb;
+    if (nf == 1) {
+      if (f[0].rows != J) throw std::runtime_error("ppals: mttv factor extent mismatch");
+      B = f[0].ptr;
+      ldb = f[0].ld;
+    } else {
+      double *kb = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * J * R);
+      krp(kb, f, nf, 0, R);
+      B = kb;
+      ldb = J;
+    }
+    prof_begin(1, (double)L * J * T * R * 8.0);
+    if (L == 1) {
+      int64_t nw = T * R;
+      int g = grid_for(nw * 64, 256, 8192);
+      hipLaunchKernelGGL(k_mttv_1, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out,
+                         out_rstride, accumulate);
+    } else {
+      int g = grid_for(L * T * R, 256, 16384);
+      hipLaunchKernelGGL(k_mttv_l, dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb, out,
+                         out_rstride, accumulate);
+    }
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+  }
+
+  // ------------------------------------------------------------------ R x R side
+  void gram(const double *W, int64_t rows, int64_t ld, int R, double *G) override {
+    int npairs = R * (R + 1) / 2;
+    int g = std::min(64, (npairs + 15) / 16);
+    hipLaunchKernelGGL(k_gram, dim3(g), dim3(1024), 0, st_, W, rows, ld, R, G);
+    HIP_CHECK(hipGetLastError());
+  }
+  void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
+                   double *Sinv) override {
+    if (R > 64) throw std::runtime_error("ppals: gram_system supports R <= 64 in this version");
+    size_t lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
+    hipLaunchKernelGGL(k_gram_system, dim3(1), dim3(64), lds, st_, Gall, N, mode, R, lambda, S,
+                       Sinv);
+    HIP_CHECK(hipGetLastError());
+  }
+  void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
+                 int64_t ldn, double *grad, int64_t ldg, int64_t rows, int R, const double *S,
+                 const double *Sinv, double *gradsq, const double *Winit, int64_t ldi, double *dW,
+                 int64_t ldd, double ratio) override {
+    size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R);
+    hipLaunchKernelGGL(k_cp_update, dim3(1), dim3(1024), lds, st_, M, ldm, Wold, ldw, Wnew, ldn,
+                       grad, ldg, rows, R, S, Sinv, gradsq, Winit, ldi, dW, ldd, ratio);
+    HIP_CHECK(hipGetLastError());
+  }
+  void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) override {
+    double *scales = small(MAX_ORDER);
+    hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(64), 0, st_, Gall, N, R, scales);
+    HIP_CHECK(hipGetLastError());
+    PtrsN w;
+    int64_t mx = 1;
+    for (int i = 0; i < N; i++) {
+      w.p[i] = W[i];
+      w.n[i] = rows[i] * R;
+      mx = std::max(mx, w.n[i]);
+    }
+    hipLaunchKernelGGL(k_scale_factors, dim3(grid_for(mx, 256, 64), N), dim3(256), 0, st_, w, N,
+                       scales);
+    HIP_CHECK(hipGetLastError());
+  }
+  void diff_norms(double *const *A, double *const *B, const int64_t *n, int N, int store_diff,
+                  double *const *D, int update_prev, double *out) override {
+    PtrsN a;
+    for (int i = 0; i < N; i++) {
+      a.p[i] = A[i];
+      a.q[i] = B ? B[i] : nullptr;
+      a.d[i] = D ? D[i] : nullptr;
+      a.n[i] = n[i];
+    }
+    hipLaunchKernelGGL(k_diff_norms, dim3(N), dim3(1024), 0, st_, a, store_diff, update_prev, out);
+    HIP_CHECK(hipGetLastError());
+  }
+  void pack_blocks(const double *nat, int64_t rows, int64_t ld, int R, int64_t blk, int P,
+                   double *blocked) override {
+    hipLaunchKernelGGL(k_pack_blocks, dim3(grid_for(blk * R * P, 256)), dim3(256), 0, st_, nat,
+                       rows, ld, R, blk, P, blocked);
+    HIP_CHECK(hipGetLastError());
+  }
+  void unpack_blocks(const double *blocked, int64_t rows, int64_t ld, int R, int64_t blk, int P,
+                     double *nat) override {
+    hipLaunchKernelGGL(k_unpack_blocks, dim3(grid_for(blk * R * P, 256)), dim3(256), 0, st_,
+                       blocked, rows, ld, R, blk, P, nat);
+    HIP_CHECK(hipGetLastError());
+  }
+  void unfold_gram(const void *, int, int64_t, int64_t, int64_t, double *) override {
+    throw std::runtime_error("ppals: Tucker unfold_gram not implemented in this build");
+  }
+  void top_eigvecs(double *, int64_t, int, double *) override {
+    throw std::runtime_error("ppals: Tucker top_eigvecs not implemented in this build");
+  }
+  void sumsq(const double *x, int64_t n, double *out) override {
+    int g = grid_for(n, 256, 1024);
+    double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * g);
+    hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(256), 0, st_, x, n, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, g, out);
+    HIP_CHECK(hipGetLastError());
+  }
+
+  // ------------------------------------------------------------------ profiling
+  void profile_enable(bool on) override { profiling_ = on; }
+  void profile_collect() override {
+    HIP_CHECK(hipStreamSynchronize(st_));
+    for (size_t i = 0; i < nev_; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, events_[i].a, events_[i].b) == hipSuccess) {
+        prof[events_[i].slot].launches += 1;
+        prof[events_[i].slot].ms += ms;
+        prof[events_[i].slot].bytes += events_[i].bytes;
+      }
+    }
+    nev_ = 0;
+  }
+
+ private:
+  struct Ev {
+    hipEvent_t a, b;
+    int slot;
+    double bytes;
+  };
+  void prof_begin(int slot, double bytes) {
+    cur_ = -1;
+    if (!profiling_) return;
+    if (nev_ == events_.size()) {
+      if (events_.size() >= 16384) return;
+      Ev e;
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      events_.push_back(e);
+    }
+    cur_ = (int)nev_++;
+    events_[cur_].slot = slot;
+    events_[cur_].bytes = bytes;
+    hipEventRecord(events_[cur_].a, st_);
+  }
+  void prof_end() {
+    if (cur_ >= 0) hipEventRecord(events_[cur_].b, st_);
+    cur_ = -1;
+  }
+  // grow-only workspace; regrowth synchronises (only happens while shapes are first seen)
+  void *ensure(void *&p, size_t &sz, size_t need) {
+    if (need > sz) {
+      if (p) {
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipFree(p));
+      }
+      size_t n = need + need / 4 + 256;
+      HIP_CHECK(hipMalloc(&p, n));
+      sz = n;
+    }
+    return p;
+  }
+  double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
+
+  int dev_ = 0, ncu_ = 256;
+  hipStream_t st_ = nullptr;
+  void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
+       *ws_small_ = nullptr;
+  size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0;
+  bool profiling_ = false;
+  std::vector<Ev> events_;
+  size_t nev_ = 0;
+  int cur_ = -1;
+};
+
+Ops *make_hip_ops(int device) { return new HipOps(device); }
+
+}  // namespace ppals

@@ -1,0 +1,339 @@
+// kernels_scan.hip.h — the tensor-scan kernels: the only code that touches the s^N tensor.
+//
+// Both kernels compute  out[.., n] = sum_j V[.., j, ..] * B[j, n]  for a skinny B (n <= 64 columns,
+// the CP rank / Tucker core size) with the tensor streamed exactly once from HBM straight into
+// registers (every element of V is used once, so there is nothing to stage in LDS) and the
+// reduction done on the matrix cores:
+//
+//   f32 tensor: v_mfma_f32_16x16x4_f32, partial sums flushed into fp64 registers every FLUSH
+//               k-blocks, so no fp32 accumulation chain is longer than 16*VEC*FLUSH terms
+//   f64 tensor: v_mfma_f64_16x16x4_f64
+//
+// MFMA operand roles (16x16x4, one value per lane each, cdna_hip_programming.md §3):
+//   A[i = lane&15][kk = lane>>4]  <- packed Khatri-Rao value   (i = output column n)
+//   B[kk = lane>>4][j = lane&15]  <- tensor value              (j = a tensor row / column)
+//   D[i][j]: lane holds column j = lane&15 and rows i = rowmap(lane, reg)
+// so each lane ends up owning one tensor row (suffix kernel) or column (prefix kernel) and 4
+// output columns n — consecutive lanes write consecutive addresses.
+//
+// The Khatri-Rao operand is pre-packed by k_krp_pack so that ONE 16-byte load per lane fetches the
+// A-operand values of VEC consecutive MFMAs:
+//   packed[((((blk*NT + nt)*4 + g)*16 + n)*VEC + u] = KRP[blk*4*VEC + idx(g,u)][16*nt + n]
+//   suffix kernel: idx(g,u) = 4*u + g     (u-th k-quad of the block, kk = g)
+//   prefix kernel: idx(g,u) = VEC*g + u   (the lane's own VEC consecutive reduction rows)
+// Restates: common.cxx:56,83 (V_temp[seq_f] = V_front[seq] * W[..]) fused over the sibling modes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppals {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename TV>
+struct ScanTraits;
+template <>
+struct ScanTraits<float> {
+  static constexpr int VEC = 4;
+  typedef f32x4 vec;
+  typedef f32x4 acc;
+  static constexpr bool NEEDS_FLUSH = true;
+  __device__ static inline acc mfma(float a, float b, acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // D-matrix row held in register `reg` of `lane` (C/D map of the f32 16x16 shapes)
+  __device__ static inline int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+template <>
+struct ScanTraits<double> {
+  static constexpr int VEC = 2;
+  typedef f64x2 vec;
+  typedef f64x4 acc;
+  static constexpr bool NEEDS_FLUSH = false;
+  __device__ static inline acc mfma(double a, double b, acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // f64 16x16x4 uses a different C/D map: row = (lane>>4) + 4*reg
+  __device__ static inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+
+constexpr int SCAN_FLUSH = 16;  // k-blocks between fp32 -> fp64 flushes
+
+template <typename TV, bool ALIGNED>
+__device__ inline typename ScanTraits<TV>::vec load_vec(const TV *__restrict__ base, int64_t off,
+                                                        bool col_ok, int64_t row, int64_t nrows) {
+  typedef typename ScanTraits<TV>::vec vec;
+  constexpr int VEC = ScanTraits<TV>::VEC;
+  vec v;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) v[e] = (TV)0;
+  if (ALIGNED) {
+    if (col_ok && row < nrows) v = *reinterpret_cast<const vec *>(base + off);
+  } else {
+    if (col_ok) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++)
+        if (row + e < nrows) v[e] = base[off + e];
+    }
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// suffix scan (K1 / batched single-mode TTM):
+//   out[m + n*out_nstride (+ split/batch offsets)] = sum_{k in split} V[m + M*k (+batch)] * B[k,n]
+// grid: 1-D, block id = mtile + n_mtiles*(split + nsplit*batch); 256 threads = 4 waves, each wave
+// owns 16*VEC consecutive rows m (lane: VEC consecutive rows), all 4 waves share the k range, so
+// one k column of V is read as 4 x 16*VEC consecutive elements (1 KiB) per step.
+template <typename TV, int NT, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_scan_suffix(
+    const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
+    const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
+    double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
+    int64_t out_batch_stride, int ncols) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  typedef typename TR::acc acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int KB = 4 * VEC;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  int64_t bid = blockIdx.x;
+  const int mtile = (int)(bid % n_mtiles);
+  bid /= n_mtiles;
+  const int split = (int)(bid % nsplit);
+  const int64_t batch = bid / nsplit;
+
+  const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
+  if (m0 >= M) return;  // wave-uniform
+  const int64_t m = m0 + (int64_t)VEC * j16;
+  const TV *__restrict__ Vb = V + batch * batch_stride;
+  const int kb0 = split * kb_per_split;
+  const int kb1 = min(nkb, kb0 + kb_per_split);
+
+  acc_t acc[VEC][NT];
+  double acc64[TR::NEEDS_FLUSH ? VEC : 1][TR::NEEDS_FLUSH ? NT : 1][4];
+#pragma unroll
+  for (int a = 0; a < VEC; a++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
+      if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
+      }
+    }
+
+  int since_flush = 0;
+  for (int kb = kb0; kb < kb1; kb++) {
+    vec bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      bv[nt] = *reinterpret_cast<const vec *>(
+          P + ((((int64_t)kb * NT + nt) * 4 + g) * 16 + j16) * VEC);
+    vec vv[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; u++) {
+      const int64_t k = (int64_t)kb * KB + 4 * u + g;
+      vv[u] = load_vec<TV, ALIGNED>(Vb, k * M + m, k < K, m, M);
+    }
+#pragma unroll
+    for (int u = 0; u < VEC; u++)
+#pragma unroll
+      for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[jj][nt] = TR::mfma(bv[nt][u], vv[u][jj], acc[jj][nt]);
+    if constexpr (TR::NEEDS_FLUSH) {
+      if (++since_flush == SCAN_FLUSH) {
+        since_flush = 0;
+#pragma unroll
+        for (int a = 0; a < VEC; a++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              acc64[a][nt][r] += (double)acc[a][nt][r];
+              acc[a][nt][r] = 0;
+            }
+      }
+    }
+  }
+
+  double *__restrict__ o = out + split * out_split_stride + batch * out_batch_stride;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int n = 16 * nt + TR::row(lane, r);
+      if (n < ncols) {
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++) {
+          double val = (double)acc[jj][nt][r];
+          if constexpr (TR::NEEDS_FLUSH) val += acc64[jj][nt][r];
+          if (m + jj < M) o[(int64_t)n * out_nstride + m + jj] = val;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prefix scan (K2 / leading-mode TTM):
+//   out[k + n*out_nstride (+ split offset)] = sum_{m in split} V[m + M*k] * B[m,n]
+// grid: (ceil(K/64), nsplit); each wave owns 16 consecutive columns k (lane&15), the 4 lane groups
+// g take VEC consecutive reduction rows each, so one step reads 16 columns x 4*VEC rows; UNROLL
+// steps are issued back to back to keep >= UNROLL KiB per wave in flight.
+template <typename TV, int NT, bool ALIGNED, int UNROLL>
+__global__ __launch_bounds__(256) void k_scan_prefix(
+    const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
+    int nmb, double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride, int ncols) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  typedef typename TR::acc acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int MB = 4 * VEC;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (k0 >= K) return;  // wave-uniform
+  const int64_t k = k0 + j16;
+  const bool k_ok = k < K;
+  const int split = blockIdx.y;
+  const int mb0 = split * mb_per_split;
+  const int mb1 = min(nmb, mb0 + mb_per_split);
+  const TV *__restrict__ Vc = V + (k_ok ? k : 0) * M;
+
+  acc_t acc[2][NT];
+  double acc64[TR::NEEDS_FLUSH ? NT : 1][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      acc[0][nt][r] = 0;
+      acc[1][nt][r] = 0;
+    }
+    if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc64[nt][r] = 0.0;
+    }
+  }
+
+  int since_flush = 0;
+  for (int mbb = mb0; mbb < mb1; mbb += UNROLL) {
+    vec vv[UNROLL];
+    vec bv[UNROLL][NT];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int mb = mbb + u;
+      const bool ok = mb < mb1;  // wave-uniform
+      const int64_t m = (int64_t)mb * MB + (int64_t)VEC * g;
+      vv[u] = load_vec<TV, ALIGNED>(Vc, m, ok && k_ok, m, M);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        if (ok)
+          bv[u][nt] = *reinterpret_cast<const vec *>(
+              P + ((((int64_t)mb * NT + nt) * 4 + g) * 16 + j16) * VEC);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) bv[u][nt][e] = (TV)0;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+      for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          acc[jj & 1][nt] = TR::mfma(bv[u][nt][jj], vv[u][jj], acc[jj & 1][nt]);
+    if constexpr (TR::NEEDS_FLUSH) {
+      since_flush += UNROLL;
+      if (since_flush >= SCAN_FLUSH) {
+        since_flush = 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            acc64[nt][r] += (double)acc[0][nt][r] + (double)acc[1][nt][r];
+            acc[0][nt][r] = 0;
+            acc[1][nt][r] = 0;
+          }
+      }
+    }
+  }
+
+  double *__restrict__ o = out + split * out_split_stride;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int n = 16 * nt + TR::row(lane, r);
+      if (n < ncols && k_ok) {
+        double val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
+        if constexpr (TR::NEEDS_FLUSH) val += acc64[nt][r];
+        o[(int64_t)n * out_nstride + k] = val;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Khatri-Rao operand packing (layouts described at the top of this file).
+struct KrpArgs {
+  const double *ptr[MAX_ORDER];
+  int64_t rows[MAX_ORDER];
+  int64_t ld[MAX_ORDER];
+  int nf;
+};
+
+template <typename TV>
+__global__ void k_krp_pack(TV *__restrict__ P, int nblk, int NT, int prefix_layout, KrpArgs a,
+                           int64_t J, int col0, int ncols) {
+  constexpr int VEC = ScanTraits<TV>::VEC;
+  const int64_t total = (int64_t)nblk * NT * 4 * 16 * VEC;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = e;
+    const int u = (int)(t % VEC);
+    t /= VEC;
+    const int n = (int)(t % 16);
+    t /= 16;
+    const int g = (int)(t % 4);
+    t /= 4;
+    const int nt = (int)(t % NT);
+    const int64_t blk = t / NT;
+    const int64_t j = blk * 4 * VEC + (prefix_layout ? VEC * g + u : 4 * u + g);
+    const int c = 16 * nt + n;
+    double v = 0.0;
+    if (j < J && c < ncols) {
+      v = 1.0;
+      int64_t rem = j;
+      for (int f = 0; f < a.nf; f++) {
+        const int64_t jf = rem % a.rows[f];
+        rem /= a.rows[f];
+        v *= a.ptr[f][jf + a.ld[f] * (col0 + c)];
+      }
+    }
+    P[e] = (TV)v;
+  }
+}
+
+// out[m + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols
+__global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64_t split_stride,
+                              int64_t M, int ncols, double *__restrict__ out,
+                              int64_t out_rstride) {
+  const int64_t total = M * ncols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e % M;
+    const int64_t n = e / M;
+    double s = 0;
+    for (int sp = 0; sp < nsplit; sp++) s += slab[sp * split_stride + e];
+    out[m + out_rstride * n] = s;
+  }
+}
+
+}  // namespace ppals

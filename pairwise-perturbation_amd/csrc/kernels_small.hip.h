@@ -1,0 +1,489 @@
+// kernels_small.hip.h — everything that is not a scan of the s^N tensor: tensor generation /
+// residual (untimed in the reference), contraction of cached intermediates (K3/K9), the R x R
+// normal-equation side (K4-K7) and the PP bookkeeping. All fp64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_scan.hip.h"
+
+namespace ppals {
+
+// ------------------------------------------------------------------ RNG (bit-identical to the
+// host generator in ppals_api.cpp and to oracle/ppals_oracle.cpp)
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ inline double u01(uint64_t seed, uint64_t idx) {
+  uint64_t h = splitmix64(splitmix64(seed) ^ idx);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------ reductions
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// sum over the block; result valid in thread 0 (and broadcast through LDS to everyone)
+__device__ inline double block_sum(double v, double *lds /* >= 17 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < nw; w++) s += lds[w];
+    lds[16] = s;
+  }
+  __syncthreads();
+  return lds[16];
+}
+
+__global__ void k_sum_partials(const double *__restrict__ part, int n, double *__restrict__ out) {
+  __shared__ double lds[17];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// ------------------------------------------------------------------ tensor generation
+template <typename TV>
+__global__ void k_fill_uniform(TV *__restrict__ V, int64_t l0, int64_t g0, int64_t row0,
+                               int64_t rest, uint64_t seed, double lo, double hi) {
+  const int64_t total = l0 * rest;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = e % l0, r = e / l0;
+    const uint64_t gi = (uint64_t)(row0 + a) + (uint64_t)g0 * (uint64_t)r;
+    V[e] = (TV)(lo + (hi - lo) * u01(seed, gi));
+  }
+}
+
+// rank-R outer structure  vhat[m,k] = sum_r Q[m,r] P[k,r]; block = 256 rows m, KCH columns k.
+// MODE 0: V = vhat (build_V, common.cxx:135-197). MODE 1: partial[blk] = sum (V - vhat)^2
+// (als_CP.cxx:183-187, nothing materialised). MODE 2: partial[blk] = sum V^2.
+template <typename TV, int RB, int MODE>
+__global__ __launch_bounds__(256) void k_rank_stream(TV *__restrict__ V, int64_t M, int64_t K,
+                                                     const double *__restrict__ Q,
+                                                     const double *__restrict__ P, int R,
+                                                     int kch, double *__restrict__ partial) {
+  __shared__ double lds[17];
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.y * kch;
+  const int64_t k1 = min(K, k0 + (int64_t)kch);
+  const bool ok = m < M;
+  double q[RB];
+  if (MODE != 2) {
+#pragma unroll
+    for (int r = 0; r < RB; r++) q[r] = (ok && r < R) ? Q[m + M * r] : 0.0;
+  }
+  double acc = 0;
+  for (int64_t k = k0; k < k1; k++) {
+    double v = 0;
+    if (MODE != 2) {
+#pragma unroll
+      for (int r = 0; r < RB; r++)
+        if (r < R) v += q[r] * P[k + K * r];
+    }
+    if (ok) {
+      if (MODE == 0)
+        V[m + M * k] = (TV)v;
+      else {
+        double d = (double)V[m + M * k] - v;
+        acc += d * d;
+      }
+    }
+  }
+  if (MODE != 0) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  }
+}
+
+template <typename TV>
+__global__ void k_convert_rows(TV *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] = (TV)src[e];
+}
+
+// ------------------------------------------------------------------ plain Khatri-Rao product
+__global__ void k_krp(double *__restrict__ out, KrpArgs a, int64_t J, int col0, int ncols) {
+  const int64_t total = J * ncols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e % J;
+    const int c = (int)(e / J);
+    double v = 1.0;
+    int64_t rem = j;
+    for (int f = 0; f < a.nf; f++) {
+      const int64_t jf = rem % a.rows[f];
+      rem /= a.rows[f];
+      v *= a.ptr[f][jf + a.ld[f] * (col0 + c)];
+    }
+    out[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------ mttv (K3, K9, deeper tree nodes)
+// out[l + L*t + rs*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j + ldb*r]
+// variant L: one thread per (l,t,r), coalesced over l.
+__global__ void k_mttv_l(const double *__restrict__ X, int64_t L, int64_t J, int64_t T, int R,
+                         const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
+                         int64_t rs, int accumulate) {
+  const int64_t total = L * T * R;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t l = e % L;
+    const int64_t t = (e / L) % T;
+    const int r = (int)(e / (L * T));
+    const double *x = X + l + L * J * (t + T * (int64_t)r);
+    const double *b = B + ldb * r;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t j = 0;
+    for (; j + 3 < J; j += 4) {
+      s0 += x[L * j] * b[j];
+      s1 += x[L * (j + 1)] * b[j + 1];
+      s2 += x[L * (j + 2)] * b[j + 2];
+      s3 += x[L * (j + 3)] * b[j + 3];
+    }
+    for (; j < J; j++) s0 += x[L * j] * b[j];
+    const double s = (s0 + s1) + (s2 + s3);
+    double *o = out + l + L * t + rs * r;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+// variant 1 (L == 1): one wave per (t,r), lanes stride the contiguous j.
+__global__ void k_mttv_1(const double *__restrict__ X, int64_t J, int64_t T, int R,
+                         const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
+                         int64_t rs, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t total = T * R;
+  for (int64_t e = wid; e < total; e += nw) {
+    const int64_t t = e % T;
+    const int r = (int)(e / T);
+    const double *x = X + J * (t + T * (int64_t)r);
+    const double *b = B + ldb * r;
+    double s = 0;
+    for (int64_t j = lane; j < J; j += 64) s += x[j] * b[j];
+    s = wave_sum(s);
+    if (lane == 0) {
+      double *o = out + t + rs * r;
+      *o = accumulate ? (*o + s) : s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Gram  G = W^T W
+// one wave per (p<=q) pair, lanes stride the rows (coalesced); symmetric fill.
+__global__ void k_gram(const double *__restrict__ W, int64_t rows, int64_t ld, int R,
+                       double *__restrict__ G) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int npairs = R * (R + 1) / 2;
+  for (int e = wid; e < npairs; e += nw) {
+    // decode e -> (p,q), p <= q, row-major over the upper triangle
+    int p = 0, rem = e;
+    while (rem >= R - p) {
+      rem -= R - p;
+      p++;
+    }
+    const int q = p + rem;
+    const double *a = W + ld * p, *b = W + ld * q;
+    double s = 0;
+    for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+      G[p + R * q] = s;
+      G[q + R * p] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ S and S^{-1}  (K4 + K6a)
+// ONE wave. S = Hadamard of the Grams of all modes but `mode` (+ lambda I); S^{-1} through a
+// parallel-ordered cyclic Jacobi eigendecomposition S = Q diag(w) Q^T, S^{-1} = Q diag(1/w) Q^T.
+// For a symmetric matrix this equals the reference's V diag(1/sigma) U^T (common.cxx:717-722),
+// including its behaviour of NOT truncating tiny singular values.
+// dynamic LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
+__global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ Gall, int N,
+                                                    int mode, int R, double lambda,
+                                                    double *__restrict__ S,
+                                                    double *__restrict__ Sinv) {
+  extern __shared__ double lds[];
+  const int ldA = R + 1;
+  double *A = lds;
+  double *Q = A + R * ldA;
+  double *cs = Q + R * ldA;   // c[i], s[i] per pair (<= 32 pairs -> 64 doubles)
+  int *pq = (int *)(cs + 64);  // p[i], q[i] per pair (64 ints)
+  const int lane = threadIdx.x;
+
+  // Hadamard product in the reference's index order (als_CP.cxx:219-232): modes 0..N-1 with
+  // `mode` and N-1 swapped, first N-1 of them
+  for (int e = lane; e < R * R; e += 64) {
+    double v = 1.0;
+    bool first = true;
+    for (int ii = 0; ii < N - 1; ii++) {
+      int j = (ii == mode) ? (N - 1) : ii;
+      double gval = Gall[(int64_t)j * R * R + e];
+      v = first ? gval : v * gval;
+      first = false;
+    }
+    const int i = e % R, j = e / R;
+    if (i == j) v += lambda;
+    S[e] = v;
+    A[i * ldA + j] = v;
+    Q[i * ldA + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+
+  const int n2 = (R + 1) & ~1;  // players (even); index R (if odd) is a bye
+  const int npair = n2 / 2;
+  for (int sweep = 0; sweep < 40; sweep++) {
+    // convergence: off-diagonal mass vs diagonal mass
+    double off = 0, diag = 0;
+    for (int e = lane; e < R * R; e += 64) {
+      const int i = e % R, j = e / R;
+      const double a = A[i * ldA + j];
+      if (i == j)
+        diag += a * a;
+      else
+        off += a * a;
+    }
+    off = wave_sum(off);
+    diag = wave_sum(diag);
+    off = __shfl(off, 0, 64);
+    diag = __shfl(diag, 0, 64);
+    if (off <= 1e-30 * diag || off == 0.0) break;
+
+    for (int rd = 0; rd < n2 - 1; rd++) {
+      // round-robin pairing: player n2-1 fixed, the others rotate
+      if (lane < npair) {
+        int a, b;
+        if (lane == 0) {
+          a = n2 - 1;
+          b = rd % (n2 - 1);
+        } else {
+          a = (rd + lane) % (n2 - 1);
+          b = (rd - lane + (n2 - 1)) % (n2 - 1);
+        }
+        int p = min(a, b), q = max(a, b);
+        double c = 1.0, s = 0.0;
+        if (q < R) {
+          const double apq = A[p * ldA + q];
+          if (apq != 0.0) {
+            const double app = A[p * ldA + p], aqq = A[q * ldA + q];
+            const double theta = (aqq - app) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            s = t * c;
+          }
+        } else {
+          p = q = -1;  // bye
+        }
+        cs[2 * lane] = c;
+        cs[2 * lane + 1] = s;
+        pq[2 * lane] = p;
+        pq[2 * lane + 1] = q;
+      }
+      __syncthreads();
+      // column update: A <- A J, Q <- Q J   (for each pair, every row i)
+      for (int e = lane; e < npair * R; e += 64) {
+        const int pi = e / R, i = e % R;
+        const int p = pq[2 * pi], q = pq[2 * pi + 1];
+        if (p >= 0) {
+          const double c = cs[2 * pi], s = cs[2 * pi + 1];
+          const double aip = A[i * ldA + p], aiq = A[i * ldA + q];
+          A[i * ldA + p] = c * aip - s * aiq;
+          A[i * ldA + q] = s * aip + c * aiq;
+          const double qip = Q[i * ldA + p], qiq = Q[i * ldA + q];
+          Q[i * ldA + p] = c * qip - s * qiq;
+          Q[i * ldA + q] = s * qip + c * qiq;
+        }
+      }
+      __syncthreads();
+      // row update: A <- J^T A
+      for (int e = lane; e < npair * R; e += 64) {
+        const int pi = e / R, j = e % R;
+        const int p = pq[2 * pi], q = pq[2 * pi + 1];
+        if (p >= 0) {
+          const double c = cs[2 * pi], s = cs[2 * pi + 1];
+          const double apj = A[p * ldA + j], aqj = A[q * ldA + j];
+          A[p * ldA + j] = c * apj - s * aqj;
+          A[q * ldA + j] = s * apj + c * aqj;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // S^{-1}[i,j] = sum_k Q[i,k] Q[j,k] / w_k      (no truncation)
+  for (int e = lane; e < R * R; e += 64) {
+    const int i = e % R, j = e / R;
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += Q[i * ldA + k] * (1.0 / A[k * ldA + k]) * Q[j * ldA + k];
+    Sinv[e] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ mode update (K5 + K6b)
+// ONE block. grad = -M + Wold*S (pre-update W, als_CP.cxx:296); Wnew = M*Sinv (SVD_solve);
+// optional SVD_solve_mod tail (common.cxx:753-756). Wnew may alias Wold.
+__global__ __launch_bounds__(1024) void k_cp_update(
+    const double *__restrict__ M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
+    int64_t ldn, double *__restrict__ grad, int64_t ldg, int64_t rows, int R,
+    const double *__restrict__ S, const double *__restrict__ Sinv, double *__restrict__ gradsq,
+    const double *__restrict__ Winit, int64_t ldi, double *__restrict__ dW, int64_t ldd,
+    double ratio) {
+  extern __shared__ double lds[];
+  double *sS = lds + 32;
+  double *sI = sS + R * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    sS[e] = S[e];
+    sI[e] = Sinv[e];
+  }
+  __syncthreads();
+  const int64_t total = rows * R;
+  double gs = 0;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += Wold[i + ldw * k] * sS[k + R * j];
+    const double gv = -M[i + ldm * j] + acc;
+    grad[i + ldg * j] = gv;
+    gs += gv * gv;
+  }
+  gs = block_sum(gs, lds);  // also the barrier between reading Wold and writing Wnew
+  if (threadIdx.x == 0) *gradsq = gs;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += M[i + ldm * k] * sI[k + R * j];
+    if (Winit) {
+      const double wi = Winit[i + ldi * j];
+      const double d = ratio * (acc - wi);
+      dW[i + ldd * j] = d;
+      if (ratio != 1.0) acc = wi + d;
+    }
+    Wnew[i + ldn * j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ Normalize (K7)
+struct PtrsN {
+  double *p[MAX_ORDER];
+  double *q[MAX_ORDER];
+  double *d[MAX_ORDER];
+  int64_t n[MAX_ORDER];
+};
+// ONE wave: scales[i] = (prod_j ||W_j||)^(1/N) / ||W_i||, with ||W_i||^2 = trace(G_i); the Grams
+// are rescaled in place (G_i *= scales[i]^2) so they stay consistent with the scaled factors.
+__global__ __launch_bounds__(64) void k_norm_scales(double *__restrict__ Gall, int N, int R,
+                                                    double *__restrict__ scales) {
+  __shared__ double nrm[MAX_ORDER];
+  const int lane = threadIdx.x;
+  if (lane < N) {
+    double tr = 0;
+    for (int k = 0; k < R; k++) tr += Gall[(int64_t)lane * R * R + k + R * k];
+    nrm[lane] = sqrt(tr);
+  }
+  __syncthreads();
+  double prod = 1;
+  for (int i = 0; i < N; i++) prod = prod * nrm[i];
+  const double c = pow(prod, 1.0 / N);
+  for (int i = 0; i < N; i++) {
+    const double f = c / nrm[i];
+    for (int e = lane; e < R * R; e += 64) Gall[(int64_t)i * R * R + e] *= f * f;
+    if (lane == 0) scales[i] = f;
+  }
+}
+__global__ void k_scale_factors(PtrsN w, int N, const double *__restrict__ scales) {
+  const int i = blockIdx.y;
+  if (i >= N) return;
+  const double f = scales[i];
+  double *p = w.p[i];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < w.n[i];
+       e += (int64_t)gridDim.x * blockDim.x)
+    p[e] = f * p[e];
+}
+
+// ------------------------------------------------------------------ PP bookkeeping
+// block i: out[2i] = ||A_i - B_i||^2, out[2i+1] = ||A_i||^2; optionally D_i = A_i - B_i and
+// B_i = A_i (als_CP.cxx:594-603). B_i == nullptr: out[2i] = ||D_i||^2 (als_CP.cxx:659-663).
+__global__ __launch_bounds__(1024) void k_diff_norms(PtrsN a, int store_diff, int update_prev,
+                                                     double *__restrict__ out) {
+  __shared__ double lds[17];
+  const int i = blockIdx.x;
+  const double *A = a.p[i];
+  double *B = a.q[i];
+  double *D = a.d[i];
+  double sd = 0, sa = 0;
+  for (int64_t e = threadIdx.x; e < a.n[i]; e += blockDim.x) {
+    const double av = A[e];
+    double dv;
+    if (B) {
+      dv = av - B[e];
+      if (store_diff) D[e] = dv;
+      if (update_prev) B[e] = av;
+    } else {
+      dv = D[e];
+    }
+    sd += dv * dv;
+    sa += av * av;
+  }
+  sd = block_sum(sd, lds);
+  sa = block_sum(sa, lds);
+  if (threadIdx.x == 0) {
+    out[2 * i] = sd;
+    out[2 * i + 1] = sa;
+  }
+}
+
+// ------------------------------------------------------------------ row-block (un)packing
+__global__ void k_pack_blocks(const double *__restrict__ nat, int64_t rows, int64_t ld, int R,
+                              int64_t blk, int P, double *__restrict__ blocked) {
+  const int64_t total = blk * R * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t x = e % blk;
+    const int r = (int)((e / blk) % R);
+    const int p = (int)(e / (blk * R));
+    const int64_t row = (int64_t)p * blk + x;
+    blocked[e] = row < rows ? nat[row + ld * r] : 0.0;
+  }
+}
+__global__ void k_unpack_blocks(const double *__restrict__ blocked, int64_t rows, int64_t ld,
+                                int R, int64_t blk, int P, double *__restrict__ nat) {
+  const int64_t total = blk * R * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t x = e % blk;
+    const int r = (int)((e / blk) % R);
+    const int p = (int)(e / (blk * R));
+    const int64_t row = (int64_t)p * blk + x;
+    if (row < rows) nat[row + ld * r] = blocked[e];
+  }
+}
+
+__global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restrict__ partial) {
+  __shared__ double lds[17];
+  double s = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    s += x[e] * x[e];
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+}  // namespace ppals

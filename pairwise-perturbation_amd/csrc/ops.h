@@ -1,0 +1,145 @@
+// ops.h — the device-operation and collective interfaces the ALS engine is written against.
+//
+// engine.cpp contains only control flow (which contraction, which cache, which collective, when to
+// restart PP — the part of the reference that is "pure algorithm orchestration") and
+// talks to the hardware through these two abstract classes. The product implements them with
+// hand-written HIP kernels (hip_ops.hip) and RCCL (rccl_comm.cpp). tests/hostsim/ implements them
+// with plain host loops + callbacks so the engine's host logic and the multi-rank shard plan can be
+// exercised on a CPU-only box (test infrastructure, never shipped in libppals.so).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace ppals {
+
+enum DType { F32 = 0, F64 = 1 };
+inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 8; }
+
+constexpr int MAX_ORDER = 8;
+
+// a factor-matrix operand of a Khatri-Rao product: `rows` rows starting at `ptr`, leading dim ld
+struct FactorRef {
+  const double *ptr;
+  int64_t rows;
+  int64_t ld;
+};
+
+struct ProfileSlot {
+  int64_t launches = 0;
+  double ms = 0;
+  double bytes = 0;
+};
+
+class Ops {
+ public:
+  virtual ~Ops() {}
+  // ---- memory (all pointers returned by alloc are "device" pointers of this Ops) ----
+  virtual void *alloc(size_t bytes) = 0;
+  virtual void free(void *p) = 0;
+  virtual void h2d(void *dst, const void *src, size_t bytes) = 0;  // returns when dst is usable
+  virtual void d2h(void *dst, const void *src, size_t bytes) = 0;  // synchronises the stream
+  virtual void d2d(void *dst, const void *src, size_t bytes) = 0;  // stream-ordered
+  virtual void zero(void *p, size_t bytes) = 0;
+  virtual void sync() = 0;
+  virtual void *stream() { return nullptr; }
+
+  // ---- tensor generation / norms ----
+  // V[e_local] = lo + (hi-lo)*u01(seed, global linear index); local shard = rows [row0,row0+l0)
+  // of a leading mode of global extent g0; `rest` = product of the other extents
+  virtual void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                            uint64_t seed, double lo, double hi) = 0;
+  // V[m,k] = sum_r Q[m,r]*P[k,r]  (Q: M x R, P: K x R, column-major fp64)   (build_V)
+  virtual void fill_rank(void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
+                         int R) = 0;
+  // *out (device scalar) = sum_{m,k} (V[m,k] - sum_r Q[m,r]P[k,r])^2 ; Q==nullptr: sum V^2
+  virtual void residual_sq(const void *V, int dt, int64_t M, int64_t K, const double *Q,
+                           const double *P, int R, double *out) = 0;
+  // upload fp64 host rows into the local shard (converting to dt): host is the FULL tensor
+  virtual void upload_shard(void *V, int dt, const double *host_full, int64_t l0, int64_t g0,
+                            int64_t row0, int64_t rest) = 0;
+
+  // ---- Khatri-Rao product, plain: out[j + J*c] = prod_f W_f[j_f + ld_f*(col0+c)], fp64 ----
+  virtual void krp(double *out, const FactorRef *f, int nf, int col0, int ncols) = 0;
+
+  // ---- tensor scans (the only kernels that touch the s^N tensor) ----
+  // V viewed as [L, J, T] (first fastest), B = KRP of `nf` factors with combined extent J:
+  //   out[l + L*t + out_rstride*r] (+)= sum_j V[l,j,t] * B[j,r]       r in [0,R)
+  // This one primitive is K1 (T=1: contract a suffix), K2 (L=1: contract a prefix) and the
+  // single-mode TTM of the PP operator build / Tucker TTMc (general L,J,T).
+  virtual void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T,
+                             const FactorRef *f, int nf, int R, double *out,
+                             int64_t out_rstride) = 0;
+  // Tucker mode product keeping the mode in place (fp64 in/out or V-typed in):
+  //   out[l + L*(k + Kc*t)] = sum_j X[l,j,t] * W[j + ldw*k]
+  virtual void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
+                        int64_t ldw, int Kc, double *out) = 0;
+
+  // ---- contraction of a cached intermediate (fp64) that already carries the rank index ----
+  //   out[l + L*t + out_rstride*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j,r]
+  // B = KRP of `nf` factor refs (combined extent J). accumulate!=0: add into out.
+  virtual void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
+                    int R, double *out, int64_t out_rstride, int accumulate) = 0;
+
+  // ---- R x R normal-equation side ----
+  // G = W^T W  (rows x R, ld)  ->  G[R*R]
+  virtual void gram(const double *W, int64_t rows, int64_t ld, int R, double *G) = 0;
+  // S = Hadamard_{j != mode} G_j (+ lambda I); Sinv = S^{-1} through a symmetric eigen-
+  // decomposition without truncation (the reference's SVD_solve, common.cxx:717-722)
+  virtual void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
+                           double *Sinv) = 0;
+  // for `rows` rows: grad = -M + Wold*S ; Wnew = M*Sinv ; *gradsq += sum grad^2
+  // if Winit != nullptr (SVD_solve_mod, common.cxx:739-758): dW = ratio*(Wnew-Winit) and, when
+  // ratio != 1, Wnew = Winit + dW.
+  virtual void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw,
+                         double *Wnew, int64_t ldn, double *grad, int64_t ldg, int64_t rows,
+                         int R, const double *S, const double *Sinv, double *gradsq,
+                         const double *Winit, int64_t ldi, double *dW, int64_t ldd,
+                         double ratio) = 0;
+  // Normalize (common.cxx:680-688) on N full factors using ||W_i||^2 = trace(G_i); rescales the
+  // Grams consistently.
+  virtual void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) = 0;
+  // out[2i] = ||A_i - B_i||^2 (B_i may be null -> ||A_i||^2 only in out[2i+1]), out[2i+1]=||A_i||^2
+  // and if B_i != null and update_prev: B_i = A_i afterwards. (als_CP.cxx:594-603, :659-663)
+  virtual void diff_norms(double *const *A, double *const *B, const int64_t *n, int N,
+                          int store_diff, double *const *D, int update_prev, double *out) = 0;
+  // row-block pack/unpack for reduce-scatter / all-gather of a column-major rows x R matrix:
+  // blocked[p][x + blk*r] <-> nat[p*blk + x + ld*r]; rows beyond `rows` are zero in blocked
+  virtual void pack_blocks(const double *nat, int64_t rows, int64_t ld, int R, int64_t blk, int P,
+                           double *blocked) = 0;
+  virtual void unpack_blocks(const double *blocked, int64_t rows, int64_t ld, int R, int64_t blk,
+                             int P, double *nat) = 0;
+
+  // ---- Tucker: Gram of the mode-`pos` unfolding and its leading eigenvectors ----
+  // G[p + J*q] = sum_{l,t} X[l,p,t]*X[l,q,t]   (unroll_tensor_contraction, common.cxx:205-223)
+  virtual void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) = 0;
+  // U (J x rank, column-major) = leading eigenvectors of symmetric PSD G (J x J), descending
+  virtual void top_eigvecs(double *G, int64_t J, int rank, double *U) = 0;
+  virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
+
+  // profiling of the scan kernels (HIP events on the launch stream)
+  virtual void profile_enable(bool) {}
+  virtual void profile_collect() {}
+  ProfileSlot prof[2];
+};
+
+class Comm {
+ public:
+  virtual ~Comm() {}
+  virtual int rank() const = 0;
+  virtual int size() const = 0;
+  // all on "device" pointers of the paired Ops, fp64, stream-ordered with the Ops' stream
+  virtual void allreduce_sum(double *buf, int64_t n) = 0;
+  virtual void reduce_scatter_sum(const double *send, double *recv, int64_t recvcount) = 0;
+  virtual void allgather(const double *send, double *recv, int64_t sendcount) = 0;
+};
+
+class SelfComm : public Comm {
+ public:
+  int rank() const override { return 0; }
+  int size() const override { return 1; }
+  void allreduce_sum(double *, int64_t) override {}
+  void reduce_scatter_sum(const double *, double *, int64_t) override {}
+  void allgather(const double *, double *, int64_t) override {}
+};
+
+}  // namespace ppals

@@ -1,0 +1,374 @@
+// ppals_api.cpp — the C ABI declared in include/ppals.h: thin, exception-free glue between plain
+// pointers/sizes and the engine. The backend (device ops + communicator) comes from backend.h:
+// libppals.so links the HIP/RCCL backend; there is no other backend in the product.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ppals.h"
+#include "backend.h"
+#include "engine.h"
+#include "tucker.h"
+
+using namespace ppals;
+
+static thread_local std::string g_err;
+
+struct ppals_ctx {
+  Ops *ops = nullptr;
+  Comm *comm = nullptr;
+  SelfComm self;
+  Comm &c() { return comm ? *comm : self; }
+};
+struct ppals_tensor {
+  ppals_ctx *ctx;
+  TensorDesc d;
+};
+struct ppals_cp {
+  ppals_ctx *ctx;
+  CpEngine *eng;
+};
+struct ppals_tucker {
+  ppals_ctx *ctx;
+  TuckerEngine *eng;
+};
+
+#define API_BEGIN try {
+#define API_END(code)                     \
+  }                                       \
+  catch (const std::exception &e) {       \
+    g_err = e.what();                     \
+    return code;                          \
+  }                                       \
+  catch (...) {                           \
+    g_err = "ppals: unknown exception";   \
+    return code;                          \
+  }
+
+static int fail(int code, const char *msg) {
+  g_err = msg;
+  return code;
+}
+
+extern "C" {
+
+const char *ppals_last_error(void) { return g_err.c_str(); }
+const char *ppals_version(void) { return backend_name(); }
+
+int ppals_ctx_create(ppals_ctx **out, int device) {
+  if (!out) return fail(PPALS_ERR_ARG, "ppals_ctx_create: out is NULL");
+  *out = nullptr;
+  API_BEGIN
+  std::unique_ptr<ppals_ctx> c(new ppals_ctx);
+  c->ops = backend_make_ops(device);  // throws when no HIP device: there is no CPU fallback
+  *out = c.release();
+  return PPALS_OK;
+  API_END(PPALS_ERR_NO_DEVICE)
+}
+void ppals_ctx_destroy(ppals_ctx *ctx) {
+  if (!ctx) return;
+  delete ctx->comm;
+  delete ctx->ops;
+  delete ctx;
+}
+int ppals_get_unique_id(void *out128) {
+  API_BEGIN
+  backend_unique_id(out128);
+  return PPALS_OK;
+  API_END(PPALS_ERR_COMM)
+}
+int ppals_ctx_init_comm(ppals_ctx *ctx, int rank, int nranks, const void *uid) {
+  if (!ctx) return fail(PPALS_ERR_ARG, "ctx is NULL");
+  API_BEGIN
+  if (nranks <= 1) return PPALS_OK;
+  ctx->comm = backend_make_comm(ctx->ops, rank, nranks, uid);
+  return PPALS_OK;
+  API_END(PPALS_ERR_COMM)
+}
+int ppals_ctx_rank(const ppals_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->rank() : 0; }
+int ppals_ctx_nranks(const ppals_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->size() : 1; }
+int ppals_ctx_sync(ppals_ctx *ctx) {
+  API_BEGIN
+  ctx->ops->sync();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_profile_enable(ppals_ctx *ctx, int on) {
+  API_BEGIN
+  ctx->ops->profile_enable(on != 0);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_profile_read(ppals_ctx *ctx, int which, int64_t *launches, double *total_ms,
+                       double *algo_bytes) {
+  if (which < 0 || which > 1) return fail(PPALS_ERR_ARG, "which must be 0 or 1");
+  API_BEGIN
+  ctx->ops->profile_collect();
+  if (launches) *launches = ctx->ops->prof[which].launches;
+  if (total_ms) *total_ms = ctx->ops->prof[which].ms;
+  if (algo_bytes) *algo_bytes = ctx->ops->prof[which].bytes;
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_profile_reset(ppals_ctx *ctx) {
+  API_BEGIN
+  ctx->ops->profile_collect();
+  ctx->ops->prof[0] = ProfileSlot();
+  ctx->ops->prof[1] = ProfileSlot();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+
+// ------------------------------------------------------------------ tensor
+int ppals_tensor_create(ppals_ctx *ctx, int order, const int64_t *global_lens, int dtype,
+                        ppals_tensor **out) {
+  if (!ctx || !global_lens || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (dtype != PPALS_F32 && dtype != PPALS_F64) return fail(PPALS_ERR_ARG, "bad dtype");
+  API_BEGIN
+  std::unique_ptr<ppals_tensor> t(new ppals_tensor);
+  t->ctx = ctx;
+  std::string err;
+  if (tensor_create(*ctx->ops, ctx->c(), order, global_lens, dtype, &t->d, &err) != 0) {
+    g_err = "ppals_tensor_create: " + err;
+    return PPALS_ERR_ARG;
+  }
+  *out = t.release();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+void ppals_tensor_destroy(ppals_tensor *t) {
+  if (!t) return;
+  try {
+    t->ctx->ops->free(t->d.data);
+  } catch (...) {
+  }
+  delete t;
+}
+int ppals_tensor_local_rows(const ppals_tensor *t, int64_t *lo, int64_t *n) {
+  if (!t) return fail(PPALS_ERR_ARG, "NULL tensor");
+  if (lo) *lo = t->d.row0;
+  if (n) *n = t->d.llens[0];
+  return PPALS_OK;
+}
+int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat) {
+  if (!t || !Wtrue_flat || R <= 0) return fail(PPALS_ERR_ARG, "bad argument");
+  API_BEGIN
+  tensor_fill_cp(*t->ctx->ops, t->d, R, Wtrue_flat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double hi) {
+  if (!t) return fail(PPALS_ERR_ARG, "NULL tensor");
+  API_BEGIN
+  tensor_fill_uniform(*t->ctx->ops, t->d, seed, lo, hi);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
+  if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  tensor_upload(*t->ctx->ops, t->d, host_full);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tensor_norm(ppals_tensor *t, double *out) {
+  if (!t || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  *out = tensor_norm(*t->ctx->ops, t->ctx->c(), t->d);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+
+static inline uint64_t sm64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+void ppals_fill_uniform_host(double *out, int64_t n, uint64_t seed, uint64_t offset, double lo,
+                             double hi) {
+  const uint64_t s = sm64(seed);
+  for (int64_t i = 0; i < n; i++) {
+    uint64_t h = sm64(s ^ (offset + (uint64_t)i));
+    out[i] = lo + (hi - lo) * ((double)(h >> 11) * (1.0 / 9007199254740992.0));
+  }
+}
+
+// ------------------------------------------------------------------ CP
+int ppals_cp_create(ppals_ctx *ctx, ppals_tensor *V, int R, ppals_cp **out) {
+  if (!ctx || !V || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (R <= 0) return fail(PPALS_ERR_ARG, "rank must be positive");
+  if (R > 64) return fail(PPALS_ERR_UNSUPPORTED, "this build supports CP rank <= 64");
+  API_BEGIN
+  std::unique_ptr<ppals_cp> s(new ppals_cp);
+  s->ctx = ctx;
+  s->eng = new CpEngine(*ctx->ops, ctx->c(), V->d, R);
+  *out = s.release();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+void ppals_cp_destroy(ppals_cp *s) {
+  if (!s) return;
+  delete s->eng;
+  delete s;
+}
+int ppals_cp_set_factors(ppals_cp *s, const double *Wflat, const double *gradWflat) {
+  if (!s || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->set_factors(Wflat, gradWflat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->get_factors(Wflat, gradWflat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  for (int i = 0; i < n; i++) s->eng->sweep_dt(lambda);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_gradnorm(ppals_cp *s, double *out) {
+  if (!s || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  *out = s->eng->gradnorm();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_residual(ppals_cp *s, double *out) {
+  if (!s || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  *out = s->eng->residual();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tree_node(ppals_cp *s, const char *key, double *out, int64_t *n) {
+  if (!s || !key) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  int64_t c = s->eng->tree_node(key, out);
+  if (c < 0) return fail(PPALS_ERR_ARG, "ppals_tree_node: not a node of the dimension tree");
+  if (n) *n = c;
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_mttkrp(ppals_cp *s, int mode, double *M) {
+  if (!s || !M) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (mode < 0 || mode >= s->eng->order()) return fail(PPALS_ERR_ARG, "mode out of range");
+  API_BEGIN
+  s->eng->mttkrp(mode, M);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_pp_operator(ppals_cp *s, const char *contracted, double *out, int64_t *n) {
+  if (!s || !contracted) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  int64_t c = s->eng->pp_operator(contracted, out);
+  if (c < 0) return fail(PPALS_ERR_ARG, "ppals_pp_operator: bad mode string");
+  if (n) *n = c;
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_gram_system(ppals_cp *s, int mode, double lambda, double *S, double *Sinv) {
+  if (!s || !S || !Sinv) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (mode < 0 || mode >= s->eng->order()) return fail(PPALS_ERR_ARG, "mode out of range");
+  API_BEGIN
+  s->eng->gram_system(mode, lambda, S, Sinv);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+
+static CpOpts to_opts(const ppals_cp_opts *o) {
+  CpOpts c;
+  c.tol = o->tol;
+  c.timelimit = o->timelimit;
+  c.maxiter = o->maxiter;
+  c.lambda = o->lambda;
+  c.resprint = o->resprint > 0 ? o->resprint : 10;
+  c.bench = o->bench;
+  c.tol_init = o->tol_init;
+  c.ratio_step = o->ratio_step;
+  if (o->csv_path) c.csv_path = o->csv_path;
+  c.csv_append = o->csv_append != 0;
+  c.verbose = o->verbose != 0;
+  return c;
+}
+int ppals_cp_dt(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  return s->eng->run_dt(to_opts(o), iters);
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_pp(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  return s->eng->run_pp(to_opts(o), iters);
+  API_END(PPALS_ERR_HIP)
+}
+
+// ------------------------------------------------------------------ Tucker
+int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out) {
+  if (!ctx || !V || !ranks || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  std::unique_ptr<ppals_tucker> s(new ppals_tucker);
+  s->ctx = ctx;
+  s->eng = new TuckerEngine(*ctx->ops, ctx->c(), V->d, ranks);
+  *out = s.release();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+void ppals_tucker_destroy(ppals_tucker *s) {
+  if (!s) return;
+  delete s->eng;
+  delete s;
+}
+int ppals_tucker_set_factors(ppals_tucker *s, const double *Wflat) {
+  if (!s || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->set_factors(Wflat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_get_factors(ppals_tucker *s, double *Wflat, double *core) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->get_factors(Wflat, core);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_hosvd(ppals_tucker *s) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->hosvd();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_ttmc(ppals_tucker *s, int skip, double *Y, int64_t *n) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  int64_t c = s->eng->ttmc(skip, Y);
+  if (n) *n = c;
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_sweeps_dt(ppals_tucker *s, int n) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  for (int i = 0; i < n; i++) s->eng->sweep_dt();
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_dt(ppals_tucker *s, const ppals_cp_opts *o, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  return s->eng->run_dt(to_opts(o), iters);
+  API_END(PPALS_ERR_HIP)
+}
+
+}  // extern "C"

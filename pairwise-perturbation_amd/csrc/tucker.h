@@ -1,0 +1,50 @@
+// tucker.h — HOOI sweep engine for Tucker decomposition (als_Tucker.cxx) over abstract ops.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ppals {
+
+class TuckerEngine {
+ public:
+  TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int *ranks);
+  ~TuckerEngine();
+  void set_factors(const double *Wflat);
+  void get_factors(double *Wflat, double *core);
+  void hosvd();                          // als_Tucker.cxx:12-70
+  int64_t ttmc(int skip, double *Yhost);  // als_Tucker.cxx:76-110
+  void sweep_dt();                       // als_Tucker.cxx:340-408
+  int run_dt(const CpOpts &o, int *iters);  // alsTucker_DT, als_Tucker.cxx:240-424
+
+ private:
+  struct Node {
+    int lo, hi, parent, slo, shi;
+    double *buf = nullptr;
+    int64_t cap = 0;
+    bool valid = false;
+  };
+  void build_tree(int lo, int hi, int parent);
+  // dims of a node's tensor: ranks on the contracted modes, full extent elsewhere
+  void compute_node(int idx);
+  double *ttmc_chain(int skip, int64_t *elems);  // returns a device buffer the caller frees
+  void compute_core_full();
+  double core_norm();
+  double residual();
+  int64_t node_elems(const Node &n) const;
+
+  Ops &ops_;
+  Comm &comm_;
+  TensorDesc V_;
+  int N_;
+  std::vector<int> r_;
+  std::vector<double *> W_;
+  double *core_ = nullptr, *core_prev_ = nullptr, *Yend_ = nullptr, *G_ = nullptr, *scal_ = nullptr;
+  int64_t ncore_ = 1, yend_elems_ = 0;
+  std::vector<Node> nodes_;
+  std::vector<int> leaf_;
+  std::vector<char> contracted_;  // scratch
+};
+
+}  // namespace ppals

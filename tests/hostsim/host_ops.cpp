@@ -1,0 +1,363 @@
+// host_ops.cpp — HOST STAND-IN for the device ops (TEST INFRASTRUCTURE, never part of libppals.so).
+//
+// The ALS engine (pairwise-perturbation_amd/csrc/engine.cpp, tucker.cpp) is pure host control flow
+// over the abstract ppals::Ops / ppals::Comm interfaces. This file implements those interfaces with
+// plain loops on host memory and a callback communicator, and is linked with the SAME engine and
+// C-ABI sources into tests/hostsim/build/libppals_hostsim.so, so that on a CPU-only box the tests can
+// exercise (a) the engine's sweep / PP-restart / CSV logic and (b) the multi-rank shard plan
+// (which partial is reduce-scattered, which block is all-gathered) with torch.distributed gloo
+// behind the callbacks. It is deliberately naive and is not a fallback of the product: libppals.so
+// contains none of it and fails without a HIP device.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+
+#include "../../pairwise-perturbation_amd/csrc/backend.h"
+#include "../../pairwise-perturbation_amd/csrc/ops.h"
+
+namespace ppals {
+namespace {
+
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+inline double u01(uint64_t seed, uint64_t idx) {
+  uint64_t h = splitmix64(splitmix64(seed) ^ idx);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+inline double ld(const void *V, int dt, int64_t e) {
+  return dt == F32 ? (double)((const float *)V)[e] : ((const double *)V)[e];
+}
+inline void st(void *V, int dt, int64_t e, double v) {
+  if (dt == F32)
+    ((float *)V)[e] = (float)v;
+  else
+    ((double *)V)[e] = v;
+}
+
+// symmetric cyclic Jacobi: A (n x n, col-major, destroyed) -> eigenvalues w, eigenvectors Q
+void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, std::vector<double> &Q) {
+  Q.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) Q[i + (size_t)n * i] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i + (size_t)n * j] * A[i + (size_t)n * j];
+    if (off <= 1e-30 * diag || off == 0.0) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = A[p + (size_t)n * q];
+        if (apq == 0.0) continue;
+        double theta = (A[q + (size_t)n * q] - A[p + (size_t)n * p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int i = 0; i < n; i++) {
+          double aip = A[i + (size_t)n * p], aiq = A[i + (size_t)n * q];
+          A[i + (size_t)n * p] = c * aip - s * aiq;
+          A[i + (size_t)n * q] = s * aip + c * aiq;
+          double qip = Q[i + (size_t)n * p], qiq = Q[i + (size_t)n * q];
+          Q[i + (size_t)n * p] = c * qip - s * qiq;
+          Q[i + (size_t)n * q] = s * qip + c * qiq;
+        }
+        for (int j = 0; j < n; j++) {
+          double apj = A[p + (size_t)n * j], aqj = A[q + (size_t)n * j];
+          A[p + (size_t)n * j] = c * apj - s * aqj;
+          A[q + (size_t)n * j] = s * apj + c * aqj;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; i++) w[i] = A[i + (size_t)n * i];
+}
+
+class HostOps : public Ops {
+ public:
+  void *alloc(size_t bytes) override { return std::calloc(1, bytes ? bytes : 8); }
+  void free(void *p) override { std::free(p); }
+  void h2d(void *d, const void *s, size_t n) override { std::memcpy(d, s, n); }
+  void d2h(void *d, const void *s, size_t n) override { std::memcpy(d, s, n); }
+  void d2d(void *d, const void *s, size_t n) override { std::memmove(d, s, n); }
+  void zero(void *p, size_t n) override { std::memset(p, 0, n); }
+  void sync() override {}
+
+  void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                    uint64_t seed, double lo, double hi) override {
+    for (int64_t e = 0; e < l0 * rest; e++) {
+      int64_t a = e % l0, r = e / l0;
+      st(V, dt, e, lo + (hi - lo) * u01(seed, (uint64_t)(row0 + a) + (uint64_t)g0 * (uint64_t)r));
+    }
+  }
+  void fill_rank(void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
+                 int R) override {
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t m = 0; m < M; m++) {
+        double v = 0;
+        for (int r = 0; r < R; r++) v += Q[m + M * r] * P[k + K * r];
+        st(V, dt, m + M * k, v);
+      }
+  }
+  void residual_sq(const void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
+                   int R, double *out) override {
+    double acc = 0;
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t m = 0; m < M; m++) {
+        double v = 0;
+        if (Q)
+          for (int r = 0; r < R; r++) v += Q[m + M * r] * P[k + K * r];
+        double d = ld(V, dt, m + M * k) - v;
+        acc += d * d;
+      }
+    *out = acc;
+  }
+  void upload_shard(void *V, int dt, const double *host_full, int64_t l0, int64_t g0, int64_t row0,
+                    int64_t rest) override {
+    for (int64_t c = 0; c < rest; c++)
+      for (int64_t a = 0; a < l0; a++) st(V, dt, a + l0 * c, host_full[row0 + a + g0 * c]);
+  }
+
+  static std::vector<double> krp_mat(const FactorRef *f, int nf, int col0, int ncols, int64_t *J) {
+    int64_t j = 1;
+    for (int i = 0; i < nf; i++) j *= f[i].rows;
+    std::vector<double> B((size_t)j * ncols);
+    for (int c = 0; c < ncols; c++)
+      for (int64_t e = 0; e < j; e++) {
+        double v = 1.0;
+        int64_t rem = e;
+        for (int i = 0; i < nf; i++) {
+          int64_t jf = rem % f[i].rows;
+          rem /= f[i].rows;
+          v *= f[i].ptr[jf + f[i].ld * (col0 + c)];
+        }
+        B[e + (size_t)j * c] = v;
+      }
+    *J = j;
+    return B;
+  }
+  void krp(double *out, const FactorRef *f, int nf, int col0, int ncols) override {
+    int64_t J;
+    std::vector<double> B = krp_mat(f, nf, col0, ncols, &J);
+    std::copy(B.begin(), B.end(), out);
+  }
+  void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
+                     int nf, int R, double *out, int64_t rs) override {
+    int64_t Jc;
+    std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
+    if (Jc != J) throw std::runtime_error("hostsim: scan_contract extent mismatch");
+    prof[0].launches++;
+    prof[0].bytes += (double)L * J * T * dtype_size(dt);
+    for (int r = 0; r < R; r++)
+      for (int64_t t = 0; t < T; t++)
+        for (int64_t l = 0; l < L; l++) {
+          double acc = 0;
+          for (int64_t j = 0; j < J; j++) acc += ld(V, dt, l + L * (j + J * t)) * B[j + J * r];
+          out[l + L * t + rs * r] = acc;
+        }
+  }
+  void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
+                int64_t ldw, int Kc, double *out) override {
+    for (int64_t t = 0; t < T; t++)
+      for (int k = 0; k < Kc; k++)
+        for (int64_t l = 0; l < L; l++) {
+          double acc = 0;
+          for (int64_t j = 0; j < J; j++) acc += ld(X, dt, l + L * (j + J * t)) * W[j + ldw * k];
+          out[l + L * (k + (int64_t)Kc * t)] = acc;
+        }
+  }
+  void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
+            double *out, int64_t rs, int accumulate) override {
+    int64_t Jc;
+    std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
+    if (Jc != J) throw std::runtime_error("hostsim: mttv extent mismatch");
+    for (int r = 0; r < R; r++)
+      for (int64_t t = 0; t < T; t++)
+        for (int64_t l = 0; l < L; l++) {
+          double acc = 0;
+          for (int64_t j = 0; j < J; j++) acc += X[l + L * (j + J * (t + T * r))] * B[j + J * r];
+          double *o = out + l + L * t + rs * r;
+          *o = accumulate ? *o + acc : acc;
+        }
+  }
+  void gram(const double *W, int64_t rows, int64_t ldw, int R, double *G) override {
+    for (int p = 0; p < R; p++)
+      for (int q = 0; q < R; q++) {
+        double acc = 0;
+        for (int64_t i = 0; i < rows; i++) acc += W[i + ldw * p] * W[i + ldw * q];
+        G[p + R * q] = acc;
+      }
+  }
+  void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
+                   double *Sinv) override {
+    std::vector<double> A((size_t)R * R);
+    for (int e = 0; e < R * R; e++) {
+      double v = 1;
+      bool first = true;
+      for (int ii = 0; ii < N - 1; ii++) {
+        int j = (ii == mode) ? N - 1 : ii;
+        double gval = Gall[(size_t)j * R * R + e];
+        v = first ? gval : v * gval;
+        first = false;
+      }
+      if (e % R == e / R) v += lambda;
+      S[e] = v;
+      A[e] = v;
+    }
+    std::vector<double> w, Q;
+    jacobi_eig(R, A, w, Q);
+    for (int i = 0; i < R; i++)
+      for (int j = 0; j < R; j++) {
+        double acc = 0;
+        for (int k = 0; k < R; k++) acc += Q[i + (size_t)R * k] * (1.0 / w[k]) * Q[j + (size_t)R * k];
+        Sinv[i + R * j] = acc;
+      }
+  }
+  void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
+                 int64_t ldn, double *grad, int64_t ldg, int64_t rows, int R, const double *S,
+                 const double *Sinv, double *gradsq, const double *Winit, int64_t ldi, double *dW,
+                 int64_t ldd, double ratio) override {
+    double gs = 0;
+    for (int j = 0; j < R; j++)
+      for (int64_t i = 0; i < rows; i++) {
+        double acc = 0;
+        for (int k = 0; k < R; k++) acc += Wold[i + ldw * k] * S[k + R * j];
+        double gv = -M[i + ldm * j] + acc;
+        grad[i + ldg * j] = gv;
+        gs += gv * gv;
+      }
+    *gradsq = gs;
+    std::vector<double> out((size_t)rows * R);
+    for (int j = 0; j < R; j++)
+      for (int64_t i = 0; i < rows; i++) {
+        double acc = 0;
+        for (int k = 0; k < R; k++) acc += M[i + ldm * k] * Sinv[k + R * j];
+        if (Winit) {
+          double wi = Winit[i + ldi * j], d = ratio * (acc - wi);
+          dW[i + ldd * j] = d;
+          if (ratio != 1.0) acc = wi + d;
+        }
+        out[i + rows * j] = acc;
+      }
+    for (int j = 0; j < R; j++)
+      for (int64_t i = 0; i < rows; i++) Wnew[i + ldn * j] = out[i + rows * j];
+  }
+  void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) override {
+    std::vector<double> nrm(N);
+    double prod = 1;
+    for (int i = 0; i < N; i++) {
+      double tr = 0;
+      for (int k = 0; k < R; k++) tr += Gall[(size_t)i * R * R + k + R * k];
+      nrm[i] = std::sqrt(tr);
+      prod *= nrm[i];
+    }
+    double c = std::pow(prod, 1.0 / N);
+    for (int i = 0; i < N; i++) {
+      double f = c / nrm[i];
+      for (int64_t e = 0; e < rows[i] * R; e++) W[i][e] *= f;
+      for (int e = 0; e < R * R; e++) Gall[(size_t)i * R * R + e] *= f * f;
+    }
+  }
+  void diff_norms(double *const *A, double *const *B, const int64_t *n, int N, int store_diff,
+                  double *const *D, int update_prev, double *out) override {
+    for (int i = 0; i < N; i++) {
+      double sd = 0, sa = 0;
+      for (int64_t e = 0; e < n[i]; e++) {
+        double av = A[i][e], dv;
+        if (B && B[i]) {
+          dv = av - B[i][e];
+          if (store_diff) D[i][e] = dv;
+          if (update_prev) B[i][e] = av;
+        } else {
+          dv = D[i][e];
+        }
+        sd += dv * dv;
+        sa += av * av;
+      }
+      out[2 * i] = sd;
+      out[2 * i + 1] = sa;
+    }
+  }
+  void pack_blocks(const double *nat, int64_t rows, int64_t ldn, int R, int64_t blk, int P,
+                   double *blocked) override {
+    for (int p = 0; p < P; p++)
+      for (int r = 0; r < R; r++)
+        for (int64_t x = 0; x < blk; x++) {
+          int64_t row = (int64_t)p * blk + x;
+          blocked[x + blk * (r + (int64_t)R * p)] = row < rows ? nat[row + ldn * r] : 0.0;
+        }
+  }
+  void unpack_blocks(const double *blocked, int64_t rows, int64_t ldn, int R, int64_t blk, int P,
+                     double *nat) override {
+    for (int p = 0; p < P; p++)
+      for (int r = 0; r < R; r++)
+        for (int64_t x = 0; x < blk; x++) {
+          int64_t row = (int64_t)p * blk + x;
+          if (row < rows) nat[row + ldn * r] = blocked[x + blk * (r + (int64_t)R * p)];
+        }
+  }
+  void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) override {
+    for (int64_t p = 0; p < J; p++)
+      for (int64_t q = 0; q < J; q++) {
+        double acc = 0;
+        for (int64_t t = 0; t < T; t++)
+          for (int64_t l = 0; l < L; l++)
+            acc += ld(X, dt, l + L * (p + J * t)) * ld(X, dt, l + L * (q + J * t));
+        G[p + J * q] = acc;
+      }
+  }
+  void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
+    std::vector<double> A(G, G + J * J), w, Q;
+    jacobi_eig((int)J, A, w, Q);
+    std::vector<int> ord(J);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return w[a] > w[b]; });
+    for (int k = 0; k < rank; k++)
+      for (int64_t i = 0; i < J; i++) U[i + J * k] = Q[i + (size_t)J * ord[k]];
+  }
+  void sumsq(const double *x, int64_t n, double *out) override {
+    double s = 0;
+    for (int64_t i = 0; i < n; i++) s += x[i] * x[i];
+    *out = s;
+  }
+};
+
+// communicator driven by callbacks (the tests put torch.distributed/gloo behind them)
+struct CommCallbacks {
+  void (*allreduce)(double *buf, int64_t n);
+  void (*reduce_scatter)(const double *send, double *recv, int64_t recvcount);
+  void (*allgather)(const double *send, double *recv, int64_t sendcount);
+};
+class CallbackComm : public Comm {
+ public:
+  CallbackComm(int rank, int size, const CommCallbacks &cb) : rank_(rank), size_(size), cb_(cb) {}
+  int rank() const override { return rank_; }
+  int size() const override { return size_; }
+  void allreduce_sum(double *buf, int64_t n) override { cb_.allreduce(buf, n); }
+  void reduce_scatter_sum(const double *s, double *r, int64_t n) override {
+    cb_.reduce_scatter(s, r, n);
+  }
+  void allgather(const double *s, double *r, int64_t n) override { cb_.allgather(s, r, n); }
+
+ private:
+  int rank_, size_;
+  CommCallbacks cb_;
+};
+
+}  // namespace
+
+const char *backend_name() { return "ppals hostsim (TEST INFRASTRUCTURE: host stand-in ops)"; }
+Ops *backend_make_ops(int) { return new HostOps(); }
+void backend_unique_id(void *out128) { std::memset(out128, 0, 128); }
+// in the hostsim library the "unique id" argument carries the three callback pointers
+Comm *backend_make_comm(Ops *, int rank, int nranks, const void *uid128) {
+  CommCallbacks cb;
+  std::memcpy(&cb, uid128, sizeof(cb));
+  return new CallbackComm(rank, nranks, cb);
+}
+
+}  // namespace ppals

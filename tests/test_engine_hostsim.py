@@ -1,0 +1,29 @@
+"""CPU tests of the engine's HOST LOGIC: the very same cases as tests/test_gpu_cp.py, but with the
+engine + C ABI linked against the host stand-in ops (tests/hostsim). They check the sweep / tree /
+PP-restart / CSV control flow of pairwise-perturbation_amd/csrc/engine.cpp against the oracle on a
+box without a GPU. They say nothing about the HIP kernels — that is what `-m gpu` is for."""
+import pytest
+
+import hostsim_util
+import test_gpu_cp as G
+
+
+@pytest.fixture(scope="module")
+def pp():
+    return hostsim_util.load()
+
+
+@pytest.fixture(scope="module")
+def ctx(pp):
+    c = pp.Context(0)
+    yield c
+    c.close()
+
+
+test_fill_and_norm = G.test_fill_and_norm
+test_tree_nodes_and_mttkrp = G.test_tree_nodes_and_mttkrp
+test_pp_operators = G.test_pp_operators
+test_gram_system = G.test_gram_system
+test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
+test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
+test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle

@@ -1,0 +1,214 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(libppals.so via ctypes), against the fp64 CPU oracle on the same seeded inputs.
+
+Tolerances: fp64 tensor storage -> 1e-10 relative (pure rounding-order differences); fp32 tensor
+storage -> kernels 2e-6 relative, factor matrices after sweeps 1e-5 relative Frobenius (the
+tolerance BASELINE.json's north_star states)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+KTOL = {0: 2e-6, 1: 1e-10}   # per-kernel relative Frobenius tolerance by dtype (F32, F64)
+FTOL = {0: 1e-5, 1: 1e-8}    # factor matrices after several sweeps
+
+
+@pytest.fixture(scope="module")
+def pp():
+    import ppals
+    return ppals
+
+
+@pytest.fixture(scope="module")
+def ctx(pp):
+    c = pp.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def problem(lens, R, seed, kind="r2"):
+    if kind == "r":
+        Wt = O.init_factors(lens, R, 1000 + seed)
+        V = O.build_V(Wt)
+    else:
+        V = O.fill_uniform(int(np.prod(lens)), 77 + seed, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W = O.init_factors(lens, R, 2000 + seed)
+    return V, W
+
+
+SHAPES = [
+    ([8, 8, 8, 8], 3),        # aligned everywhere
+    ([5, 6, 7, 4], 3),        # nothing aligned, tiny tails
+    ([20, 12, 16, 10], 10),   # headline rank
+    ([16, 8, 12, 8], 20),     # two n-tiles
+    ([8, 4, 8, 4], 40),       # four n-tiles (padded to 64)
+    ([24, 10, 9], 5),         # order 3 (generalised tree)
+    ([6, 5, 4, 3, 4], 4),     # order 5
+    ([4, 3, 4, 3, 2, 3], 2),  # order 6
+    ([70, 66, 5, 3], 6),      # M spans several waves / workgroups, short K
+    ([3, 5, 40, 37], 6),      # long K (split-K path), short M
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_fill_and_norm(pp, ctx, dtype):
+    lens = [7, 6, 5, 9]
+    t = pp.Tensor(ctx, lens, dtype).fill_uniform(123, 0.5, 1.0)
+    ref = O.fill_uniform(int(np.prod(lens)), 123, lo=0.5, hi=1.0)
+    assert abs(t.norm() - np.linalg.norm(ref)) < (1e-6 if dtype == 0 else 1e-12) * np.linalg.norm(ref)
+    Wt = O.init_factors(lens, 4, 5)
+    t2 = pp.Tensor(ctx, lens, dtype).fill_cp(Wt)
+    V = O.build_V(Wt)
+    assert abs(t2.norm() - np.linalg.norm(V)) < (1e-6 if dtype == 0 else 1e-12) * np.linalg.norm(V)
+    s = pp.CP(ctx, t2, 4)
+    s.set_factors(Wt)
+    assert s.residual() < (1e-6 if dtype == 0 else 1e-12) * np.linalg.norm(V)
+    W2 = O.init_factors(lens, 4, 6)
+    s.set_factors(W2)
+    assert abs(s.residual() - O.residual(V, W2)) < (1e-6 if dtype == 0 else 1e-11) * O.residual(V, W2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", SHAPES)
+def test_tree_nodes_and_mttkrp(pp, ctx, lens, R, dtype):
+    """K1/K2/K3: every first-level node and every mode's MTTKRP vs the oracle"""
+    V, W = problem(lens, R, 1)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W)
+    tree = O.dimension_tree(len(lens))
+    N = len(lens)
+    for key, info in tree.items():
+        if len(info["parent"]) != N or len(key) == 1:
+            continue
+        got = s.tree_node(key)
+        want = O.tree_node(V, W, key).ravel(order="F")
+        assert relerr(got, want) < KTOL[dtype], (key, relerr(got, want))
+    for mode in range(N):
+        got = s.mttkrp(mode)
+        want = O.mttkrp(V, W, mode, 0)
+        assert relerr(got, want) < KTOL[dtype], (mode, relerr(got, want))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", [([8, 8, 8, 8], 3), ([5, 6, 7, 4], 3), ([12, 10, 9, 11], 10),
+                                    ([9, 8, 7], 4), ([5, 4, 3, 4, 3], 2)])
+def test_pp_operators(pp, ctx, lens, R, dtype):
+    """K8: every pair operator and every full MTTKRP of the PP cache vs the oracle"""
+    V, W = problem(lens, R, 2)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W)
+    N = len(lens)
+    keys = []
+    for i in range(N):
+        for j in range(i + 1, N):
+            keys.append("".join(chr(97 + m) for m in range(N) if m not in (i, j)))
+        keys.append("".join(chr(97 + m) for m in range(N) if m != i))
+    for key in keys:
+        got = s.pp_operator(key)
+        want = O.pp_operator(V, W, key).ravel(order="F")
+        assert relerr(got, want) < KTOL[dtype], (key, relerr(got, want))
+
+
+@pytest.mark.parametrize("R", [3, 10, 20, 33])
+def test_gram_system(pp, ctx, R):
+    """K4 + the S^-1 of K6 vs the oracle's Hadamard/Gram and numpy's inverse"""
+    lens = [40, 36, 50, 44]
+    W = O.init_factors(lens, R, 7)
+    t = pp.Tensor(ctx, [4, 4, 4, 4], 1).fill_uniform(1)
+    t2 = pp.Tensor(ctx, lens, 0)
+    s = pp.CP(ctx, t2, R)
+    s.set_factors(W)
+    for mode in range(4):
+        S, Si = s.gram_system(mode, 0.125)
+        want = O.gram_hadamard(W, mode, 0.125)
+        assert relerr(S, want) < 1e-13
+        assert relerr(Si @ want, np.eye(R)) < 1e-9 * np.linalg.cond(want)
+        X = O.svd_solve(np.eye(R), want)
+        assert relerr(Si, X) < 1e-9 * np.linalg.cond(want)
+    del t
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R,kind", [([12, 10, 9, 11], 4, "r"), ([12, 10, 9, 11], 4, "r2"),
+                                         ([16, 16, 16, 16], 10, "r"), ([14, 9, 11], 3, "r"),
+                                         ([6, 5, 4, 5, 4, 3], 2, "r")])
+def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype):
+    """K sweeps of the HIP engine == K sweeps of alsCP_DT in the oracle (factor matrices within
+    1e-5 relative Frobenius for fp32 storage)"""
+    V, W = problem(lens, R, 3, kind)
+    G = O.init_factors(lens, R, 99)
+    K = 5
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    s.sweeps_dt(K)
+    W_got, G_got = s.get_factors(with_grad=True)
+    for a, b in zip(W_got, W_ref):
+        assert relerr(a, b) < FTOL[dtype], relerr(a, b)
+    gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
+    assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
+    assert abs(s.residual() - O.residual(V, W_ref)) < 1e-4 * np.linalg.norm(V) * (1 if dtype == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_driver_dt_csv_matches_oracle(pp, ctx, dtype, tmp_path):
+    lens, R = [10, 9, 8, 7], 3
+    V, W = problem(lens, R, 4, "r")
+    G = O.init_factors(lens, R, 98)
+    Vn = np.linalg.norm(V)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    rc_ref, it_ref, W_ref, _ = O.als_cp_dt(V, W, G, tol=1e-7 * Vn, maxiter=60, csv=c_ref, resprint=5)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    Wl = [w.copy(order="F") for w in W]
+    Gl = [g.copy(order="F") for g in G]
+    ok = pp.alsCP_DT(t, Wl, Gl, 1e-7 * Vn, 5e3, 60, 0.0, c_got, 5, False, ctx)
+    h1, r1 = O.read_csv(c_ref)
+    h2, r2 = O.read_csv(c_got)
+    assert h1 == h2
+    if dtype == 1:
+        assert ok == bool(rc_ref) and len(r1) == len(r2)
+    n = min(len(r1), len(r2))
+    for a, b in zip(r1[:n], r2[:n]):
+        assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
+        tolr = 1e-3 if dtype == 0 else 1e-5
+        assert abs(a[2] - b[2]) <= tolr * abs(a[2]) + 1e-5 * Vn * (1 if dtype == 0 else 1e-6)
+        assert abs(a[5] - b[5]) <= tolr * abs(a[5]) + 2e-6 * Vn * (1 if dtype == 0 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_driver_pp_matches_oracle(pp, ctx, dtype, tmp_path):
+    lens, R = [12, 11, 10, 9], 3
+    V, W = problem(lens, R, 5, "r")
+    G = O.init_factors(lens, R, 97)
+    Vn = np.linalg.norm(V)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    kw = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=40, resprint=1)
+    rc_ref, it_ref, W_ref, _ = O.als_cp_pp(V, W, G, csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    Wl = [w.copy(order="F") for w in W]
+    Gl = [g.copy(order="F") for g in G]
+    pp.alsCP_PP(t, Wl, Gl, kw["tol"], kw["tol_init"], 5e3, kw["maxiter"], 0.0, 1.0, c_got, 1,
+                False, ctx)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert any(r[4] == 1 for r in r2), "PP phase never entered"
+    n = min(len(r1), len(r2))
+    assert n >= 5
+    # same DT/PP phase pattern and matching trajectories while both are far from the noise floor
+    for a, b in zip(r1[:n], r2[:n]):
+        if a[5] < 1e-4 * Vn:
+            break
+        assert a[1] == b[1] and a[4] == b[4], (a, b)
+        assert abs(a[5] - b[5]) <= (2e-3 if dtype == 0 else 1e-5) * abs(a[5])
+    if dtype == 1:
+        for a, b in zip(Wl, W_ref):
+            assert relerr(a, b) < 1e-6
