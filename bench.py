@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — ALS sweeps/s of the MI355X-native CP engine on BASELINE.json's headline problem.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE exact dimension-tree ALS sweep (the body of alsCP_DT's loop incl. Normalize,
+reference als_CP.cxx:215-303) of the order-4 s=200 R=10 CP problem of BASELINE.json configs[1]
+(`-tensor r`: V = [[W_true]], W_true and W0 ~ U(0,1)), tensor resident in HBM before the timed
+region. With N > 1 the SAME tensor is block-partitioned along its leading mode over the N ranks
+(strong scaling), one process per GPU, factor-matrix partials reduce-scattered over RCCL.
+
+One JSON line is printed by rank 0; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pairwise-perturbation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (lens, R)   — BASELINE.json configs[1] and configs[3]
+    "cp4_s200_r10": ([200, 200, 200, 200], 10),
+    "cp4_s400_r20": ([400, 400, 400, 400], 20),
+    "cp4_s64_r10": ([64, 64, 64, 64], 10),  # smoke-sized
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def sweep_flops(lens, R):
+    """algorithmic flops of one N=4 DT sweep: 4 s^4 R + 4 s^3 R + 8 s^2 R"""
+    s = lens[0]
+    return 4.0 * s ** 4 * R + 4.0 * s ** 3 * R + 8.0 * s ** 2 * R
+
+
+def cpu_baseline(lens, R, budget_s=20.0):
+    """the fp64 oracle (CTF-like contraction sequence, OpenMP) timed on this host's cores on a
+    bounded sample: the same problem at reduced mode size, scaled by s^4"""
+    import numpy as np
+    import oracle_lib as O
+    s_full = lens[0]
+    s = min(s_full, 96)
+    small = [s] * len(lens)
+    Wt = O.init_factors(small, R, 1000)
+    V = O.build_V(Wt)
+    W = O.init_factors(small, R, 2000)
+    G = O.init_factors(small, R, 3000)
+    t0 = time.time()
+    _, _, W1, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # 1 sweep (+1 print)
+    t_one = time.time() - t0
+    k = max(1, min(10, int(budget_s / max(t_one, 1e-3))))
+    t0 = time.time()
+    O.als_cp_dt(V, W, G, tol=0.0, maxiter=k - 1, resprint=10 ** 9)
+    t = time.time() - t0
+    # subtract the two untimed-in-the-reference print blocks (iter 0 and iter maxiter): measure one
+    t0 = time.time()
+    O.residual(V, W)
+    t_print = time.time() - t0
+    per_sweep_small = max((t - 2 * t_print) / k, 1e-9)
+    scale = (s_full / s) ** 4
+    return {
+        "value": 1.0 / (per_sweep_small * scale),
+        "unit": "sweeps/s",
+        "cores": O.lib().ppo_num_threads(),
+        "kind": "port",
+        "sample": f"{k} sweeps of the same CP order-4 R={R} problem at s={s} (fp64, OpenMP oracle "
+                  f"with the reference's TTM-by-TTM contraction order), {per_sweep_small:.3f} s/sweep, "
+                  f"scaled by (s/{s})^4 = {scale:.1f} to s={s_full}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cp4_s200_r10", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
+                    help="storage type of the tensor in HBM (all factor math is fp64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch  # first: libppals.so then shares torch's libamdhip64 / librccl
+    import ppals
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    lens, R = WORKLOADS[args.workload]
+    dtype = ppals.F32 if args.dtype == "f32" else ppals.F64
+    ctx = ppals.Context(local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(ppals.Context.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        ctx.init_comm(rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+    Wtrue = ppals.init_factors(lens, R, 1000)
+    W0 = ppals.init_factors(lens, R, 2000)
+    G0 = ppals.init_factors(lens, R, 3000)
+    V = ppals.Tensor(ctx, lens, dtype).fill_cp(Wtrue)
+    cp = ppals.CP(ctx, V, R)
+    cp.set_factors(W0, G0)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    cp.sweeps_dt(args.warmup)
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    cp.sweeps_dt(args.steps)
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+
+    launches, scan_ms, scan_bytes = ctx.profile_read(0)
+    _, other_ms, _ = ctx.profile_read(1)
+    gradnorm = cp.gradnorm()
+    resid = cp.residual()
+    vnorm = V.norm()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        sweeps_s = args.steps / elapsed
+        flops = sweep_flops(lens, R)
+        esz = 4 if args.dtype == "f32" else 8
+        out = {
+            "metric": "ALS sweeps/sec (exact dimension-tree sweep, CP order-4 "
+                      f"s={lens[0]} R={R})",
+            "value": sweeps_s,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"CP order-4 s={lens[0]} R={R} dense `-tensor r` (V=[[W_true]], "
+                                   "U(0,1) factors), -pp 0 exact DT sweep incl. Normalize; tensor "
+                                   f"stored {args.dtype} in HBM, factor/Gram/solve math fp64",
+                       "lens": lens, "rank": R, "sharding": f"leading-mode block x{world}"},
+            "mttkrp_tflops": flops * sweeps_s / 1e12,
+            "sweep_flops": flops,
+            "final_gradnorm": gradnorm,
+            "final_rel_residual": resid / vnorm,
+        }
+        if launches > 0:
+            avg_ms = scan_ms / launches
+            achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_scan_suffix/k_scan_prefix (tensor scans K1/K2)",
+                "launches": launches, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": scan_bytes / launches,
+                "scan_ms_per_step": scan_ms / args.steps,
+                "other_profiled_ms_per_step": other_ms / args.steps,
+                "note": f"algorithmic bytes = one read of the local tensor shard "
+                        f"({esz} B/elem) per scan launch, 2 launches per sweep",
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(lens, R)
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 0,
+                                       "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+
+    cp.close()
+    V.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ factor matrices are (s_i, R) Fortran-ordered.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -103,6 +104,7 @@ class Context:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
+        self._children = weakref.WeakSet()  # tensors / sessions that must die before the context
         _check(lib().ppals_ctx_create(C.byref(self._h), device))
 
     def init_comm(self, rank, nranks, unique_id):
@@ -138,6 +140,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for ch in sorted(list(self._children), key=lambda c: isinstance(c, Tensor)):
+                ch.close()  # sessions first, then tensors
             lib().ppals_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -158,6 +162,7 @@ class Tensor:
         self._h = C.c_void_p()
         arr = (C.c_int64 * len(lens))(*self.lens)
         _check(lib().ppals_tensor_create(ctx._h, len(lens), arr, dtype, C.byref(self._h)))
+        ctx._children.add(self)
 
     def local_rows(self):
         lo, n = C.c_int64(0), C.c_int64(0)
@@ -211,6 +216,7 @@ class CP:
         self.lens = V.lens
         self._h = C.c_void_p()
         _check(lib().ppals_cp_create(ctx._h, V._h, R, C.byref(self._h)))
+        ctx._children.add(self)
 
     def set_factors(self, Ws, gradWs=None):
         wf = flat(Ws)
@@ -296,6 +302,7 @@ class Tucker:
         self._h = C.c_void_p()
         arr = (C.c_int * len(ranks))(*self.ranks)
         _check(lib().ppals_tucker_create(ctx._h, V._h, arr, C.byref(self._h)))
+        ctx._children.add(self)
 
     def set_factors(self, Ws):
         wf = flat(Ws)

@@ -1,0 +1,110 @@
+"""One rank of the world_size-N CPU rehearsal of the sharded engine (TEST INFRASTRUCTURE).
+
+Runs the product's engine + C ABI over the host stand-in ops with torch.distributed (gloo) behind
+the communicator callbacks, on a tensor block-partitioned along its leading mode, and checks the
+result against the unsharded fp64 oracle. Launched by tests/test_multirank_gloo.py."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import hostsim_util  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pp = hostsim_util.load()
+    ctx = pp.Context(0)
+
+    AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64)
+    RS = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+    AG = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+    calls = {"ar": 0, "rs": 0, "ag": 0}
+
+    def allreduce(buf, n):
+        calls["ar"] += 1
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, (n,)))
+        dist.all_reduce(t)
+
+    def reduce_scatter(send, recv, n):  # gloo has no reduce_scatter: all_reduce + slice
+        calls["rs"] += 1
+        t = torch.from_numpy(np.ctypeslib.as_array(send, (n * world,)).copy())
+        dist.all_reduce(t)
+        np.ctypeslib.as_array(recv, (n,))[:] = t.numpy()[rank * n:(rank + 1) * n]
+
+    def allgather(send, recv, n):
+        calls["ag"] += 1
+        mine = torch.from_numpy(np.ctypeslib.as_array(send, (n,)).copy())
+        outs = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, mine)
+        np.ctypeslib.as_array(recv, (n * world,))[:] = torch.cat(outs).numpy()
+
+    cbs = (AR(allreduce), RS(reduce_scatter), AG(allgather))
+    uid = C.create_string_buffer(128)
+    for i, cb in enumerate(cbs):
+        C.memmove(C.byref(uid, 8 * i), C.byref(C.cast(cb, C.c_void_p)), 8)
+    ctx.init_comm(rank, world, uid)
+    assert ctx.nranks == world and ctx.rank == rank
+
+    def relerr(a, b):
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+    for lens, R, dtype in [([10, 7, 6, 5], 3, 1), ([9, 8, 7, 6], 4, 0), ([11, 6, 5], 2, 1),
+                           ([8, 4, 5, 4, 3, 3], 2, 1)]:
+        Wt = O.init_factors(lens, R, 1234)
+        V = O.build_V(Wt)
+        W = O.init_factors(lens, R, 4321)
+        G = O.init_factors(lens, R, 99)
+        t = pp.Tensor(ctx, lens, dtype).upload(V)
+        lo, n = t.local_rows()
+        blk = -(-lens[0] // world)
+        assert lo == rank * blk and n == min(blk, lens[0] - lo)
+        assert abs(t.norm() - np.linalg.norm(V)) < 1e-6 * np.linalg.norm(V)
+        s = pp.CP(ctx, t, R)
+        s.set_factors(W, G)
+        tol = 1e-10 if dtype == 1 else 2e-6
+        for mode in range(len(lens)):
+            assert relerr(s.mttkrp(mode), O.mttkrp(V, W, mode, 0)) < tol
+        assert abs(s.residual() - O.residual(V, W)) < 1e-6 * O.residual(V, W)
+        K = 4
+        _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+        s.sweeps_dt(K)
+        W_got, G_got = s.get_factors(with_grad=True)
+        for a, b in zip(W_got, W_ref):
+            assert relerr(a, b) < (1e-8 if dtype == 1 else 1e-5), relerr(a, b)
+        for a, b in zip(G_got, G_ref):
+            assert np.linalg.norm(a - b) < (1e-7 if dtype == 1 else 1e-3) * (1 + np.linalg.norm(b))
+        gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
+        assert abs(s.gradnorm() - gn_ref) < 1e-4 * gn_ref + 1e-9
+        # PP driver, sharded, against the unsharded oracle
+        Vn = np.linalg.norm(V)
+        csv = f"/tmp/ppals_gloo_{os.getpid()}.csv"
+        kw = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=30, resprint=1)
+        _, _, W_pp_ref, _ = O.als_cp_pp(V, W, G, csv=csv + ".ref", **kw)
+        s.set_factors(W, G)
+        s.run_pp(csv=csv if rank == 0 else None, **kw)
+        W_pp = s.get_factors()
+        if dtype == 1:
+            for a, b in zip(W_pp, W_pp_ref):
+                assert relerr(a, b) < 1e-6, relerr(a, b)
+            if rank == 0:
+                _, r1 = O.read_csv(csv + ".ref")
+                _, r2 = O.read_csv(csv)
+                assert [r[:2] + [r[4]] for r in r1] == [r[:2] + [r[4]] for r in r2]
+                assert any(r[4] == 1 for r in r2)
+        s.close()
+        t.close()
+    assert calls["rs"] > 0 and calls["ag"] > 0 and calls["ar"] > 0
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: OK", calls)
+
+
+if __name__ == "__main__":
+    main()
