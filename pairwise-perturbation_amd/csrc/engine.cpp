@@ -257,9 +257,9 @@ void CpEngine::compute_node(int idx) {
   const bool sib_is_suffix = n.slo > n.hi;
   if (n.parent < 0) {
     if (sib_is_suffix)
-      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, n.elems);
+      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, n.elems, n.elems);
     else
-      ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, n.elems);
+      ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, 1, n.elems);
   } else {
     compute_node(n.parent);
     const Node &p = nodes_[n.parent];
@@ -481,7 +481,7 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     }
     op.elems = L * T;
     op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, op.elems);
+    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, L, op.elems);
   } else {
     const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
     int64_t L = 1, T = 1;

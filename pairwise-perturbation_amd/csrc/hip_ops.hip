@@ -1,5 +1,6 @@
 // hip_ops.hip — the product implementation of ppals::Ops: hand-written HIP kernels for gfx950,
 // launched on one engine-owned stream. No CPU fallback: construction throws without a HIP device.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -208,7 +209,7 @@ class HipOps : public Ops {
   // ------------------------------------------------------------------ scans
   template <typename TV>
   void scan_t(const TV *V, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
-              double *out, int64_t out_rstride) {
+              double *out, int64_t out_tstride, int64_t out_rstride) {
     constexpr int VEC = ScanTraits<TV>::VEC;
     int64_t Jc;
     KrpArgs a = krp_args(f, nf, &Jc);
@@ -241,9 +242,10 @@ class HipOps : public Ops {
         const int per = (nblk + nsplit - 1) / nsplit;
         nsplit = (nblk + per - 1) / per;
         double *dst = o;
-        int64_t dst_ns = out_rstride, dst_ss = 0;
+        int64_t dst_ks = out_tstride, dst_ns = out_rstride, dst_ss = 0;
         if (nsplit > 1) {
           dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * K);
+          dst_ks = 1;
           dst_ns = K;
           dst_ss = (int64_t)ncols * K;
         }
@@ -251,7 +253,7 @@ class HipOps : public Ops {
         prof_begin(0, bytes);
 #define LAUNCH_PREFIX(NTv, ALv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
-                     nblk, dst, dst_ns, dst_ss, ncols)
+                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
         if (al) {
           if (NT == 1) LAUNCH_PREFIX(1, true);
           else if (NT == 2) LAUNCH_PREFIX(2, true);
@@ -266,7 +268,7 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(K * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, K, ncols, o, out_rstride);
+                             nsplit, dst_ss, K, ncols, o, out_tstride, out_rstride);
           HIP_CHECK(hipGetLastError());
         }
       } else {
@@ -284,7 +286,7 @@ class HipOps : public Ops {
         const int per = (nblk + nsplit - 1) / nsplit;
         nsplit = (nblk + per - 1) / per;
         double *dst = o;
-        int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = L;
+        int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = out_tstride;
         if (nsplit > 1) {
           dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M);
           dst_ns = M;
@@ -312,23 +314,19 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, M, ncols, o, out_rstride);
+                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride);
           HIP_CHECK(hipGetLastError());
         }
       }
     }
   }
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
-                     int nf, int R, double *out, int64_t out_rstride) override {
+                     int nf, int R, double *out, int64_t out_tstride,
+                     int64_t out_rstride) override {
     if (dt == F32)
-      scan_t<float>((const float *)V, L, J, T, f, nf, R, out, out_rstride);
+      scan_t<float>((const float *)V, L, J, T, f, nf, R, out, out_tstride, out_rstride);
     else
-      scan_t<double>((const double *)V, L, J, T, f, nf, R, out, out_rstride);
-  }
-
-  void ttm_keep(const void *, int, int64_t, int64_t, int64_t, const double *, int64_t, int,
-                double *) override {
-    throw std::runtime_error("ppals: Tucker ttm_keep not implemented in this build");
+      scan_t<double>((const double *)V, L, J, T, f, nf, R, out, out_tstride, out_rstride);
   }
 
   // ------------------------------------------------------------------ mttv
@@ -424,11 +422,49 @@ class HipOps : public Ops {
                        blocked, rows, ld, R, blk, P, nat);
     HIP_CHECK(hipGetLastError());
   }
-  void unfold_gram(const void *, int, int64_t, int64_t, int64_t, double *) override {
-    throw std::runtime_error("ppals: Tucker unfold_gram not implemented in this build");
+  // K12/K13: Gram of the mode unfolding (fp64 accumulation), reduction split over grid.z slabs
+  void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) override {
+    const int64_t C = L * T;
+    const int tiles = (int)((J + 31) / 32);
+    int nsplit = 1;
+    const int64_t want = (int64_t)ncu_ * 4;
+    if ((int64_t)tiles * tiles < want) nsplit = (int)std::min<int64_t>(
+        (want + (int64_t)tiles * tiles - 1) / ((int64_t)tiles * tiles), std::max<int64_t>(1, C / 256));
+    nsplit = std::max(1, std::min(nsplit, 1024));
+    int64_t per = (C + nsplit - 1) / nsplit;
+    per = (per + 31) / 32 * 32;
+    nsplit = (int)((C + per - 1) / per);
+    double *dst = G;
+    if (nsplit > 1) dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * J * J);
+    dim3 grid(tiles, tiles, nsplit);
+    prof_begin(1, (double)C * J * dtype_size(dt));
+    if (dt == F32)
+      hipLaunchKernelGGL(k_unfold_gram<float>, grid, dim3(256), 0, st_, (const float *)X, L, J, T,
+                         per, dst);
+    else
+      hipLaunchKernelGGL(k_unfold_gram<double>, grid, dim3(256), 0, st_, (const double *)X, L, J,
+                         T, per, dst);
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+    if (nsplit > 1) {
+      hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(J * J, 256)), dim3(256), 0, st_, dst, nsplit,
+                         J * J, J * J, 1, G, (int64_t)1, (int64_t)0);
+      HIP_CHECK(hipGetLastError());
+    }
   }
-  void top_eigvecs(double *, int64_t, int, double *) override {
-    throw std::runtime_error("ppals: Tucker top_eigvecs not implemented in this build");
+  // Leading eigenvectors of the s x s Gram (the reference's MTM.svd(U,S,VT,rank),
+  // als_Tucker.cxx:20,402). SURVEY.md §2.1 K12 allows the vendor symmetric eigensolver here:
+  // rocSOLVER dsyevd, resolved with dlopen on first use (only Tucker sessions ever load it).
+  void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
+    RocSolver &rs = rocsolver();
+    double *D = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * (2 * J + 2));
+    double *E = D + J;
+    int *info = (int *)(E + J);
+    int rc = rs.dsyevd(rs.handle, 211 /*evect_original*/, 121 /*fill_upper*/, (int)J, G, (int)J, D,
+                       E, info);
+    if (rc != 0) throw std::runtime_error("ppals: rocsolver_dsyevd failed");
+    hipLaunchKernelGGL(k_take_top, dim3(grid_for(J * rank, 256)), dim3(256), 0, st_, G, J, rank, U);
+    HIP_CHECK(hipGetLastError());
   }
   void sumsq(const double *x, int64_t n, double *out) override {
     int g = grid_for(n, 256, 1024);
@@ -454,6 +490,27 @@ class HipOps : public Ops {
   }
 
  private:
+  struct RocSolver {
+    void *handle = nullptr;
+    int (*dsyevd)(void *, int, int, int, double *, int, double *, double *, int *) = nullptr;
+  };
+  RocSolver &rocsolver() {
+    if (rs_.handle) return rs_;
+    void *lb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!lb) lb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void *ls = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!ls) ls = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lb || !ls) throw std::runtime_error(std::string("ppals: cannot load rocSOLVER: ") + dlerror());
+    auto create = (int (*)(void **))dlsym(lb, "rocblas_create_handle");
+    auto set_stream = (int (*)(void *, hipStream_t))dlsym(lb, "rocblas_set_stream");
+    *(void **)(&rs_.dsyevd) = dlsym(ls, "rocsolver_dsyevd");
+    if (!create || !set_stream || !rs_.dsyevd)
+      throw std::runtime_error("ppals: rocSOLVER symbols missing");
+    if (create(&rs_.handle) != 0 || set_stream(rs_.handle, st_) != 0)
+      throw std::runtime_error("ppals: rocblas handle creation failed");
+    return rs_;
+  }
+  RocSolver rs_;
   struct Ev {
     hipEvent_t a, b;
     int slot;

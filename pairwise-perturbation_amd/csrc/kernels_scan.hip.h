@@ -182,14 +182,15 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
 
 // ---------------------------------------------------------------------------------------------
 // prefix scan (K2 / leading-mode TTM):
-//   out[k + n*out_nstride (+ split offset)] = sum_{m in split} V[m + M*k] * B[m,n]
+//   out[k*out_kstride + n*out_nstride (+ split offset)] = sum_{m in split} V[m + M*k] * B[m,n]
 // grid: (ceil(K/64), nsplit); each wave owns 16 consecutive columns k (lane&15), the 4 lane groups
 // g take VEC consecutive reduction rows each, so one step reads 16 columns x 4*VEC rows; UNROLL
 // steps are issued back to back to keep >= UNROLL KiB per wave in flight.
 template <typename TV, int NT, bool ALIGNED, int UNROLL>
 __global__ __launch_bounds__(256) void k_scan_prefix(
     const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
-    int nmb, double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride, int ncols) {
+    int nmb, double *__restrict__ out, int64_t out_kstride, int64_t out_nstride,
+    int64_t out_split_stride, int ncols) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix(
       if (n < ncols && k_ok) {
         double val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
         if constexpr (TR::NEEDS_FLUSH) val += acc64[nt][r];
-        o[(int64_t)n * out_nstride + k] = val;
+        o[(int64_t)n * out_nstride + k * out_kstride] = val;
       }
     }
 }
@@ -321,9 +322,9 @@ __global__ void k_krp_pack(TV *__restrict__ P, int nblk, int NT, int prefix_layo
   }
 }
 
-// out[m + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols
+// out[m*out_mstride + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols
 __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64_t split_stride,
-                              int64_t M, int ncols, double *__restrict__ out,
+                              int64_t M, int ncols, double *__restrict__ out, int64_t out_mstride,
                               int64_t out_rstride) {
   const int64_t total = M * ncols;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -332,7 +333,7 @@ __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64
     const int64_t n = e / M;
     double s = 0;
     for (int sp = 0; sp < nsplit; sp++) s += slab[sp * split_stride + e];
-    out[m + out_rstride * n] = s;
+    out[m * out_mstride + out_rstride * n] = s;
   }
 }
 

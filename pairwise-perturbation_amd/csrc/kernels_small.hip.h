@@ -476,6 +476,66 @@ __global__ void k_unpack_blocks(const double *__restrict__ blocked, int64_t rows
   }
 }
 
+// ------------------------------------------------------------------ Tucker: Gram of an unfolding
+// G[p + J*q] (slab blockIdx.z) = sum_{c in chunk} A[p][c] * A[q][c],  A[p][c] = X[l + L*(p + J*t)],
+// c = l + L*t (unroll_tensor_contraction, common.cxx:205-223). 32x32 output tile per block, the
+// reduction index staged through LDS in chunks of 32; loads are arranged so that consecutive
+// threads touch consecutive addresses (p fastest when L == 1, c fastest otherwise).
+template <typename TV>
+__global__ __launch_bounds__(256) void k_unfold_gram(const TV *__restrict__ X, int64_t L, int64_t J,
+                                                     int64_t T, int64_t c_per_split,
+                                                     double *__restrict__ slab) {
+  __shared__ double As[32][33];
+  __shared__ double Bs[32][33];
+  const int64_t C = L * T;
+  const int64_t p0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32;
+  const int64_t c_begin = (int64_t)blockIdx.z * c_per_split;
+  const int64_t c_end = min(C, c_begin + c_per_split);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty in [0,8)
+  double acc[4] = {0, 0, 0, 0};                            // outputs (ty + 8*i, tx)
+  const bool p_fast = (L == 1);
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int a = tx, b = ty + 8 * i;
+      const int pi = p_fast ? a : b, ci = p_fast ? b : a;
+      const int64_t c = c0 + ci;
+      double va = 0, vb = 0;
+      if (c < c_end) {
+        const int64_t l = c % L, t = c / L;
+        if (p0 + pi < J) va = (double)X[l + L * ((p0 + pi) + J * t)];
+        if (q0 + pi < J) vb = (double)X[l + L * ((q0 + pi) + J * t)];
+      }
+      As[pi][ci] = va;
+      Bs[pi][ci] = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int ci = 0; ci < 32; ci++) {
+      const double bq = Bs[tx][ci];
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] += As[ty + 8 * i][ci] * bq;
+    }
+    __syncthreads();
+  }
+  double *g = slab + (int64_t)blockIdx.z * J * J;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int64_t p = p0 + ty + 8 * i, q = q0 + tx;
+    if (p < J && q < J) g[p + J * q] = acc[i];
+  }
+}
+// U[:,k] = Z[:, J-1-k] for k < rank (syevd returns ascending eigenvalues)
+__global__ void k_take_top(const double *__restrict__ Z, int64_t J, int rank,
+                           double *__restrict__ U) {
+  const int64_t total = J * rank;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, k = e / J;
+    U[e] = Z[i + J * (J - 1 - k)];
+  }
+}
+
 __global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restrict__ partial) {
   __shared__ double lds[17];
   double s = 0;

@@ -63,16 +63,24 @@ class Ops {
 
   // ---- tensor scans (the only kernels that touch the s^N tensor) ----
   // V viewed as [L, J, T] (first fastest), B = KRP of `nf` factors with combined extent J:
-  //   out[l + L*t + out_rstride*r] (+)= sum_j V[l,j,t] * B[j,r]       r in [0,R)
-  // This one primitive is K1 (T=1: contract a suffix), K2 (L=1: contract a prefix) and the
-  // single-mode TTM of the PP operator build / Tucker TTMc (general L,J,T).
+  //   out[l + out_tstride*t + out_rstride*r] = sum_j V[l,j,t] * B[j,r]       r in [0,R)
+  // This one primitive is K1 (T=1: contract a suffix), K2 (L=1: contract a prefix), the
+  // single-mode TTM of the PP operator build (tstride=L, rstride=L*T: rank index last) and the
+  // Tucker mode product that keeps the mode in place (tstride=L*R, rstride=L). V may also be a
+  // cached fp64 intermediate (dt = F64).
   virtual void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T,
-                             const FactorRef *f, int nf, int R, double *out,
+                             const FactorRef *f, int nf, int R, double *out, int64_t out_tstride,
                              int64_t out_rstride) = 0;
   // Tucker mode product keeping the mode in place (fp64 in/out or V-typed in):
-  //   out[l + L*(k + Kc*t)] = sum_j X[l,j,t] * W[j + ldw*k]
+  //   out[l + L*(k + Kc*t)] = sum_j X[l,j,t] * W[j + ldw*k]      (als_Tucker.cxx:102,224)
   virtual void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
-                        int64_t ldw, int Kc, double *out) = 0;
+                        int64_t ldw, int Kc, double *out) {
+    FactorRef f;
+    f.ptr = W;
+    f.rows = J;
+    f.ld = ldw;
+    scan_contract(X, dt, L, J, T, &f, 1, Kc, out, L * Kc, L);
+  }
 
   // ---- contraction of a cached intermediate (fp64) that already carries the rank index ----
   //   out[l + L*t + out_rstride*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j,r]

@@ -146,7 +146,7 @@ class HostOps : public Ops {
     std::copy(B.begin(), B.end(), out);
   }
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
-                     int nf, int R, double *out, int64_t rs) override {
+                     int nf, int R, double *out, int64_t ts, int64_t rs) override {
     int64_t Jc;
     std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
     if (Jc != J) throw std::runtime_error("hostsim: scan_contract extent mismatch");
@@ -157,7 +157,7 @@ class HostOps : public Ops {
         for (int64_t l = 0; l < L; l++) {
           double acc = 0;
           for (int64_t j = 0; j < J; j++) acc += ld(V, dt, l + L * (j + J * t)) * B[j + J * r];
-          out[l + L * t + rs * r] = acc;
+          out[l + ts * t + rs * r] = acc;
         }
   }
   void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,

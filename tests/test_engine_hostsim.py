@@ -27,3 +27,8 @@ test_gram_system = G.test_gram_system
 test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
+
+import test_gpu_tucker as GT  # noqa: E402
+
+test_ttmc_matches_oracle = GT.test_ttmc_matches_oracle
+test_hosvd_and_dt_sweeps = GT.test_hosvd_and_dt_sweeps

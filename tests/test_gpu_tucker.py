@@ -1,0 +1,80 @@
+"""GPU parity tests of the Tucker (HOOI) path: TTMc (K11), Gram of the unfolding + leading
+eigenvectors (K12/K13), hosvd, alsTucker_DT — against the fp64 oracle. Eigenvector signs are
+LAPACK-defined in the reference, so factors are compared as subspaces (projectors)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pp():
+    import ppals
+    return ppals
+
+
+@pytest.fixture(scope="module")
+def ctx(pp):
+    c = pp.Context(0)
+    yield c
+    c.close()
+
+
+def proj(U):
+    return U @ U.T
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+CASES = [([12, 10, 9], [3, 4, 2]), ([9, 8, 7, 6], [3, 2, 3, 2]), ([20, 16, 24], [5, 5, 5])]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,ranks", CASES)
+def test_ttmc_matches_oracle(pp, ctx, lens, ranks, dtype):
+    V = O.fill_uniform(int(np.prod(lens)), 3, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W = [np.linalg.qr(O.fill_uniform(s * r, 40 + i, lo=-1, hi=1).reshape((s, r), order="F"))[0]
+         for i, (s, r) in enumerate(zip(lens, ranks))]
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.set_factors(W)
+    for skip in [-1] + list(range(len(lens))):
+        got = s.ttmc(skip)
+        want = O.ttmc(V, W, skip)
+        assert relerr(got, want) < (2e-6 if dtype == 0 else 1e-11), (skip, relerr(got, want))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,ranks", CASES)
+def test_hosvd_and_dt_sweeps(pp, ctx, lens, ranks, dtype, tmp_path):
+    V = O.fill_uniform(int(np.prod(lens)), 4, lo=0.5, hi=1.0).reshape(lens, order="F")
+    tol = 1e-4 if dtype == 0 else 1e-8
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.hosvd()
+    W, core = s.get_factors()
+    W_ref, core_ref = O.hosvd(V, ranks)
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert np.linalg.norm(proj(a) - proj(b)) < tol * 10
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < tol * np.linalg.norm(core_ref)
+    # full driver from the same (oracle) initialisation
+    s.set_factors(W_ref)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    _, it_ref, W_dt_ref, core_dt_ref = O.als_tucker_dt(V, W_ref, core_ref, tol=0.0, maxiter=4,
+                                                       csv=c_ref, resprint=1)
+    rc, it = s.run_dt(tol=0.0, maxiter=4, csv=c_got, resprint=1)
+    W_dt, core_dt = s.get_factors()
+    assert it == it_ref
+    for a, b in zip(W_dt, W_dt_ref):
+        assert np.linalg.norm(proj(a) - proj(b)) < tol * 100
+    h1, r1 = O.read_csv(c_ref)
+    h2, r2 = O.read_csv(c_got)
+    assert h1 == h2 and len(r1) == len(r2)
+    for a, b in zip(r1, r2):
+        assert a[1] == b[1]
+        assert abs(a[5] - b[5]) < (1e-4 if dtype == 0 else 1e-8) * np.linalg.norm(V)
