@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -47,6 +48,8 @@ class HipOps : public Ops {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
     ncu_ = prop.multiProcessorCount;
+    // PPALS_SCAN_VARIANT=0 selects the generic (predicated) scan kernels for A/B measurements
+    if (const char *v = getenv("PPALS_SCAN_VARIANT")) variant_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
@@ -254,7 +257,14 @@ class HipOps : public Ops {
 #define LAUNCH_PREFIX(NTv, ALv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
-        if (al) {
+#define LAUNCH_PREFIX_FAST(NTv)                                                               \
+  hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv>), grid, dim3(256), 0, st_, V, M, K, P, per, \
+                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
+        if (al && variant_ >= 1 && M >= VEC) {
+          if (NT == 1) LAUNCH_PREFIX_FAST(1);
+          else if (NT == 2) LAUNCH_PREFIX_FAST(2);
+          else LAUNCH_PREFIX_FAST(4);
+        } else if (al) {
           if (NT == 1) LAUNCH_PREFIX(1, true);
           else if (NT == 2) LAUNCH_PREFIX(2, true);
           else LAUNCH_PREFIX(4, true);
@@ -264,6 +274,7 @@ class HipOps : public Ops {
           else LAUNCH_PREFIX(4, false);
         }
 #undef LAUNCH_PREFIX
+#undef LAUNCH_PREFIX_FAST
         prof_end();
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
@@ -300,7 +311,14 @@ class HipOps : public Ops {
 #define LAUNCH_SUFFIX(NTv, ALv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
-        if (al) {
+#define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
+  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+        if (al && variant_ >= 1 && M >= VEC) {
+          if (NT == 1) LAUNCH_SUFFIX_FAST(1);
+          else if (NT == 2) LAUNCH_SUFFIX_FAST(2);
+          else LAUNCH_SUFFIX_FAST(4);
+        } else if (al) {
           if (NT == 1) LAUNCH_SUFFIX(1, true);
           else if (NT == 2) LAUNCH_SUFFIX(2, true);
           else LAUNCH_SUFFIX(4, true);
@@ -310,6 +328,7 @@ class HipOps : public Ops {
           else LAUNCH_SUFFIX(4, false);
         }
 #undef LAUNCH_SUFFIX
+#undef LAUNCH_SUFFIX_FAST
         prof_end();
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
@@ -549,7 +568,7 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256;
+  int dev_ = 0, ncu_ = 256, variant_ = 1;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;

@@ -59,7 +59,7 @@ struct ScanTraits<double> {
   __device__ static inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 
-constexpr int SCAN_FLUSH = 16;  // k-blocks between fp32 -> fp64 flushes
+constexpr int SCAN_FLUSH = 4;  // k-blocks between fp32 -> fp64 flushes (chains of <= 64 terms)
 
 template <typename TV, bool ALIGNED>
 __device__ inline typename ScanTraits<TV>::vec load_vec(const TV *__restrict__ base, int64_t off,
@@ -276,6 +276,254 @@ __global__ __launch_bounds__(256) void k_scan_prefix(
       if (n < ncols && k_ok) {
         double val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
         if constexpr (TR::NEEDS_FLUSH) val += acc64[nt][r];
+        o[(int64_t)n * out_nstride + k * out_kstride] = val;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast variants (the ones the hot path runs): shapes whose leading extent is a multiple of VEC, so
+// every lane access is one aligned 16-byte load. Differences from the generic kernels above:
+//  * no predication: out-of-range rows/columns are CLAMPED to a valid address and their lanes'
+//    results are simply not stored; out-of-range reduction indices are harmless because the
+//    packed Khatri-Rao operand is zero there;
+//  * the loads of block i+1 are issued before the MFMAs of block i (register double buffer), so a
+//    wave overlaps its own HBM latency with its own matrix work instead of relying on occupancy;
+//  * fp32 chains are flushed to fp64 every FLUSH blocks in a fixed-trip inner loop.
+template <typename TV, int NT>
+__global__ __launch_bounds__(256) void k_scan_suffix_fast(
+    const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
+    const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
+    double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
+    int64_t out_batch_stride, int ncols) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  typedef typename TR::acc acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int KB = 4 * VEC;
+  constexpr int FLUSH = 4;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  int64_t bid = blockIdx.x;
+  const int mtile = (int)(bid % n_mtiles);
+  bid /= n_mtiles;
+  const int split = (int)(bid % nsplit);
+  const int64_t batch = bid / nsplit;
+
+  const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
+  if (m0 >= M) return;  // wave-uniform
+  const int64_t m = m0 + (int64_t)VEC * j16;
+  const int64_t m_ld = min(m, M - VEC);  // clamped: lanes past the edge re-read the last rows
+  const int kb0 = split * kb_per_split;
+  const int kb1 = min(nkb, kb0 + kb_per_split);
+  const TV *__restrict__ vp = V + batch * batch_stride + m_ld;
+  const TV *__restrict__ pp = P + ((int64_t)g * 16 + j16) * VEC;
+
+  acc_t acc[VEC][NT];
+  double acc64[TR::NEEDS_FLUSH ? VEC : 1][TR::NEEDS_FLUSH ? NT : 1][4];
+#pragma unroll
+  for (int a = 0; a < VEC; a++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
+      if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
+      }
+    }
+
+  vec cv[VEC], cb[NT];
+  // block kb: k-quad u holds k = kb*KB + 4u + g. Blocks entirely below K ("full") are addressed
+  // as lane-constant pointer + wave-uniform offset; the last, partial block clamps k to K-1 (the
+  // packed operand is zero there, so the re-read values do not contribute).
+  const int kfull = (int)min((int64_t)kb1, K / KB);
+  const TV *__restrict__ vg = vp + (int64_t)g * M;
+#define PPALS_LOAD_BLOCK(kb_, vv_, bb_)                                                  \
+  {                                                                                      \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bb_[nt] =                          \
+        *reinterpret_cast<const vec *>(pp + ((int64_t)(kb_)*NT + nt) * (4 * 16 * VEC));  \
+    if ((kb_) < kfull) {                                                                 \
+      const TV *__restrict__ src_ = vg + (int64_t)(kb_) * ((int64_t)KB * M);             \
+      _Pragma("unroll") for (int u = 0; u < VEC; u++) vv_[u] =                           \
+          *reinterpret_cast<const vec *>(src_ + (int64_t)(4 * u) * M);                   \
+    } else {                                                                             \
+      _Pragma("unroll") for (int u = 0; u < VEC; u++) {                                  \
+        const int64_t k_ = min((int64_t)(kb_)*KB + 4 * u + g, K - 1);                    \
+        vv_[u] = *reinterpret_cast<const vec *>(vp + k_ * M);                            \
+      }                                                                                  \
+    }                                                                                    \
+  }
+  if (kb0 < kb1) PPALS_LOAD_BLOCK(kb0, cv, cb);
+  for (int kc = kb0; kc < kb1; kc += FLUSH) {
+    const int ke = min(kb1, kc + FLUSH);
+    for (int kb = kc; kb < ke; kb++) {
+      vec nv[VEC], nb[NT];
+      const int kn = min(kb + 1, kb1 - 1);  // the last block is simply loaded twice
+      PPALS_LOAD_BLOCK(kn, nv, nb);
+#pragma unroll
+      for (int u = 0; u < VEC; u++)
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            acc[jj][nt] = TR::mfma(cb[nt][u], cv[u][jj], acc[jj][nt]);
+#pragma unroll
+      for (int u = 0; u < VEC; u++) cv[u] = nv[u];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) cb[nt] = nb[nt];
+    }
+    if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+      for (int a = 0; a < VEC; a++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            acc64[a][nt][r] += (double)acc[a][nt][r];
+            acc[a][nt][r] = 0;
+          }
+    }
+  }
+#undef PPALS_LOAD_BLOCK
+
+  double *__restrict__ o = out + split * out_split_stride + batch * out_batch_stride;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int n = 16 * nt + TR::row(lane, r);
+      if (n < ncols && m < M) {
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++) {
+          double val;
+          if constexpr (TR::NEEDS_FLUSH)
+            val = acc64[jj][nt][r];
+          else
+            val = (double)acc[jj][nt][r];
+          o[(int64_t)n * out_nstride + m + jj] = val;
+        }
+      }
+    }
+}
+
+template <typename TV, int NT>
+__global__ __launch_bounds__(256) void k_scan_prefix_fast(
+    const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
+    int nmb, double *__restrict__ out, int64_t out_kstride, int64_t out_nstride,
+    int64_t out_split_stride, int ncols) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  typedef typename TR::acc acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int MB = 4 * VEC;
+  constexpr int U = 4;      // reduction blocks per step (U x 16 B per lane in flight, x2 prefetch)
+  constexpr int FLUSH = 2;  // steps between fp32 -> fp64 flushes (chains of <= 16*VEC*... terms)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (k0 >= K) return;  // wave-uniform
+  const int64_t k = k0 + j16;
+  const bool k_ok = k < K;
+  const int split = blockIdx.y;
+  const int mb0 = split * mb_per_split;
+  const int mb1 = min(nmb, mb0 + mb_per_split);
+  const TV *__restrict__ vc = V + min(k, K - 1) * M + (int64_t)VEC * g;  // clamped column
+  const TV *__restrict__ pp = P + ((int64_t)g * 16 + j16) * VEC;
+  const int64_t m_last = M - VEC - (int64_t)VEC * g;  // largest valid block offset for this lane
+
+  acc_t acc[2][NT];
+  double acc64[TR::NEEDS_FLUSH ? NT : 1][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      acc[0][nt][r] = 0;
+      acc[1][nt][r] = 0;
+    }
+    if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc64[nt][r] = 0.0;
+    }
+  }
+
+  vec cv[U], cb[U][NT];
+  // step at block mb_: blocks mb_..mb_+U-1. Steps whose blocks all lie below min(mb1, M/MB) are
+  // addressed as lane-constant pointer + wave-uniform offset. Otherwise (last step): blocks past
+  // mb1 are clamped to mb1-1 with a ZERO operand, rows past M are clamped (operand zero there).
+  const int mfull = (int)min((int64_t)mb1, M / MB);
+#define PPALS_LOAD_STEP(mb_, vv_, bb_)                                                       \
+  {                                                                                          \
+    if ((mb_) + U <= mfull) {                                                                \
+      _Pragma("unroll") for (int u = 0; u < U; u++) {                                        \
+        vv_[u] = *reinterpret_cast<const vec *>(vc + (int64_t)((mb_) + u) * MB);             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bb_[u][nt] =                       \
+            *reinterpret_cast<const vec *>(pp + ((int64_t)((mb_) + u) * NT + nt) * (4 * 16 * VEC)); \
+      }                                                                                      \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int u = 0; u < U; u++) {                                        \
+        const int mbu_ = min((mb_) + u, mb1 - 1);                                            \
+        const bool dup_ = (mb_) + u > mb1 - 1;                                               \
+        const int64_t off_ = min((int64_t)mbu_ * MB, m_last);                                \
+        vv_[u] = *reinterpret_cast<const vec *>(vc + off_);                                  \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                  \
+          bb_[u][nt] = *reinterpret_cast<const vec *>(                                       \
+              pp + ((int64_t)mbu_ * NT + nt) * (4 * 16 * VEC));                              \
+          if (dup_) {                                                                        \
+            _Pragma("unroll") for (int e = 0; e < VEC; e++) bb_[u][nt][e] = (TV)0;           \
+          }                                                                                  \
+        }                                                                                    \
+      }                                                                                      \
+    }                                                                                        \
+  }
+  if (mb0 < mb1) PPALS_LOAD_STEP(mb0, cv, cb);
+  for (int mc = mb0; mc < mb1; mc += U * FLUSH) {
+    const int me = min(mb1, mc + U * FLUSH);
+    for (int mb = mc; mb < me; mb += U) {
+      vec nv[U], nb[U][NT];
+      const int mn = min(mb + U, mb1 - 1);
+      PPALS_LOAD_STEP(mn, nv, nb);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            acc[jj & 1][nt] = TR::mfma(cb[u][nt][jj], cv[u][jj], acc[jj & 1][nt]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        cv[u] = nv[u];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) cb[u][nt] = nb[u][nt];
+      }
+    }
+    if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          acc64[nt][r] += (double)acc[0][nt][r] + (double)acc[1][nt][r];
+          acc[0][nt][r] = 0;
+          acc[1][nt][r] = 0;
+        }
+    }
+  }
+#undef PPALS_LOAD_STEP
+
+  double *__restrict__ o = out + split * out_split_stride;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int n = 16 * nt + TR::row(lane, r);
+      if (n < ncols && k_ok) {
+        double val;
+        if constexpr (TR::NEEDS_FLUSH)
+          val = acc64[nt][r];
+        else
+          val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
         o[(int64_t)n * out_nstride + k * out_kstride] = val;
       }
     }
