@@ -325,11 +325,12 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
                            double ratio) {
   const int64_t s = V_.glens[i];
   double *Gi = G_ + (size_t)i * R_ * R_;
-  ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
   if (P_ == 1) {
-    ops_.cp_update(M, ldm, W_[i], s, W_[i], s, gradW_[i], s, s, R_, S_, Sinv_, gradsq_ + i,
-                   pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio);
+    ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
+                        pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
+    return;
   } else {
+    ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
     const int64_t blk = block_rows(s, P_);
     const int64_t r0 = blk * rank_;
     const int64_t nr = std::max<int64_t>(0, std::min(blk, s - r0));

@@ -54,6 +54,9 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
   }
   ~HipOps() override {
     hipSetDevice(dev_);
@@ -370,7 +373,8 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_mttv_1, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out,
                          out_rstride, accumulate);
     } else {
-      int g = grid_for(L * T * R, 256, 16384);
+      int64_t nb = ((L + 63) / 64) * T * R;
+      int g = (int)std::min<int64_t>(nb, 32768);
       hipLaunchKernelGGL(k_mttv_l, dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb, out,
                          out_rstride, accumulate);
     }
@@ -390,7 +394,23 @@ class HipOps : public Ops {
     if (R > 64) throw std::runtime_error("ppals: gram_system supports R <= 64 in this version");
     size_t lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
     hipLaunchKernelGGL(k_gram_system, dim3(1), dim3(64), lds, st_, Gall, N, mode, R, lambda, S,
-                       Sinv);
+                       Sinv, force_jacobi_);
+    HIP_CHECK(hipGetLastError());
+  }
+  void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
+                      int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
+                      double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,
+                      double ratio, double *S, double *Sinv) override {
+    if (R > 64) throw std::runtime_error("ppals: mode update supports R <= 64 in this version");
+    if (force_jacobi_) {  // A/B path: the three separate kernels with the Jacobi inverse
+      Ops::cp_mode_update(Gall, N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit,
+                          ldi, dW, ldd, ratio, S, Sinv);
+      return;
+    }
+    size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
+                 sizeof(int) * 64;
+    hipLaunchKernelGGL(k_cp_mode_update, dim3(1), dim3(1024), lds, st_, Gall, N, mode, R, lambda, M,
+                       ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio, S, Sinv);
     HIP_CHECK(hipGetLastError());
   }
   void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
@@ -568,7 +588,7 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 1;
+  int dev_ = 0, ncu_ = 256, variant_ = 1, force_jacobi_ = 0;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;

@@ -290,7 +290,17 @@ __global__ __launch_bounds__(256) void k_scan_prefix(
 //  * the loads of block i+1 are issued before the MFMAs of block i (register double buffer), so a
 //    wave overlaps its own HBM latency with its own matrix work instead of relying on occupancy;
 //  * fp32 chains are flushed to fp64 every FLUSH blocks in a fixed-trip inner loop.
-template <typename TV, int NT>
+// OPT bit 0: non-temporal loads of the tensor (streamed once: do not displace the packed operand
+// from L2). OPT bit 1: XCD-aware block remap (blocks of one k-split share an XCD's L2).
+template <typename vec, int OPT>
+__device__ inline vec scan_ld(const vec *p) {
+  if constexpr (OPT & 1)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+template <typename TV, int NT, int OPT = 0>
 __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
@@ -306,6 +316,13 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j16 = lane & 15;
   int64_t bid = blockIdx.x;
+  if constexpr (OPT & 2) {
+    // blocks are dealt round-robin over the 8 XCDs (speed only): give each XCD a contiguous
+    // eighth of the (mtile-fastest) id space so that it works on few k-splits at a time
+    const int64_t nb = gridDim.x;
+    const int64_t per = nb / 8;
+    if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+  }
   const int mtile = (int)(bid % n_mtiles);
   bid /= n_mtiles;
   const int split = (int)(bid % nsplit);
@@ -347,11 +364,11 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     if ((kb_) < kfull) {                                                                 \
       const TV *__restrict__ src_ = vg + (int64_t)(kb_) * ((int64_t)KB * M);             \
       _Pragma("unroll") for (int u = 0; u < VEC; u++) vv_[u] =                           \
-          *reinterpret_cast<const vec *>(src_ + (int64_t)(4 * u) * M);                   \
+          scan_ld<vec, OPT>(reinterpret_cast<const vec *>(src_ + (int64_t)(4 * u) * M)); \
     } else {                                                                             \
       _Pragma("unroll") for (int u = 0; u < VEC; u++) {                                  \
         const int64_t k_ = min((int64_t)(kb_)*KB + 4 * u + g, K - 1);                    \
-        vv_[u] = *reinterpret_cast<const vec *>(vp + k_ * M);                            \
+        vv_[u] = scan_ld<vec, OPT>(reinterpret_cast<const vec *>(vp + k_ * M));          \
       }                                                                                  \
     }                                                                                    \
   }
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     }
 }
 
-template <typename TV, int NT>
+template <typename TV, int NT, int OPT = 0>
 __global__ __launch_bounds__(256) void k_scan_prefix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
     int nmb, double *__restrict__ out, int64_t out_kstride, int64_t out_nstride,
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
   {                                                                                          \
     if ((mb_) + U <= mfull) {                                                                \
       _Pragma("unroll") for (int u = 0; u < U; u++) {                                        \
-        vv_[u] = *reinterpret_cast<const vec *>(vc + (int64_t)((mb_) + u) * MB);             \
+        vv_[u] = scan_ld<vec, OPT>(reinterpret_cast<const vec *>(vc + (int64_t)((mb_) + u) * MB)); \
         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bb_[u][nt] =                       \
             *reinterpret_cast<const vec *>(pp + ((int64_t)((mb_) + u) * NT + nt) * (4 * 16 * VEC)); \
       }                                                                                      \
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
         const int mbu_ = min((mb_) + u, mb1 - 1);                                            \
         const bool dup_ = (mb_) + u > mb1 - 1;                                               \
         const int64_t off_ = min((int64_t)mbu_ * MB, m_last);                                \
-        vv_[u] = *reinterpret_cast<const vec *>(vc + off_);                                  \
+        vv_[u] = scan_ld<vec, OPT>(reinterpret_cast<const vec *>(vc + off_));                \
         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                  \
           bb_[u][nt] = *reinterpret_cast<const vec *>(                                       \
               pp + ((int64_t)mbu_ * NT + nt) * (4 * 16 * VEC));                              \

@@ -134,30 +134,40 @@ __global__ void k_krp(double *__restrict__ out, KrpArgs a, int64_t J, int col0, 
 
 // ------------------------------------------------------------------ mttv (K3, K9, deeper tree nodes)
 // out[l + L*t + rs*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j + ldb*r]
-// variant L: one thread per (l,t,r), coalesced over l.
-__global__ void k_mttv_l(const double *__restrict__ X, int64_t L, int64_t J, int64_t T, int R,
-                         const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
-                         int64_t rs, int accumulate) {
-  const int64_t total = L * T * R;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t l = e % L;
-    const int64_t t = (e / L) % T;
-    const int r = (int)(e / (L * T));
+// variant L: block = 64 consecutive l for one (t,r); the 4 waves split the j range and combine
+// through LDS, so even a 200 x 200 x R leaf contraction spreads over hundreds of waves.
+__global__ __launch_bounds__(256) void k_mttv_l(const double *__restrict__ X, int64_t L, int64_t J,
+                                                int64_t T, int R, const double *__restrict__ B,
+                                                int64_t ldb, double *__restrict__ out, int64_t rs,
+                                                int accumulate) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ltiles = (L + 63) / 64;
+  const int64_t total = ltiles * T * R;
+  for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const int64_t lt = blk % ltiles;
+    const int64_t t = (blk / ltiles) % T;
+    const int r = (int)(blk / (ltiles * T));
+    const int64_t l = lt * 64 + lane;
     const double *x = X + l + L * J * (t + T * (int64_t)r);
     const double *b = B + ldb * r;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int64_t j = 0;
-    for (; j + 3 < J; j += 4) {
-      s0 += x[L * j] * b[j];
-      s1 += x[L * (j + 1)] * b[j + 1];
-      s2 += x[L * (j + 2)] * b[j + 2];
-      s3 += x[L * (j + 3)] * b[j + 3];
+    double s0 = 0, s1 = 0;
+    if (l < L) {
+      int64_t j = wave;
+      for (; j + 4 < J; j += 8) {
+        s0 += x[L * j] * b[j];
+        s1 += x[L * (j + 4)] * b[j + 4];
+      }
+      for (; j < J; j += 4) s0 += x[L * j] * b[j];
     }
-    for (; j < J; j++) s0 += x[L * j] * b[j];
-    const double s = (s0 + s1) + (s2 + s3);
-    double *o = out + l + L * t + rs * r;
-    *o = accumulate ? (*o + s) : s;
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && l < L) {
+      const double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      double *o = out + l + L * t + rs * r;
+      *o = accumulate ? (*o + s) : s;
+    }
+    __syncthreads();
   }
 }
 // variant 1 (L == 1): one wave per (t,r), lanes stride the contiguous j.
@@ -211,46 +221,46 @@ __global__ void k_gram(const double *__restrict__ W, int64_t rows, int64_t ld, i
 }
 
 // ------------------------------------------------------------------ S and S^{-1}  (K4 + K6a)
-// ONE wave. S = Hadamard of the Grams of all modes but `mode` (+ lambda I); S^{-1} through a
-// parallel-ordered cyclic Jacobi eigendecomposition S = Q diag(w) Q^T, S^{-1} = Q diag(1/w) Q^T.
-// For a symmetric matrix this equals the reference's V diag(1/sigma) U^T (common.cxx:717-722),
-// including its behaviour of NOT truncating tiny singular values.
-// dynamic LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
-__global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ Gall, int N,
-                                                    int mode, int R, double lambda,
-                                                    double *__restrict__ S,
-                                                    double *__restrict__ Sinv) {
-  extern __shared__ double lds[];
-  const int ldA = R + 1;
-  double *A = lds;
-  double *Q = A + R * ldA;
-  double *cs = Q + R * ldA;   // c[i], s[i] per pair (<= 32 pairs -> 64 doubles)
-  int *pq = (int *)(cs + 64);  // p[i], q[i] per pair (64 ints)
-  const int lane = threadIdx.x;
+// wave-level ordering point for LDS traffic between lanes of ONE wave (LDS executes a wave's DS
+// instructions in order; this only stops the compiler from moving them)
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
-  // Hadamard product in the reference's index order (als_CP.cxx:219-232): modes 0..N-1 with
-  // `mode` and N-1 swapped, first N-1 of them
+// Hadamard product of the Grams of all modes but `mode` in the reference's index order
+// (als_CP.cxx:219-232: modes 0..N-1 with `mode` and N-1 swapped, first N-1 of them) + lambda*I
+__device__ inline double hadamard_entry(const double *__restrict__ Gall, int N, int mode, int R,
+                                        double lambda, int e) {
+  double v = 1.0;
+  bool first = true;
+  for (int ii = 0; ii < N - 1; ii++) {
+    const int j = (ii == mode) ? (N - 1) : ii;
+    const double gval = Gall[(int64_t)j * R * R + e];
+    v = first ? gval : v * gval;
+    first = false;
+  }
+  if (e % R == e / R) v += lambda;
+  return v;
+}
+
+// ONE wave (lane = threadIdx.x & 63). In: A (R x R, ld R+1, row-major view of symmetric S).
+// Out: Sinv[i + R*j]. Parallel-ordered cyclic Jacobi S = Q diag(w) Q^T, S^{-1} = Q diag(1/w) Q^T:
+// for a symmetric matrix this equals the reference's V diag(1/sigma) U^T (common.cxx:717-722),
+// including its behaviour of NOT truncating tiny singular values.
+// LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
+__device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int *pq, int R,
+                                           double *Sinv_out) {
+  const int lane = threadIdx.x & 63;
+  const int ldA = R + 1;
   for (int e = lane; e < R * R; e += 64) {
-    double v = 1.0;
-    bool first = true;
-    for (int ii = 0; ii < N - 1; ii++) {
-      int j = (ii == mode) ? (N - 1) : ii;
-      double gval = Gall[(int64_t)j * R * R + e];
-      v = first ? gval : v * gval;
-      first = false;
-    }
     const int i = e % R, j = e / R;
-    if (i == j) v += lambda;
-    S[e] = v;
-    A[i * ldA + j] = v;
     Q[i * ldA + j] = (i == j) ? 1.0 : 0.0;
   }
-  __syncthreads();
-
+  wave_sync();
   const int n2 = (R + 1) & ~1;  // players (even); index R (if odd) is a bye
   const int npair = n2 / 2;
   for (int sweep = 0; sweep < 40; sweep++) {
-    // convergence: off-diagonal mass vs diagonal mass
     double off = 0, diag = 0;
     for (int e = lane; e < R * R; e += 64) {
       const int i = e % R, j = e / R;
@@ -265,10 +275,8 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
     off = __shfl(off, 0, 64);
     diag = __shfl(diag, 0, 64);
     if (off <= 1e-30 * diag || off == 0.0) break;
-
     for (int rd = 0; rd < n2 - 1; rd++) {
-      // round-robin pairing: player n2-1 fixed, the others rotate
-      if (lane < npair) {
+      if (lane < npair) {  // round-robin pairing: player n2-1 fixed, the others rotate
         int a, b;
         if (lane == 0) {
           a = n2 - 1;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
           b = (rd - lane + (n2 - 1)) % (n2 - 1);
         }
         int p = min(a, b), q = max(a, b);
-        double c = 1.0, s = 0.0;
+        double c = 1.0, sn = 0.0;
         if (q < R) {
           const double apq = A[p * ldA + q];
           if (apq != 0.0) {
@@ -286,52 +294,127 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
             const double theta = (aqq - app) / (2.0 * apq);
             const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
             c = 1.0 / sqrt(t * t + 1.0);
-            s = t * c;
+            sn = t * c;
           }
         } else {
           p = q = -1;  // bye
         }
         cs[2 * lane] = c;
-        cs[2 * lane + 1] = s;
+        cs[2 * lane + 1] = sn;
         pq[2 * lane] = p;
         pq[2 * lane + 1] = q;
       }
-      __syncthreads();
-      // column update: A <- A J, Q <- Q J   (for each pair, every row i)
-      for (int e = lane; e < npair * R; e += 64) {
+      wave_sync();
+      for (int e = lane; e < npair * R; e += 64) {  // A <- A J, Q <- Q J
         const int pi = e / R, i = e % R;
         const int p = pq[2 * pi], q = pq[2 * pi + 1];
         if (p >= 0) {
-          const double c = cs[2 * pi], s = cs[2 * pi + 1];
+          const double c = cs[2 * pi], sn = cs[2 * pi + 1];
           const double aip = A[i * ldA + p], aiq = A[i * ldA + q];
-          A[i * ldA + p] = c * aip - s * aiq;
-          A[i * ldA + q] = s * aip + c * aiq;
+          A[i * ldA + p] = c * aip - sn * aiq;
+          A[i * ldA + q] = sn * aip + c * aiq;
           const double qip = Q[i * ldA + p], qiq = Q[i * ldA + q];
-          Q[i * ldA + p] = c * qip - s * qiq;
-          Q[i * ldA + q] = s * qip + c * qiq;
+          Q[i * ldA + p] = c * qip - sn * qiq;
+          Q[i * ldA + q] = sn * qip + c * qiq;
         }
       }
-      __syncthreads();
-      // row update: A <- J^T A
-      for (int e = lane; e < npair * R; e += 64) {
+      wave_sync();
+      for (int e = lane; e < npair * R; e += 64) {  // A <- J^T A
         const int pi = e / R, j = e % R;
         const int p = pq[2 * pi], q = pq[2 * pi + 1];
         if (p >= 0) {
-          const double c = cs[2 * pi], s = cs[2 * pi + 1];
+          const double c = cs[2 * pi], sn = cs[2 * pi + 1];
           const double apj = A[p * ldA + j], aqj = A[q * ldA + j];
-          A[p * ldA + j] = c * apj - s * aqj;
-          A[q * ldA + j] = s * apj + c * aqj;
+          A[p * ldA + j] = c * apj - sn * aqj;
+          A[q * ldA + j] = sn * apj + c * aqj;
         }
       }
-      __syncthreads();
+      wave_sync();
     }
   }
-  // S^{-1}[i,j] = sum_k Q[i,k] Q[j,k] / w_k      (no truncation)
-  for (int e = lane; e < R * R; e += 64) {
+  for (int e = lane; e < R * R; e += 64) {  // S^{-1}[i,j] = sum_k Q[i,k] Q[j,k] / w_k
     const int i = e % R, j = e / R;
     double acc = 0;
     for (int k = 0; k < R; k++) acc += Q[i * ldA + k] * (1.0 / A[k * ldA + k]) * Q[j * ldA + k];
-    Sinv[e] = acc;
+    Sinv_out[e] = acc;
+  }
+  wave_sync();
+}
+
+// ONE wave. Fast path for the (overwhelmingly common) positive-definite S: Cholesky S = L L^T,
+// X = L^{-1}, S^{-1} = X^T X. Returns false (wave-uniform) when a pivot is not positive — the
+// caller then falls back to the Jacobi path, which handles any symmetric S like the reference's
+// SVD does. In: A (R x R, ld R+1) lower triangle used, destroyed. X: R*(R+1) scratch.
+__device__ inline bool cholesky_inverse_wave(double *A, double *X, int R, double *Sinv_out) {
+  const int lane = threadIdx.x & 63;
+  const int ldA = R + 1;  // element (i,j) at A[i*ldA + j]
+  for (int k = 0; k < R; k++) {
+    wave_sync();
+    const double d = A[k * ldA + k];
+    if (!(d > 0.0)) return false;  // same value in every lane -> uniform
+    const double sq = sqrt(d), inv = 1.0 / sq;
+    for (int i = k + lane; i < R; i += 64) {
+      const double v = A[i * ldA + k];
+      A[i * ldA + k] = (i == k) ? sq : v * inv;
+    }
+    wave_sync();
+    const int n = R - k - 1;
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = k + 1 + e % n, j = k + 1 + e / n;
+      if (i >= j) A[i * ldA + j] -= A[i * ldA + k] * A[j * ldA + k];
+    }
+  }
+  wave_sync();
+  // X = L^{-1} (lower triangular): lane c owns column c, forward substitution down the column
+  for (int c = lane; c < R; c += 64) {
+    for (int i = 0; i < R; i++) {
+      double v = 0.0;
+      if (i >= c) {
+        double acc = (i == c) ? 1.0 : 0.0;
+        for (int j = c; j < i; j++) acc -= A[i * ldA + j] * X[j * ldA + c];
+        v = acc / A[i * ldA + i];
+      }
+      X[i * ldA + c] = v;
+    }
+  }
+  wave_sync();
+  for (int e = lane; e < R * R; e += 64) {  // S^{-1} = X^T X
+    const int a = e % R, b = e / R;
+    double acc = 0;
+    for (int i = max(a, b); i < R; i++) acc += X[i * ldA + a] * X[i * ldA + b];
+    Sinv_out[e] = acc;
+  }
+  wave_sync();
+  return true;
+}
+
+// S and S^{-1} for one mode, ONE wave (used stand-alone by the sharded path and the parity tests;
+// the single-GPU sweep uses the fused k_cp_mode_update below).
+// dynamic LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
+__global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ Gall, int N,
+                                                    int mode, int R, double lambda,
+                                                    double *__restrict__ S,
+                                                    double *__restrict__ Sinv, int force_jacobi) {
+  extern __shared__ double lds[];
+  const int ldA = R + 1;
+  double *A = lds;
+  double *Q = A + R * ldA;
+  double *cs = Q + R * ldA;
+  int *pq = (int *)(cs + 64);
+  const int lane = threadIdx.x;
+  for (int e = lane; e < R * R; e += 64) {
+    const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
+    S[e] = v;
+    A[(e % R) * ldA + e / R] = v;
+  }
+  wave_sync();
+  bool ok = false;
+  if (!force_jacobi) ok = cholesky_inverse_wave(A, Q, R, Sinv);
+  if (!ok) {
+    wave_sync();
+    for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = S[e];
+    wave_sync();
+    jacobi_inverse_wave(A, Q, cs, pq, R, Sinv);
   }
 }
 
@@ -377,6 +460,99 @@ __global__ __launch_bounds__(1024) void k_cp_update(
       if (ratio != 1.0) acc = wi + d;
     }
     Wnew[i + ldn * j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ fused mode update (single GPU)
+// ONE block of 1024 threads does a whole mode update: S (K4), S^{-1} (wave 0: Cholesky, Jacobi
+// fallback), gradient with the pre-update W + ||grad||^2 (K5), W = M S^{-1} (K6, optional
+// SVD_solve_mod tail), and the refreshed Gram G_mode = W^T W. Replaces three launches per mode.
+// dynamic LDS: red[32] | sS[R*R] | sI[R*R] | A[R*(R+1)] | Q[R*(R+1)] | cs[64] | pq[64 ints]
+__global__ __launch_bounds__(1024) void k_cp_mode_update(
+    double *__restrict__ Gall, int N, int mode, int R, double lambda, const double *__restrict__ M,
+    int64_t ldm, double *W, int64_t ldw, double *__restrict__ grad, int64_t ldg, int64_t rows,
+    double *__restrict__ gradsq, const double *__restrict__ Winit, int64_t ldi,
+    double *__restrict__ dW, int64_t ldd, double ratio, double *__restrict__ S_out,
+    double *__restrict__ Sinv_out) {
+  extern __shared__ double lds[];
+  const int ldA = R + 1;
+  double *red = lds;
+  double *sS = lds + 32;
+  double *sI = sS + R * R;
+  double *A = sI + R * R;
+  double *Q = A + R * ldA;
+  double *cs = Q + R * ldA;
+  int *pq = (int *)(cs + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int e = tid; e < R * R; e += blockDim.x) {
+    const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
+    sS[e] = v;
+    A[(e % R) * ldA + e / R] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    bool ok = cholesky_inverse_wave(A, Q, R, sI);
+    if (!ok) {
+      wave_sync();
+      for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = sS[e];
+      wave_sync();
+      jacobi_inverse_wave(A, Q, cs, pq, R, sI);
+    }
+  }
+  __syncthreads();
+  if (S_out)
+    for (int e = tid; e < R * R; e += blockDim.x) {
+      S_out[e] = sS[e];
+      Sinv_out[e] = sI[e];
+    }
+
+  const int64_t total = rows * R;
+  double gs = 0;
+  for (int64_t e = tid; e < total; e += blockDim.x) {
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += W[i + ldw * k] * sS[k + R * j];
+    const double gv = -M[i + ldm * j] + acc;
+    grad[i + ldg * j] = gv;
+    gs += gv * gv;
+  }
+  gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
+  if (tid == 0) *gradsq = gs;
+  for (int64_t e = tid; e < total; e += blockDim.x) {
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += M[i + ldm * k] * sI[k + R * j];
+    if (Winit) {
+      const double wi = Winit[i + ldi * j];
+      const double d = ratio * (acc - wi);
+      dW[i + ldd * j] = d;
+      if (ratio != 1.0) acc = wi + d;
+    }
+    W[i + ldw * j] = acc;
+  }
+  __syncthreads();  // W_new visible to the whole workgroup (same CU, shared L1)
+  // G_mode = W^T W: one wave per (p <= q) pair
+  double *G = Gall + (int64_t)mode * R * R;
+  const int nw = blockDim.x >> 6;
+  const int npairs = R * (R + 1) / 2;
+  for (int e = wave; e < npairs; e += nw) {
+    int p = 0, rem = e;
+    while (rem >= R - p) {
+      rem -= R - p;
+      p++;
+    }
+    const int q = p + rem;
+    const double *a = W + ldw * p, *b = W + ldw * q;
+    double sacc = 0;
+    for (int64_t i = lane; i < rows; i += 64) sacc += a[i] * b[i];
+    sacc = wave_sum(sacc);
+    if (lane == 0) {
+      G[p + R * q] = sacc;
+      G[q + R * p] = sacc;
+    }
   }
 }
 

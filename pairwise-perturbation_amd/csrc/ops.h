@@ -103,6 +103,17 @@ class Ops {
                          int R, const double *S, const double *Sinv, double *gradsq,
                          const double *Winit, int64_t ldi, double *dW, int64_t ldd,
                          double ratio) = 0;
+  // one whole single-rank mode update: gram_system + cp_update (W updated in place) + gram of the
+  // new W into Gall[mode]. Backends may fuse it into one launch; S/Sinv may be nullptr.
+  virtual void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
+                              int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg,
+                              int64_t rows, double *gradsq, const double *Winit, int64_t ldi,
+                              double *dW, int64_t ldd, double ratio, double *S, double *Sinv) {
+    gram_system(Gall, N, mode, R, lambda, S, Sinv);
+    cp_update(M, ldm, W, ldw, W, ldw, grad, ldg, rows, R, S, Sinv, gradsq, Winit, ldi, dW, ldd,
+              ratio);
+    gram(W, rows, ldw, R, Gall + (size_t)mode * R * R);
+  }
   // Normalize (common.cxx:680-688) on N full factors using ||W_i||^2 = trace(G_i); rescales the
   // Grams consistently.
   virtual void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) = 0;

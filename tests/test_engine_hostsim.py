@@ -24,6 +24,7 @@ test_fill_and_norm = G.test_fill_and_norm
 test_tree_nodes_and_mttkrp = G.test_tree_nodes_and_mttkrp
 test_pp_operators = G.test_pp_operators
 test_gram_system = G.test_gram_system
+test_jacobi_fallback_path = G.test_jacobi_fallback_path
 test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle

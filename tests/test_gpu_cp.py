@@ -136,6 +136,30 @@ def test_gram_system(pp, ctx, R):
     del t
 
 
+def test_jacobi_fallback_path(pp, tmp_path):
+    """the Jacobi eigen-inverse (fallback when Cholesky meets a non-positive pivot) gives the same
+    sweeps as the Cholesky fast path; forced through PPALS_FORCE_JACOBI on a fresh context"""
+    import os
+    lens, R = [12, 10, 9, 11], 4
+    V, W = problem(lens, R, 3, "r")
+    G = O.init_factors(lens, R, 99)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=3, resprint=1000)
+    os.environ["PPALS_FORCE_JACOBI"] = "1"
+    try:
+        c2 = pp.Context(0)
+    finally:
+        del os.environ["PPALS_FORCE_JACOBI"]
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.CP(c2, t, R)
+    s.set_factors(W, G)
+    S, Si = s.gram_system(1, 0.0)
+    assert relerr(Si @ S, np.eye(R)) < 1e-9 * np.linalg.cond(S)
+    s.sweeps_dt(4)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < 1e-8
+    c2.close()
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R,kind", [([12, 10, 9, 11], 4, "r"), ([12, 10, 9, 11], 4, "r2"),
                                          ([16, 16, 16, 16], 10, "r"), ([14, 9, 11], 3, "r"),

@@ -1,0 +1,139 @@
+// scan_bench.hip — A/B micro-benchmark of the tensor-scan kernel variants (development tool, not
+// part of the product). All variants run interleaved in ONE process on the same buffers
+// (cdna_hip_programming.md §5.4 rule 24); prints median / min ms and algorithmic GB/s.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/scan_bench tools/scan_bench.hip
+//   run:   tools/scan_bench [s=200] [R=10] [rounds=7]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../pairwise-perturbation_amd/csrc/ops.h"
+#include "../pairwise-perturbation_amd/csrc/kernels_scan.hip.h"
+
+using namespace ppals;
+
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) {                                                      \
+      fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__);  \
+      exit(1);                                                                   \
+    }                                                                            \
+  } while (0)
+
+__global__ void k_fill(float *p, int64_t n, uint32_t seed) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)e * 2654435761u ^ seed;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    p[e] = 0.5f + (float)(h & 0xffff) * (0.5f / 65536.f);
+  }
+}
+
+struct Variant {
+  std::string name;
+  std::function<void()> launch;
+  std::vector<float> ms;
+};
+
+int main(int argc, char **argv) {
+  const int s = argc > 1 ? atoi(argv[1]) : 200;
+  const int R = argc > 2 ? atoi(argv[2]) : 10;
+  const int rounds = argc > 3 ? atoi(argv[3]) : 7;
+  const int64_t M = (int64_t)s * s, K = (int64_t)s * s;
+  const int NT = R <= 16 ? 1 : 2;
+  constexpr int VEC = 4;
+  const int nblk = (int)((K + 15) / 16);
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int ncu = prop.multiProcessorCount;
+  printf("device %s, %d CUs; s=%d R=%d: V = %lld x %lld fp32 = %.2f GB\n", prop.name, ncu, s, R,
+         (long long)M, (long long)K, M * K * 4.0 / 1e9);
+
+  float *V, *P;
+  double *slab, *out;
+  CK(hipMalloc(&V, sizeof(float) * M * K));
+  CK(hipMalloc(&P, sizeof(float) * (size_t)nblk * NT * 256 * VEC));
+  CK(hipMalloc(&slab, sizeof(double) * 64 * 16 * NT * M));
+  CK(hipMalloc(&out, sizeof(double) * 16 * NT * M));
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, V, M * K, 1u);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, P, (int64_t)nblk * NT * 256 * VEC, 2u);
+  CK(hipDeviceSynchronize());
+
+  const int n_mtiles = (int)((M + 255) / 256);
+  auto suffix_cfg = [&](int target_mult, int &nsplit, int &per) {
+    nsplit = std::max(1, std::min((ncu * target_mult + n_mtiles - 1) / n_mtiles, nblk / 32));
+    per = (nblk + nsplit - 1) / nsplit;
+    nsplit = (nblk + per - 1) / per;
+  };
+  const int64_t ncolgrp = (K + 63) / 64;
+
+  std::vector<Variant> vs;
+  int ns8, per8, ns4, per4, ns16, per16;
+  suffix_cfg(8, ns8, per8);
+  suffix_cfg(4, ns4, per4);
+  suffix_cfg(16, ns16, per16);
+#define SUFFIX(KERN, ns, per)                                                                     \
+  [=]() {                                                                                         \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)(n_mtiles * ns)), dim3(256), 0, 0, V, M, K, M * K, P, \
+                       n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * M, (int64_t)0, R);         \
+  }
+#define PREFIX(KERN, nsp)                                                                        \
+  [=]() {                                                                                        \
+    int per_ = (nblk + (nsp)-1) / (nsp);                                                         \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)ncolgrp, (unsigned)(nsp)), dim3(256), 0, 0, V, M, K, \
+                       P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * K, R);                  \
+  }
+  if (NT == 1) {
+    vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
+    vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 1, 0>), ns8, per8), {}});
+    vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns8, per8), {}});
+    vs.push_back({"suffix fast xcd         x8", SUFFIX((k_scan_suffix_fast<float, 1, 2>), ns8, per8), {}});
+    vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 1, 3>), ns8, per8), {}});
+    vs.push_back({"suffix fast nt          x4", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns4, per4), {}});
+    vs.push_back({"suffix fast nt         x16", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns16, per16), {}});
+    vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 1, true, 4>), 1), {}});
+    vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 1, 0>), 1), {}});
+    vs.push_back({"prefix fast nt      split1", PREFIX((k_scan_prefix_fast<float, 1, 1>), 1), {}});
+    vs.push_back({"prefix fast nt      split2", PREFIX((k_scan_prefix_fast<float, 1, 1>), 2), {}});
+    vs.push_back({"prefix fast nt      split4", PREFIX((k_scan_prefix_fast<float, 1, 1>), 4), {}});
+  } else {
+    vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
+    vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
+    vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 2, 1>), ns8, per8), {}});
+    vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 2, 3>), ns8, per8), {}});
+    vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 2, true, 4>), 1), {}});
+    vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
+    vs.push_back({"prefix fast nt      split1", PREFIX((k_scan_prefix_fast<float, 2, 1>), 1), {}});
+  }
+  // a plain streaming read of V as the practical ceiling on this device
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int r = 0; r < rounds + 1; r++)
+    for (auto &v : vs) {
+      CK(hipEventRecord(e0, 0));
+      v.launch();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) v.ms.push_back(ms);
+    }
+  const double bytes = (double)M * K * 4.0;
+  printf("%-28s %9s %9s %10s\n", "variant", "med ms", "min ms", "GB/s(med)");
+  for (auto &v : vs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
+    printf("%-28s %9.4f %9.4f %10.1f\n", v.name.c_str(), med, mn, bytes / (med * 1e-3) / 1e9);
+  }
+  return 0;
+}
