@@ -42,6 +42,7 @@ def cpu_baseline(lens, R, budget_s=20.0):
     bounded sample: the same problem at reduced mode size, scaled by s^4"""
     import numpy as np
     import oracle_lib as O
+    O.lib().ppo_set_num_threads(os.cpu_count() or 1)  # the baseline uses every host core
     s_full = lens[0]
     s = min(s_full, 96)
     small = [s] * len(lens)

@@ -315,7 +315,7 @@ class HipOps : public Ops {
   hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
-  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
+  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
         if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_SUFFIX_FAST(1);

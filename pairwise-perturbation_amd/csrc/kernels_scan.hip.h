@@ -447,9 +447,17 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
   const int split = blockIdx.y;
   const int mb0 = split * mb_per_split;
   const int mb1 = min(nmb, mb0 + mb_per_split);
-  const TV *__restrict__ vc = V + min(k, K - 1) * M + (int64_t)VEC * g;  // clamped column
+  // OPT bit 2: the MFMA wants lane = column + 16*rowgroup, but a load coalesces best when the 4
+  // lanes of a quad read 64 contiguous bytes of ONE column. So load as (column = lane>>2,
+  // rowgroup = lane&3) and move every dword to its MFMA lane with ds_bpermute (LDS crossbar,
+  // no LDS memory): lane l pulls from lane 4*(l&15) + (l>>4).
+  constexpr bool PERMUTE = (OPT & 4) != 0;
+  const int lcol = PERMUTE ? (lane >> 2) : j16;
+  const int lg = PERMUTE ? (lane & 3) : g;
+  const int pull = (4 * j16 + g) * 4;  // byte address of the source lane for ds_bpermute
+  const TV *__restrict__ vc = V + min(k0 + lcol, K - 1) * M + (int64_t)VEC * lg;  // clamped column
   const TV *__restrict__ pp = P + ((int64_t)g * 16 + j16) * VEC;
-  const int64_t m_last = M - VEC - (int64_t)VEC * g;  // largest valid block offset for this lane
+  const int64_t m_last = M - VEC - (int64_t)VEC * lg;  // largest valid block offset for this lane
 
   acc_t acc[2][NT];
   double acc64[TR::NEEDS_FLUSH ? NT : 1][4];
@@ -502,6 +510,16 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
       vec nv[U], nb[U][NT];
       const int mn = min(mb + U, mb1 - 1);
       PPALS_LOAD_STEP(mn, nv, nb);
+      if constexpr (PERMUTE) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          typedef int dwords_t __attribute__((ext_vector_type(4)));
+          dwords_t d = __builtin_bit_cast(dwords_t, cv[u]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) d[e] = __builtin_amdgcn_ds_bpermute(pull, d[e]);
+          cv[u] = __builtin_bit_cast(vec, d);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll

@@ -1,0 +1,228 @@
+// driver_common.h — flag parsing, echo block, RCCL bootstrap and tensor construction shared by the
+// test_ALS and pp_bench drivers (reference: test_ALS.cxx:14-326, pp_bench.cxx:14-274).
+#pragma once
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/ppals.h"
+
+using namespace std;
+
+static char *getCmdOption(char **begin, char **end, const std::string &option) {
+  char **itr = std::find(begin, end, option);
+  if (itr != end && ++itr != end) return *itr;
+  return 0;
+}
+static double wtime() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define CHECK(call)                                                          \
+  do {                                                                       \
+    int _rc = (call);                                                        \
+    if (_rc < 0) {                                                           \
+      fprintf(stderr, "ppals driver: %s failed (%d): %s\n", #call, _rc, ppals_last_error()); \
+      return 1;                                                              \
+    }                                                                        \
+  } while (0)
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// RCCL unique-id exchange through the file system (single node): rank 0 writes, the others poll
+static int exchange_uid(int rank, unsigned char *uid) {
+  std::string dir = getenv("PPALS_UID_DIR") ? getenv("PPALS_UID_DIR") : "/tmp";
+  std::string tag = getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
+  std::string path = dir + "/ppals_uid_" + tag + "_" + std::to_string((long)getppid());
+  if (getenv("PPALS_UID_FILE")) path = getenv("PPALS_UID_FILE");
+  if (rank == 0) {
+    if (ppals_get_unique_id(uid) < 0) return -1;
+    std::string tmp = path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return -1;
+    fwrite(uid, 1, PPALS_UNIQUE_ID_BYTES, f);
+    fclose(f);
+    rename(tmp.c_str(), path.c_str());
+    return 0;
+  }
+  for (int tries = 0; tries < 6000; tries++) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (f) {
+      size_t n = fread(uid, 1, PPALS_UNIQUE_ID_BYTES, f);
+      fclose(f);
+      if (n == PPALS_UNIQUE_ID_BYTES) return 0;
+    }
+    usleep(10000);
+  }
+  return -1;
+}
+
+
+struct Args {
+  const char *model, *tensor, *filename, *tensorfile;
+  int pp, dim, s, R, issparse, maxiter, resprint, prec, device, rank, world;
+  double update_percentage_pp, tol, pp_res_tol, lambda_, magni, col_min, col_max, ratio_noise,
+      timelimit;
+  uint64_t seed;
+};
+
+// test_ALS.cxx:64-196 — same defaults, same silent resets. resprint_default: 10 in test_ALS
+// (test_ALS.cxx:133-139), 1 in pp_bench (pp_bench.cxx).
+static Args parse_args(int argc, char **argv, int resprint_default) {
+  Args a;
+  char **b = argv, **e = argv + argc;
+  char *o;
+  a.model = (o = getCmdOption(b, e, "-model")) ? o : "CP";
+  if (a.model[0] != 'C' && a.model[0] != 'T') a.model = "CP";
+  a.tensor = (o = getCmdOption(b, e, "-tensor")) ? o : "p";
+  a.pp = (o = getCmdOption(b, e, "-pp")) ? atoi(o) : 0;
+  if (a.pp < 0 || a.pp > 2) a.pp = 0;
+  a.update_percentage_pp = (o = getCmdOption(b, e, "-update_percentage_pp")) ? atof(o) : 1.0;
+  if (a.update_percentage_pp < 0 || a.update_percentage_pp > 1) a.update_percentage_pp = 1.0;
+  a.dim = (o = getCmdOption(b, e, "-dim")) ? atoi(o) : 8;
+  if (a.dim < 0) a.dim = 8;
+  a.maxiter = (o = getCmdOption(b, e, "-maxiter")) ? atoi(o) : 5e3;
+  if (a.maxiter < 0) a.maxiter = 5e3;
+  a.timelimit = (o = getCmdOption(b, e, "-timelimit")) ? atof(o) : 5e3;
+  if (a.timelimit < 0) a.timelimit = 5e3;
+  a.s = (o = getCmdOption(b, e, "-size")) ? atoi(o) : 10;
+  if (a.s < 0) a.s = 10;
+  a.R = (o = getCmdOption(b, e, "-rank")) ? atoi(o) : a.s / 2;
+  if (a.R < 0 || a.R > a.s) a.R = a.s / 2;
+  a.issparse = (o = getCmdOption(b, e, "-issparse")) ? atoi(o) : 0;
+  if (a.issparse < 0 || a.issparse > 1) a.issparse = 0;
+  a.resprint = (o = getCmdOption(b, e, "-resprint")) ? atoi(o) : resprint_default;
+  if (a.resprint < 0) a.resprint = 10;
+  a.tol = (o = getCmdOption(b, e, "-tol")) ? atof(o) : 1e-10;
+  if (a.tol < 0 || a.tol > 1) a.tol = 1e-10;
+  a.pp_res_tol = (o = getCmdOption(b, e, "-pp_res_tol")) ? atof(o) : 1e-2;
+  if (a.pp_res_tol < 0 || a.pp_res_tol > 1) a.pp_res_tol = 1e-2;
+  a.lambda_ = (o = getCmdOption(b, e, "-lambda")) ? atof(o) : 0.;
+  if (a.lambda_ < 0) a.lambda_ = 0.;
+  a.magni = (o = getCmdOption(b, e, "-magni")) ? atof(o) : 1.;
+  if (a.magni < 0) a.magni = 1.;
+  a.filename = (o = getCmdOption(b, e, "-filename")) ? o : "out.csv";
+  a.tensorfile = (o = getCmdOption(b, e, "-tensorfile")) ? o : "test";
+  a.col_min = (o = getCmdOption(b, e, "-colmin")) ? atof(o) : 0.5;
+  a.col_max = (o = getCmdOption(b, e, "-colmax")) ? atof(o) : 0.9;
+  a.ratio_noise = (o = getCmdOption(b, e, "-rationoise")) ? atof(o) : 0.01;
+  if (a.ratio_noise < 0) a.ratio_noise = 0.01;
+  // extra flags (the reference's parser ignores unknown flags)
+  a.prec = (o = getCmdOption(b, e, "-prec")) ? atoi(o) : 32;
+  a.seed = (o = getCmdOption(b, e, "-seed")) ? strtoull(o, 0, 10) : 0;
+  a.rank = env_int("RANK", 0);
+  a.world = env_int("WORLD_SIZE", 1);
+  a.device = (o = getCmdOption(b, e, "-device")) ? atoi(o) : env_int("LOCAL_RANK", 0);
+  return a;
+}
+
+// test_ALS.cxx:203-217
+static void echo_args(const Args &a, bool with_files) {
+  cout << "  model=  " << a.model << "  tensor=  " << a.tensor << "  pp=  " << a.pp << endl;
+  cout << "  dim=  " << a.dim << "  size=  " << a.s << "  rank=  " << a.R << endl;
+  cout << "  issparse=  " << a.issparse << "  tolerance=  " << a.tol << "  restarttol=  "
+       << a.pp_res_tol << endl;
+  cout << "  lambda=  " << a.lambda_ << "  magnitude=  " << a.magni << "  filename=  "
+       << a.filename << endl;
+  cout << "  col_min=  " << a.col_min << "  col_max=  " << a.col_max << "  rationoise  "
+       << a.ratio_noise << endl;
+  cout << "  timelimit=  " << a.timelimit << "  maxiter=  " << a.maxiter << "  resprint=  "
+       << a.resprint << endl;
+  if (with_files)
+    cout << "  tensorfile=  " << a.tensorfile
+         << "  update_percentage_pp=  " << a.update_percentage_pp << endl;
+}
+
+static void init_factors_flat(const std::vector<int64_t> &lens, int R, uint64_t sd,
+                              std::vector<double> &flat) {
+  size_t tot = 0;
+  for (auto l : lens) tot += (size_t)l * R;
+  flat.resize(tot);
+  double *p = flat.data();
+  for (size_t i = 0; i < lens.size(); i++) {
+    ppals_fill_uniform_host(p, lens[i] * R, sd + i, 0, 0.0, 1.0);
+    p += lens[i] * R;
+  }
+}
+
+// context (+ RCCL bootstrap) and tensor: test_ALS.cxx:220-326. r2_lo/r2_hi: (0.5,1) in test_ALS
+// (test_ALS.cxx:272), (-1,1) in pp_bench. Returns 0 on success.
+static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **ctx_out,
+                               ppals_tensor **V_out, std::vector<int64_t> &lens) {
+  if (a.dim < 2 || a.dim > PPALS_MAX_ORDER) {
+    fprintf(stderr, "-dim must be in [2,%d] for this engine\n", PPALS_MAX_ORDER);
+    return 2;
+  }
+  if (a.issparse) {
+    fprintf(stderr, "-issparse 1 is not supported (dense engine)\n");
+    return 2;
+  }
+  ppals_ctx *ctx = nullptr;
+  CHECK(ppals_ctx_create(&ctx, a.device));
+  if (a.world > 1) {
+    unsigned char uid[PPALS_UNIQUE_ID_BYTES];
+    if (exchange_uid(a.rank, uid) != 0) {
+      fprintf(stderr, "RCCL unique-id exchange failed\n");
+      return 1;
+    }
+    CHECK(ppals_ctx_init_comm(ctx, a.rank, a.world, uid));
+  }
+  lens.assign(a.dim, (int64_t)a.s);
+  const int dtype = a.prec == 64 ? PPALS_F64 : PPALS_F32;
+  const char *tensor = a.tensor;
+  bool from_file = false;
+  if (tensor[0] == 'o') {  // raw fp64, first index fastest (test_ALS.cxx:287-326)
+    if (strlen(tensor) > 1 && tensor[1] == '1') {
+      a.tensorfile = "coil-100.bin";
+      lens = {3, 128, 128, 7200};
+    } else if (strlen(tensor) > 1 && tensor[1] == '2') {
+      a.tensorfile = "time-lapse.bin";
+      lens = {33, 1344, 1024, 9};
+    }
+    a.dim = (int)lens.size();
+    from_file = true;
+  }
+  ppals_tensor *V = nullptr;
+  CHECK(ppals_tensor_create(ctx, a.dim, lens.data(), dtype, &V));
+  if (from_file) {
+    if (a.rank == 0) cout << "Read the tensor from file " << a.tensorfile << " ...... " << endl;
+    size_t n = 1;
+    for (auto l : lens) n *= (size_t)l;
+    std::vector<double> host(n);
+    FILE *f = fopen(a.tensorfile, "rb");
+    if (!f || fread(host.data(), sizeof(double), n, f) != n) {
+      fprintf(stderr, "cannot read %zu doubles from %s\n", n, a.tensorfile);
+      return 2;
+    }
+    fclose(f);
+    CHECK(ppals_tensor_upload(V, host.data()));
+    if (a.rank == 0) cout << "Read dataset finished " << endl;
+  } else if (tensor[0] == 'r' && strlen(tensor) > 1 && tensor[1] == '2') {
+    CHECK(ppals_tensor_fill_uniform(V, 7000 + a.seed, r2_lo, r2_hi));
+  } else if (tensor[0] == 'r') {
+    if (a.R > 64) {
+      fprintf(stderr, "this build supports -rank <= 64\n");
+      return 2;
+    }
+    std::vector<double> Wtrue;  // test_ALS.cxx:279-284
+    init_factors_flat(lens, a.R, 1000 + 16 * a.seed, Wtrue);
+    CHECK(ppals_tensor_fill_cp(V, a.R, Wtrue.data()));
+  } else {
+    fprintf(stderr, "-tensor %s is not supported by this engine yet (supported: r, r2, o1, o2)\n",
+            tensor);
+    return 2;
+  }
+  *ctx_out = ctx;
+  *V_out = V;
+  return 0;
+}

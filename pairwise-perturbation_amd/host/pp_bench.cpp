@@ -1,0 +1,70 @@
+// pp_bench.cpp — replacement of the reference's pp_bench driver (pp_bench.cxx:22-364): the
+// per-phase timer the authors' scaling scripts use. Same CLI; runs `maxiter` repetitions of ONE
+// exact dimension-tree sweep and of ONE PP initialisation + approximate sweep, each restarted from
+// the same W, and writes `[DTtime],t`, `  [PPfirst]  ,t` (PP init + 1 approximate sweep) and
+// `  [PPsecond]  ,t` (1 approximate sweep) lines (emitters: als_CP.cxx:204-208,736-747).
+#include "driver_common.h"
+
+int main(int argc, char **argv) {
+  Args a = parse_args(argc, argv, 1);
+  double start_time = wtime();
+  if (a.rank == 0) echo_args(a, false);
+  if (a.resprint == 0) a.resprint = 1;
+  ppals_ctx *ctx = nullptr;
+  ppals_tensor *V = nullptr;
+  std::vector<int64_t> lens;
+  if (int rc = make_ctx_and_tensor(a, -1.0, 1.0, &ctx, &V, lens)) return rc;  // pp_bench.cxx r2
+  double Vnorm = 0;
+  CHECK(ppals_tensor_norm(V, &Vnorm));
+
+  if (a.rank == 0) {  // pp_bench.cxx:296-298: heading line, the callees append
+    std::ofstream f(a.filename);
+    f << "[timetype],[dtime]" << "\n";
+  }
+  ppals_cp_opts opt;
+  memset(&opt, 0, sizeof(opt));
+  opt.tol = a.tol * Vnorm;
+  opt.timelimit = a.timelimit;
+  opt.maxiter = 1;  // pp_bench.cxx:300,307
+  opt.lambda = a.lambda_;
+  opt.resprint = a.resprint;
+  opt.bench = 1;
+  opt.tol_init = a.pp_res_tol;
+  opt.ratio_step = a.magni;
+  opt.csv_path = a.filename;
+  opt.csv_append = 1;
+  opt.verbose = 1;
+  int iters = 0;
+
+  if (a.model[0] == 'C') {
+    std::vector<double> W, G;
+    init_factors_flat(lens, a.R, 2000 + 16 * a.seed, W);
+    init_factors_flat(lens, a.R, 3000 + 16 * a.seed, G);
+    ppals_cp *cp = nullptr;
+    CHECK(ppals_cp_create(ctx, V, a.R, &cp));
+    for (int i = 0; i < a.maxiter; i++) {  // pp_bench.cxx:299-305
+      CHECK(ppals_cp_set_factors(cp, W.data(), G.data()));
+      CHECK(ppals_cp_dt(cp, &opt, &iters));
+    }
+    if (a.rank == 0) {
+      std::ofstream f(a.filename, std::ios::app);
+      f << std::endl;
+    }
+    for (int i = 0; i < a.maxiter; i++) {  // pp_bench.cxx:308-314
+      CHECK(ppals_cp_set_factors(cp, W.data(), G.data()));
+      CHECK(ppals_cp_pp(cp, &opt, &iters));
+    }
+    if (a.rank == 0) {
+      std::ofstream f(a.filename, std::ios::app);
+      f << std::endl;
+    }
+    ppals_cp_destroy(cp);
+  } else {
+    fprintf(stderr, "pp_bench: -model Tucker is not supported yet (Tucker PP is out of scope)\n");
+    return 2;
+  }
+  if (a.rank == 0) printf("experiment took %lf seconds\n", wtime() - start_time);
+  ppals_tensor_destroy(V);
+  ppals_ctx_destroy(ctx);
+  return 0;
+}

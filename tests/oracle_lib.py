@@ -28,6 +28,9 @@ def lib():
         _LIB.ppo_residual.restype = C.c_double
         _LIB.ppo_tree_node.restype = C.c_int64
         _LIB.ppo_pp_operator.restype = C.c_int64
+        # the parity problems are tiny: on a many-core host (the GPU box exposes 128 threads) the
+        # OpenMP fork/join of hundreds of small regions dominates, so cap the team
+        _LIB.ppo_set_num_threads(int(os.environ.get("PPALS_ORACLE_THREADS", "4")))
     return _LIB
 
 

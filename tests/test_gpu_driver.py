@@ -1,0 +1,88 @@
+"""GPU tests of the C++ drivers (bin/test_ALS, bin/pp_bench): CLI compatibility with the reference
+(test_ALS.cxx:64-217), CSV format, and numeric agreement of the whole run with the oracle driven
+from the same counter-based initialisation."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "pairwise-perturbation_amd", "bin")
+
+
+def run(cmd):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("pp,prec", [(0, 64), (1, 64), (0, 32)])
+def test_test_ALS_matches_oracle(tmp_path, pp, prec):
+    s, R, N = 12, 3, 4
+    csv = str(tmp_path / "out.csv")
+    out = run([os.path.join(BIN, "test_ALS"), "-model", "CP", "-tensor", "r", "-dim", str(N),
+               "-size", str(s), "-rank", str(R), "-pp", str(pp), "-maxiter", "30", "-resprint", "1",
+               "-pp_res_tol", "0.1", "-tol", "1e-6", "-filename", csv, "-prec", str(prec)])
+    lines = out.splitlines()
+    # echo block, test_ALS.cxx:203-217
+    assert lines[0] == f"  model=  CP  tensor=  r  pp=  {pp}"
+    assert lines[1] == f"  dim=  {N}  size=  {s}  rank=  {R}"
+    assert lines[2] == "  issparse=  0  tolerance=  1e-06  restarttol=  0.1"
+    assert lines[5] == "  timelimit=  5000  maxiter=  30  resprint=  1"
+    assert lines[6] == "  tensorfile=  test  update_percentage_pp=  1"
+    assert lines[7].startswith("Vnorm= ")
+    assert any(ln.startswith("Iter = ") for ln in lines)
+    assert any(ln.startswith("tf took ") for ln in lines)
+    assert lines[-1].startswith("experiment took ")
+    lens = [s] * N
+    V = O.build_V(O.init_factors(lens, R, 1000))
+    W, G = O.init_factors(lens, R, 2000), O.init_factors(lens, R, 3000)
+    Vn = np.linalg.norm(V)
+    assert abs(float(lines[7].split()[1]) - Vn) < 1e-5 * Vn
+    ref = str(tmp_path / "ref.csv")
+    if pp == 0:
+        O.als_cp_dt(V, W, G, tol=1e-6 * Vn, maxiter=30, csv=ref, resprint=1)
+    else:
+        O.als_cp_pp(V, W, G, tol=1e-6 * Vn, tol_init=0.1, maxiter=30, csv=ref, resprint=1)
+    h1, r1 = O.read_csv(ref)
+    h2, r2 = O.read_csv(csv)
+    assert h1 == h2 == ["[dim]", "[iter]", "[gradnorm]", "[tol]", "[pp_update]", "[diffV]", "[dtime]"]
+    n = min(len(r1), len(r2))
+    assert n >= 5
+    tol = 1e-4 if prec == 64 else 5e-3
+    for a, b in zip(r1[:n], r2[:n]):
+        if a[5] < 1e-4 * Vn:
+            break
+        assert a[:2] == b[:2] and a[4] == b[4]
+        assert abs(a[2] - b[2]) <= tol * abs(a[2]) and abs(a[5] - b[5]) <= tol * abs(a[5])
+
+
+def test_cli_defaults_and_silent_resets(tmp_path):
+    """out-of-range values are silently reset to the defaults (test_ALS.cxx:76-146)"""
+    csv = str(tmp_path / "o.csv")
+    out = run([os.path.join(BIN, "test_ALS"), "-model", "X", "-tensor", "r", "-dim", "3", "-size",
+               "8", "-rank", "99", "-pp", "7", "-tol", "5", "-maxiter", "2", "-bogus", "1",
+               "-filename", csv])
+    lines = out.splitlines()
+    assert lines[0] == "  model=  CP  tensor=  r  pp=  0"
+    assert lines[1] == "  dim=  3  size=  8  rank=  4"      # rank reset to s/2
+    assert "tolerance=  1e-10" in lines[2]                   # tol > 1 reset
+    assert "resprint=  10" in lines[5]
+
+
+def test_pp_bench_lines(tmp_path):
+    csv = str(tmp_path / "b.csv")
+    run([os.path.join(BIN, "pp_bench"), "-model", "CP", "-tensor", "r", "-dim", "4", "-size", "16",
+         "-rank", "3", "-maxiter", "3", "-filename", csv])
+    text = open(csv).read().splitlines()
+    assert text[0] == "[timetype],[dtime]"
+    assert sum(ln.startswith("[DTtime],") for ln in text) == 3
+    assert sum(ln.startswith("  [PPfirst]  ,") for ln in text) == 3
+    assert sum(ln.startswith("  [PPsecond]  ,") for ln in text) == 3
+    for ln in text:
+        if "," in ln and not ln.startswith("[timetype]"):
+            assert float(ln.split(",")[1]) > 0

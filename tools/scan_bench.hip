@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <functional>
 #include <string>
@@ -41,6 +42,7 @@ struct Variant {
   std::string name;
   std::function<void()> launch;
   std::vector<float> ms;
+  int kind = 0, nsplit = 1;  // filled from the name below
 };
 
 int main(int argc, char **argv) {
@@ -102,8 +104,11 @@ int main(int argc, char **argv) {
     vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 1, true, 4>), 1), {}});
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 1, 0>), 1), {}});
     vs.push_back({"prefix fast nt      split1", PREFIX((k_scan_prefix_fast<float, 1, 1>), 1), {}});
-    vs.push_back({"prefix fast nt      split2", PREFIX((k_scan_prefix_fast<float, 1, 1>), 2), {}});
-    vs.push_back({"prefix fast nt      split4", PREFIX((k_scan_prefix_fast<float, 1, 1>), 4), {}});
+    vs.push_back({"prefix fast         split2", PREFIX((k_scan_prefix_fast<float, 1, 0>), 2), {}});
+    vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 1, 4>), 1), {}});
+    vs.push_back({"prefix fast perm    split2", PREFIX((k_scan_prefix_fast<float, 1, 4>), 2), {}});
+    vs.push_back({"prefix fast perm+nt split2", PREFIX((k_scan_prefix_fast<float, 1, 5>), 2), {}});
+    vs.push_back({"prefix fast perm    split4", PREFIX((k_scan_prefix_fast<float, 1, 4>), 4), {}});
   } else {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
@@ -111,7 +116,8 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 2, 3>), ns8, per8), {}});
     vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 2, true, 4>), 1), {}});
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
-    vs.push_back({"prefix fast nt      split1", PREFIX((k_scan_prefix_fast<float, 2, 1>), 1), {}});
+    vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 2, 4>), 1), {}});
+    vs.push_back({"prefix fast perm    split2", PREFIX((k_scan_prefix_fast<float, 2, 4>), 2), {}});
   }
   // a plain streaming read of V as the practical ceiling on this device
   hipEvent_t e0, e1;
@@ -129,11 +135,40 @@ int main(int argc, char **argv) {
       if (r > 0) v.ms.push_back(ms);
     }
   const double bytes = (double)M * K * 4.0;
-  printf("%-28s %9s %9s %10s\n", "variant", "med ms", "min ms", "GB/s(med)");
+  // correctness cross-check: every variant must reproduce the first variant of its kind on the
+  // first 2048 outputs of column n=0..1 (summed over its split slabs)
+  const int NCHK = 2048;
+  std::vector<double> ref[2];
+  printf("%-28s %9s %9s %10s %12s\n", "variant", "med ms", "min ms", "GB/s(med)", "max rel diff");
   for (auto &v : vs) {
+    v.kind = v.name.rfind("prefix", 0) == 0 ? 1 : 0;
+    if (v.kind == 0) {
+      int mult = atoi(v.name.c_str() + v.name.rfind('x') + 1);
+      int ns, per;
+      suffix_cfg(mult, ns, per);
+      v.nsplit = ns;
+    } else {
+      v.nsplit = atoi(v.name.c_str() + v.name.size() - 1);
+    }
+    CK(hipMemset(slab, 0, sizeof(double) * 64 * 16 * NT * M));
+    v.launch();
+    CK(hipDeviceSynchronize());
+    std::vector<double> acc(NCHK, 0.0), tmp(NCHK);
+    const int64_t stride = (int64_t)16 * (v.kind == 0 ? M : K);
+    for (int sp = 0; sp < v.nsplit; sp++) {
+      CK(hipMemcpy(tmp.data(), slab + sp * stride, sizeof(double) * NCHK, hipMemcpyDeviceToHost));
+      for (int i = 0; i < NCHK; i++) acc[i] += tmp[i];
+    }
+    double maxrel = 0;
+    if (ref[v.kind].empty())
+      ref[v.kind] = acc;
+    else
+      for (int i = 0; i < NCHK; i++)
+        maxrel = std::max(maxrel, fabs(acc[i] - ref[v.kind][i]) / (fabs(ref[v.kind][i]) + 1e-300));
     std::sort(v.ms.begin(), v.ms.end());
     float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
-    printf("%-28s %9.4f %9.4f %10.1f\n", v.name.c_str(), med, mn, bytes / (med * 1e-3) / 1e9);
+    printf("%-28s %9.4f %9.4f %10.1f %12.3e\n", v.name.c_str(), med, mn,
+           bytes / (med * 1e-3) / 1e9, maxrel);
   }
   return 0;
 }
