@@ -99,6 +99,7 @@ class HipOps : public Ops {
   void zero(void *p, size_t bytes) override { HIP_CHECK(hipMemsetAsync(p, 0, bytes, st_)); }
   void sync() override { HIP_CHECK(hipStreamSynchronize(st_)); }
   void *stream() override { return (void *)st_; }
+  void bind() override { HIP_CHECK(hipSetDevice(dev_)); }
 
   // ------------------------------------------------------------------ generation / norms
   void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
@@ -261,7 +262,7 @@ class HipOps : public Ops {
   hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
 #define LAUNCH_PREFIX_FAST(NTv)                                                               \
-  hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv>), grid, dim3(256), 0, st_, V, M, K, P, per, \
+  hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
         if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_PREFIX_FAST(1);

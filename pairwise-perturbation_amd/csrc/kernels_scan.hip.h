@@ -440,8 +440,13 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j16 = lane & 15;
-  const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
-  if (k0 >= K) return;  // wave-uniform
+  // OPT bit 3: the 4 waves of a workgroup share ONE group of 16 columns and interleave along the
+  // reduction rows (wave w takes steps w, w+4, ...), so a workgroup step reads 4 x U x 64 B =
+  // 1 KiB contiguous per column instead of 256 B from 64 different columns (DRAM page locality);
+  // the four partial tiles are combined through LDS at the end. grid.x = ceil(K/16) then.
+  constexpr bool INTERLEAVE = (OPT & 8) != 0;
+  const int64_t k0 = INTERLEAVE ? (int64_t)blockIdx.x * 16 : ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (k0 >= K) return;  // wave-uniform (block-uniform when INTERLEAVE)
   const int64_t k = k0 + j16;
   const bool k_ok = k < K;
   const int split = blockIdx.y;
@@ -503,12 +508,14 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
       }                                                                                      \
     }                                                                                        \
   }
-  if (mb0 < mb1) PPALS_LOAD_STEP(mb0, cv, cb);
-  for (int mc = mb0; mc < mb1; mc += U * FLUSH) {
-    const int me = min(mb1, mc + U * FLUSH);
-    for (int mb = mc; mb < me; mb += U) {
+  constexpr int STRIDE = INTERLEAVE ? 4 * U : U;  // distance between this wave's steps
+  const int mstart = INTERLEAVE ? mb0 + wave * U : mb0;
+  if (mstart < mb1) PPALS_LOAD_STEP(mstart, cv, cb);
+  for (int mc = mstart; mc < mb1; mc += STRIDE * FLUSH) {
+    const int me = min(mb1, mc + STRIDE * FLUSH);
+    for (int mb = mc; mb < me; mb += STRIDE) {
       vec nv[U], nb[U][NT];
-      const int mn = min(mb + U, mb1 - 1);
+      const int mn = min(mb + STRIDE, mb1 - 1);
       PPALS_LOAD_STEP(mn, nv, nb);
       if constexpr (PERMUTE) {
 #pragma unroll
@@ -548,19 +555,38 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 #undef PPALS_LOAD_STEP
 
   double *__restrict__ o = out + split * out_split_stride;
+  double val[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if constexpr (TR::NEEDS_FLUSH)
+        val[nt][r] = acc64[nt][r];
+      else
+        val[nt][r] = (double)acc[0][nt][r] + (double)acc[1][nt][r];
+    }
+  if constexpr (INTERLEAVE) {
+    __shared__ double red[3][NT][4][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave - 1][nt][r][lane] = val[nt][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        val[nt][r] += (red[0][nt][r][lane] + red[1][nt][r][lane]) + red[2][nt][r][lane];
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int n = 16 * nt + TR::row(lane, r);
-      if (n < ncols && k_ok) {
-        double val;
-        if constexpr (TR::NEEDS_FLUSH)
-          val = acc64[nt][r];
-        else
-          val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
-        o[(int64_t)n * out_nstride + k * out_kstride] = val;
-      }
+      if (n < ncols && k_ok) o[(int64_t)n * out_nstride + k * out_kstride] = val[nt][r];
     }
 }
 

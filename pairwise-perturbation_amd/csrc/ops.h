@@ -42,6 +42,7 @@ class Ops {
   virtual void zero(void *p, size_t bytes) = 0;
   virtual void sync() = 0;
   virtual void *stream() { return nullptr; }
+  virtual void bind() {}  // make this Ops' device current on the calling thread
 
   // ---- tensor generation / norms ----
   // V[e_local] = lo + (hi-lo)*u01(seed, global linear index); local shard = rows [row0,row0+l0)

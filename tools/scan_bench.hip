@@ -85,13 +85,19 @@ int main(int argc, char **argv) {
 #define SUFFIX(KERN, ns, per)                                                                     \
   [=]() {                                                                                         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)(n_mtiles * ns)), dim3(256), 0, 0, V, M, K, M * K, P, \
-                       n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * M, (int64_t)0, R);         \
+                       n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * NT * M, (int64_t)0, R);    \
+  }
+#define PREFIXI(KERN, nsp)                                                                        \
+  [=]() {                                                                                         \
+    int per_ = (nblk + (nsp)-1) / (nsp);                                                          \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)((K + 15) / 16), (unsigned)(nsp)), dim3(256), 0, 0, V, \
+                       M, K, P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R);        \
   }
 #define PREFIX(KERN, nsp)                                                                        \
   [=]() {                                                                                        \
     int per_ = (nblk + (nsp)-1) / (nsp);                                                         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)ncolgrp, (unsigned)(nsp)), dim3(256), 0, 0, V, M, K, \
-                       P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * K, R);                  \
+                       P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R);             \
   }
   if (NT == 1) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
@@ -108,7 +114,10 @@ int main(int argc, char **argv) {
     vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 1, 4>), 1), {}});
     vs.push_back({"prefix fast perm    split2", PREFIX((k_scan_prefix_fast<float, 1, 4>), 2), {}});
     vs.push_back({"prefix fast perm+nt split2", PREFIX((k_scan_prefix_fast<float, 1, 5>), 2), {}});
-    vs.push_back({"prefix fast perm    split4", PREFIX((k_scan_prefix_fast<float, 1, 4>), 4), {}});
+    vs.push_back({"prefix fast il      split1", PREFIXI((k_scan_prefix_fast<float, 1, 8>), 1), {}});
+    vs.push_back({"prefix fast il+perm split1", PREFIXI((k_scan_prefix_fast<float, 1, 12>), 1), {}});
+    vs.push_back({"prefix fast il+p+nt split1", PREFIXI((k_scan_prefix_fast<float, 1, 13>), 1), {}});
+    vs.push_back({"prefix fast il+perm split2", PREFIXI((k_scan_prefix_fast<float, 1, 12>), 2), {}});
   } else {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
@@ -118,6 +127,8 @@ int main(int argc, char **argv) {
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
     vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 2, 4>), 1), {}});
     vs.push_back({"prefix fast perm    split2", PREFIX((k_scan_prefix_fast<float, 2, 4>), 2), {}});
+    vs.push_back({"prefix fast il+perm split1", PREFIXI((k_scan_prefix_fast<float, 2, 12>), 1), {}});
+    vs.push_back({"prefix fast il+p+nt split1", PREFIXI((k_scan_prefix_fast<float, 2, 13>), 1), {}});
   }
   // a plain streaming read of V as the practical ceiling on this device
   hipEvent_t e0, e1;
@@ -154,7 +165,7 @@ int main(int argc, char **argv) {
     v.launch();
     CK(hipDeviceSynchronize());
     std::vector<double> acc(NCHK, 0.0), tmp(NCHK);
-    const int64_t stride = (int64_t)16 * (v.kind == 0 ? M : K);
+    const int64_t stride = (int64_t)16 * NT * (v.kind == 0 ? M : K);
     for (int sp = 0; sp < v.nsplit; sp++) {
       CK(hipMemcpy(tmp.data(), slab + sp * stride, sizeof(double) * NCHK, hipMemcpyDeviceToHost));
       for (int i = 0; i < NCHK; i++) acc[i] += tmp[i];
