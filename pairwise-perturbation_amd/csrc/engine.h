@@ -117,6 +117,9 @@ class CpEngine {
   double *sendbuf_ = nullptr, *recvbuf_ = nullptr, *gatherbuf_ = nullptr;
   double *Mbuf_ = nullptr;    // PP: M_i^0 + corrections
   double *Qbuf_ = nullptr, *Pbuf_ = nullptr;  // residual KRP operands
+  void *VT_ = nullptr;        // second resident layout of V: right-half modes fastest
+  int vt_state_ = 0;          // 0 not tried, 1 built, -1 unavailable (disabled / no memory)
+  void ensure_transposed();
   int64_t maxs_ = 0, maxblk_ = 0;
   std::vector<Node> nodes_;
   std::vector<int> leaf_;  // node index of each leaf

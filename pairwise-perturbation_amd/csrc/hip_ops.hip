@@ -190,6 +190,27 @@ class HipOps : public Ops {
     free(stage);
   }
 
+  void *try_alloc(size_t bytes) override {
+    void *p = nullptr;
+    hipSetDevice(dev_);
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return p;
+  }
+  void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) override {
+    const int64_t nb = ((rows + 63) / 64) * ((cols + 63) / 64);
+    if (nb > 0x7fffffff) throw std::runtime_error("ppals: transpose grid too large");
+    if (dt == F32)
+      hipLaunchKernelGGL(k_transpose<float>, dim3((unsigned)nb), dim3(256), 0, st_,
+                         (const float *)src, rows, cols, (float *)dst);
+    else
+      hipLaunchKernelGGL(k_transpose<double>, dim3((unsigned)nb), dim3(256), 0, st_,
+                         (const double *)src, rows, cols, (double *)dst);
+    HIP_CHECK(hipGetLastError());
+  }
+
   // ------------------------------------------------------------------ KRP
   static KrpArgs krp_args(const FactorRef *f, int nf, int64_t *J) {
     KrpArgs a;
@@ -257,12 +278,13 @@ class HipOps : public Ops {
           dst_ss = (int64_t)ncols * K;
         }
         dim3 grid((unsigned)ncolgrp, (unsigned)nsplit);
+        dim3 grid_il((unsigned)((K + 15) / 16), (unsigned)nsplit);  // interleaved-waves variant
         prof_begin(0, bytes);
 #define LAUNCH_PREFIX(NTv, ALv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
 #define LAUNCH_PREFIX_FAST(NTv)                                                               \
-  hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
+  hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv, 12>), grid_il, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
         if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_PREFIX_FAST(1);

@@ -107,6 +107,27 @@ __global__ __launch_bounds__(256) void k_rank_stream(TV *__restrict__ V, int64_t
   }
 }
 
+// dst[c + cols*r] = src[r + rows*c]: 64x64 tiles through LDS (both sides coalesced)
+template <typename TV>
+__global__ __launch_bounds__(256) void k_transpose(const TV *__restrict__ src, int64_t rows,
+                                                   int64_t cols, TV *__restrict__ dst) {
+  __shared__ TV tile[64][65];
+  const int64_t tiles_r = (rows + 63) / 64;
+  const int64_t r0 = (int64_t)(blockIdx.x % tiles_r) * 64, c0 = (int64_t)(blockIdx.x / tiles_r) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty in [0,4)
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+    if (r < rows && c < cols) tile[ty + 4 * i][tx] = src[r + rows * c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+    if (r < rows && c < cols) dst[c + cols * r] = tile[tx][ty + 4 * i];
+  }
+}
+
 template <typename TV>
 __global__ void k_convert_rows(TV *__restrict__ dst, const double *__restrict__ src, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;

@@ -59,6 +59,12 @@ class Ops {
   virtual void upload_shard(void *V, int dt, const double *host_full, int64_t l0, int64_t g0,
                             int64_t row0, int64_t rest) = 0;
 
+  // dst[c + cols*r] = src[r + rows*c] (same element type dt): builds the second resident layout
+  // of the tensor (right-half modes fastest) so that BOTH first-level tree nodes are suffix scans
+  virtual void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) = 0;
+  // alloc that returns nullptr instead of throwing when the device is out of memory
+  virtual void *try_alloc(size_t bytes) { return alloc(bytes); }
+
   // ---- Khatri-Rao product, plain: out[j + J*c] = prod_f W_f[j_f + ld_f*(col0+c)], fp64 ----
   virtual void krp(double *out, const FactorRef *f, int nf, int col0, int ncols) = 0;
 

@@ -122,6 +122,10 @@ class HostOps : public Ops {
       for (int64_t a = 0; a < l0; a++) st(V, dt, a + l0 * c, host_full[row0 + a + g0 * c]);
   }
 
+  void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) override {
+    for (int64_t c = 0; c < cols; c++)
+      for (int64_t r = 0; r < rows; r++) st(dst, dt, c + cols * r, ld(src, dt, r + rows * c));
+  }
   static std::vector<double> krp_mat(const FactorRef *f, int nf, int col0, int ncols, int64_t *J) {
     int64_t j = 1;
     for (int i = 0; i < nf; i++) j *= f[i].rows;

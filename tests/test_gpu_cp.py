@@ -74,10 +74,13 @@ def test_fill_and_norm(pp, ctx, dtype):
     assert abs(s.residual() - O.residual(V, W2)) < (1e-6 if dtype == 0 else 1e-11) * O.residual(V, W2)
 
 
+@pytest.mark.parametrize("vt", [1, 0])
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R", SHAPES)
-def test_tree_nodes_and_mttkrp(pp, ctx, lens, R, dtype):
-    """K1/K2/K3: every first-level node and every mode's MTTKRP vs the oracle"""
+def test_tree_nodes_and_mttkrp(pp, ctx, lens, R, dtype, vt, monkeypatch):
+    """K1/K2/K3: every first-level node and every mode's MTTKRP vs the oracle. vt=1: the right
+    node runs as a suffix scan of the transposed resident copy; vt=0: as the prefix scan (K2)."""
+    monkeypatch.setenv("PPALS_TRANSPOSED_COPY", str(vt))
     V, W = problem(lens, R, 1)
     t = pp.Tensor(ctx, lens, dtype).upload(V)
     s = pp.CP(ctx, t, R)
