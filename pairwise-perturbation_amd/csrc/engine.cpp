@@ -172,6 +172,8 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ops_.zero(sendbuf_, n);
     ops_.zero(gatherbuf_, n);
   }
+  if (const char *e = std::getenv("PPALS_COMM_SMALL_BYTES")) small_msg_bytes_ = std::atoll(e);
+  for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = (P_ == 1);
   build_tree(0, N_ - 1, -1);
   leaf_.assign(N_, -1);
   for (size_t k = 0; k < nodes_.size(); k++)
@@ -333,7 +335,7 @@ void CpEngine::get_factors(double *Wflat, double *gradWflat) {
       w += n;
     }
     if (g) {
-      if (P_ > 1 && grad_from_sweep_) {
+      if (P_ > 1 && grad_from_sweep_ && !grad_replicated_[i]) {
         // every rank holds only its own row block of grad_W: gather it
         const int64_t blk = block_rows(V_.glens[i], P_);
         ops_.pack_blocks(gradW_[i], V_.glens[i], V_.glens[i], R_, blk, P_, gatherbuf_);
@@ -356,7 +358,18 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
     ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
                         pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
     return;
+  } else if (i != 0 && (int64_t)sizeof(double) * s * R_ <= small_msg_bytes_) {
+    // latency regime (s x R is a few KB): ONE all-reduce of the partial rows, then every rank runs
+    // the whole (tiny) mode update redundantly — the reduce-scatter + all-gather pair below
+    // collapsed into a single collective, and the same fused launch as on one GPU.
+    if (ldm != s) throw std::runtime_error("ppals: partial MTTKRP must be contiguous");
+    comm_.allreduce_sum(const_cast<double *>(M), s * R_);
+    ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
+                        pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
+    grad_replicated_[i] = true;
+    return;
   } else {
+    grad_replicated_[i] = false;
     ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
     const int64_t blk = block_rows(s, P_);
     const int64_t r0 = blk * rank_;
@@ -421,9 +434,9 @@ double CpEngine::gradnorm() {
   if (!grad_from_sweep_) return init_gradnorm_;
   double h[MAX_ORDER];
   ops_.d2h(h, gradsq_, sizeof(double) * N_);
-  double s = 0;
-  for (int i = 0; i < N_; i++) s += h[i];
-  return std::sqrt(allreduce_scalar(s));
+  double part = 0, repl = 0;  // row-block partial sums vs. sums every rank already holds in full
+  for (int i = 0; i < N_; i++) (grad_replicated_[i] ? repl : part) += h[i];
+  return std::sqrt(allreduce_scalar(part) + repl);
 }
 
 double CpEngine::residual() {

@@ -120,6 +120,10 @@ class CpEngine {
   void *VT_ = nullptr;        // second resident layout of V: right-half modes fastest
   int vt_state_ = 0;          // 0 not tried, 1 built, -1 unavailable (disabled / no memory)
   void ensure_transposed();
+  // s x R partials up to this size use one all-reduce + redundant update instead of
+  // reduce-scatter + row-block update + all-gather (PPALS_COMM_SMALL_BYTES overrides)
+  int64_t small_msg_bytes_ = 1 << 20;
+  bool grad_replicated_[MAX_ORDER];
   int64_t maxs_ = 0, maxblk_ = 0;
   std::vector<Node> nodes_;
   std::vector<int> leaf_;  // node index of each leaf

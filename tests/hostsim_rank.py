@@ -55,8 +55,12 @@ def main():
     def relerr(a, b):
         return np.linalg.norm(a - b) / np.linalg.norm(b)
 
-    for lens, R, dtype in [([10, 7, 6, 5], 3, 1), ([9, 8, 7, 6], 4, 0), ([11, 6, 5], 2, 1),
-                           ([8, 4, 5, 4, 3, 3], 2, 1)]:
+    cases = [([10, 7, 6, 5], 3, 1), ([9, 8, 7, 6], 4, 0), ([11, 6, 5], 2, 1),
+             ([8, 4, 5, 4, 3, 3], 2, 1)]
+    for case_no, (lens, R, dtype) in enumerate(cases):
+        # alternate the two shard plans of a mode update: one all-reduce + redundant update
+        # (small s x R) vs reduce-scatter + row-block update + all-gather
+        os.environ["PPALS_COMM_SMALL_BYTES"] = "0" if case_no % 2 else str(1 << 20)
         Wt = O.init_factors(lens, R, 1234)
         V = O.build_V(Wt)
         W = O.init_factors(lens, R, 4321)
