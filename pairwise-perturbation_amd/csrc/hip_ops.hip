@@ -48,7 +48,8 @@ class HipOps : public Ops {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
     ncu_ = prop.multiProcessorCount;
-    // PPALS_SCAN_VARIANT=0 selects the generic (predicated) scan kernels for A/B measurements
+    // PPALS_SCAN_VARIANT: 2 (default) buffer-load suffix scan, 1 global-load fast kernels,
+    // 0 generic predicated kernels — for A/B measurements
     if (const char *v = getenv("PPALS_SCAN_VARIANT")) variant_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -340,7 +341,18 @@ class HipOps : public Ops {
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
-        if (al && variant_ >= 1 && M >= VEC) {
+#define LAUNCH_SUFFIX_BUF(NTv)                                                                   \
+  hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+        // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
+        const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
+        // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
+        // loses to the global-load kernel, so it is used for one n-tile / fp64 storage only)
+        if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8)) {
+          if (NT == 1) LAUNCH_SUFFIX_BUF(1);
+          else if (NT == 2) LAUNCH_SUFFIX_BUF(2);
+          else LAUNCH_SUFFIX_BUF(4);
+        } else if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_SUFFIX_FAST(1);
           else if (NT == 2) LAUNCH_SUFFIX_FAST(2);
           else LAUNCH_SUFFIX_FAST(4);
@@ -355,6 +367,7 @@ class HipOps : public Ops {
         }
 #undef LAUNCH_SUFFIX
 #undef LAUNCH_SUFFIX_FAST
+#undef LAUNCH_SUFFIX_BUF
         prof_end();
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
@@ -611,7 +624,7 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 1, force_jacobi_ = 0;
+  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;

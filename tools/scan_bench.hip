@@ -78,7 +78,8 @@ int main(int argc, char **argv) {
   const int64_t ncolgrp = (K + 63) / 64;
 
   std::vector<Variant> vs;
-  int ns8, per8, ns4, per4, ns16, per16;
+  int ns8, per8, ns4, per4, ns16, per16, ns12, per12;
+  suffix_cfg(12, ns12, per12);
   suffix_cfg(8, ns8, per8);
   suffix_cfg(4, ns4, per4);
   suffix_cfg(16, ns16, per16);
@@ -103,7 +104,9 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 1, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns8, per8), {}});
-    vs.push_back({"suffix fast xcd         x8", SUFFIX((k_scan_suffix_fast<float, 1, 2>), ns8, per8), {}});
+    vs.push_back({"suffix buf nt           x8", SUFFIX((k_scan_suffix_buf<float, 1, 1>), ns8, per8), {}});
+    vs.push_back({"suffix buf              x8", SUFFIX((k_scan_suffix_buf<float, 1, 0>), ns8, per8), {}});
+    vs.push_back({"suffix buf nt          x12", SUFFIX((k_scan_suffix_buf<float, 1, 1>), ns12, per12), {}});
     vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 1, 3>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x4", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns4, per4), {}});
     vs.push_back({"suffix fast nt         x16", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns16, per16), {}});
@@ -122,7 +125,7 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 2, 1>), ns8, per8), {}});
-    vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 2, 3>), ns8, per8), {}});
+    vs.push_back({"suffix buf nt           x8", SUFFIX((k_scan_suffix_buf<float, 2, 1>), ns8, per8), {}});
     vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 2, true, 4>), 1), {}});
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
     vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 2, 4>), 1), {}});
