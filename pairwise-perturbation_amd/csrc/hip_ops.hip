@@ -55,6 +55,8 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_top_eig_small,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
@@ -531,6 +533,12 @@ class HipOps : public Ops {
   // als_Tucker.cxx:20,402). SURVEY.md §2.1 K12 allows the vendor symmetric eigensolver here:
   // rocSOLVER dsyevd, resolved with dlopen on first use (only Tucker sessions ever load it).
   void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
+    if (J <= 64) {  // small modes: in-LDS Jacobi, one wave
+      size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64) + sizeof(int) * 64;
+      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(64), lds, st_, G, (int)J, rank, U);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     RocSolver &rs = rocsolver();
     double *D = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * (2 * J + 2));
     double *E = D + J;

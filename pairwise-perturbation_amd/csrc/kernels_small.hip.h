@@ -270,8 +270,7 @@ __device__ inline double hadamard_entry(const double *__restrict__ Gall, int N, 
 // for a symmetric matrix this equals the reference's V diag(1/sigma) U^T (common.cxx:717-722),
 // including its behaviour of NOT truncating tiny singular values.
 // LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
-__device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int *pq, int R,
-                                           double *Sinv_out) {
+__device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq, int R) {
   const int lane = threadIdx.x & 63;
   const int ldA = R + 1;
   for (int e = lane; e < R * R; e += 64) {
@@ -353,6 +352,13 @@ __device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int
       wave_sync();
     }
   }
+  wave_sync();
+}
+__device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int *pq, int R,
+                                           double *Sinv_out) {
+  const int lane = threadIdx.x & 63;
+  const int ldA = R + 1;
+  jacobi_eig_wave(A, Q, cs, pq, R);
   for (int e = lane; e < R * R; e += 64) {  // S^{-1}[i,j] = sum_k Q[i,k] Q[j,k] / w_k
     const int i = e % R, j = e / R;
     double acc = 0;
@@ -722,6 +728,33 @@ __global__ __launch_bounds__(256) void k_unfold_gram(const TV *__restrict__ X, i
     if (p < J && q < J) g[p + J * q] = acc[i];
   }
 }
+// Leading eigenvectors of a small symmetric matrix (J <= 64) entirely in LDS, ONE wave: the same
+// parallel-ordered Jacobi as the R x R solve, eigenvalues ranked descending. Used for the Tucker
+// eigen-step whenever the mode extent is small (no vendor library involved).
+__global__ __launch_bounds__(64) void k_top_eig_small(const double *__restrict__ G, int J, int rank,
+                                                      double *__restrict__ U) {
+  extern __shared__ double lds[];
+  const int ldA = J + 1;
+  double *A = lds;
+  double *Q = A + J * ldA;
+  double *cs = Q + J * ldA;
+  int *pq = (int *)(cs + 64);
+  const int lane = threadIdx.x;
+  for (int e = lane; e < J * J; e += 64) A[(e % J) * ldA + e / J] = G[e];
+  wave_sync();
+  jacobi_eig_wave(A, Q, cs, pq, J);
+  for (int k = lane; k < J; k += 64) {
+    const double wk = A[k * ldA + k];
+    int pos = 0;  // number of eigenvalues that come before k in descending order
+    for (int j = 0; j < J; j++) {
+      const double wj = A[j * ldA + j];
+      if (wj > wk || (wj == wk && j < k)) pos++;
+    }
+    if (pos < rank)
+      for (int i = 0; i < J; i++) U[i + (int64_t)J * pos] = Q[i * ldA + k];
+  }
+}
+
 // U[:,k] = Z[:, J-1-k] for k < rank (syevd returns ascending eigenvalues)
 __global__ void k_take_top(const double *__restrict__ Z, int64_t J, int rank,
                            double *__restrict__ U) {

@@ -1,6 +1,8 @@
 """GPU parity tests of the Tucker (HOOI) path: TTMc (K11), Gram of the unfolding + leading
 eigenvectors (K12/K13), hosvd, alsTucker_DT — against the fp64 oracle. Eigenvector signs are
 LAPACK-defined in the reference, so factors are compared as subspaces (projectors)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,3 +80,18 @@ def test_hosvd_and_dt_sweeps(pp, ctx, lens, ranks, dtype, tmp_path):
     for a, b in zip(r1, r2):
         assert a[1] == b[1]
         assert abs(a[5] - b[5]) < (1e-4 if dtype == 0 else 1e-8) * np.linalg.norm(V)
+
+
+@pytest.mark.skipif(os.environ.get("PPALS_TEST_ROCSOLVER", "0") != "1",
+                    reason="mode extents > 64 use rocSOLVER dsyevd, whose first call costs minutes "
+                           "of one-time initialisation on a fresh box; set PPALS_TEST_ROCSOLVER=1")
+def test_large_mode_uses_vendor_eig(pp, ctx):
+    lens, ranks = [72, 10, 9], [4, 3, 3]
+    V = O.fill_uniform(int(np.prod(lens)), 8, lo=0.5, hi=1.0).reshape(lens, order="F")
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.hosvd()
+    W, core = s.get_factors()
+    W_ref, core_ref = O.hosvd(V, ranks)
+    for a, b in zip(W, W_ref):
+        assert np.linalg.norm(proj(a) - proj(b)) < 1e-7
