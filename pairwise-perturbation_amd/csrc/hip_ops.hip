@@ -202,6 +202,17 @@ class HipOps : public Ops {
     }
     return p;
   }
+  void unpack_shards(const void *stage, int dt, int64_t s0, int64_t rest, int64_t blk, int P,
+                     int64_t chunk_bytes, void *full) override {
+    const int g = grid_for(s0 * rest, 256, 16384);
+    if (dt == F32)
+      hipLaunchKernelGGL(k_unpack_shards<float>, dim3(g), dim3(256), 0, st_, (const char *)stage,
+                         s0, rest, blk, P, chunk_bytes, (float *)full);
+    else
+      hipLaunchKernelGGL(k_unpack_shards<double>, dim3(g), dim3(256), 0, st_, (const char *)stage,
+                         s0, rest, blk, P, chunk_bytes, (double *)full);
+    HIP_CHECK(hipGetLastError());
+  }
   void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) override {
     const int64_t nb = ((rows + 63) / 64) * ((cols + 63) / 64);
     if (nb > 0x7fffffff) throw std::runtime_error("ppals: transpose grid too large");

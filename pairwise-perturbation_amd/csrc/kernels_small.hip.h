@@ -129,6 +129,20 @@ __global__ __launch_bounds__(256) void k_transpose(const TV *__restrict__ src, i
 }
 
 template <typename TV>
+__global__ void k_unpack_shards(const char *__restrict__ stage, int64_t s0, int64_t rest,
+                                int64_t blk, int P, int64_t chunk_bytes, TV *__restrict__ full) {
+  const int64_t total = s0 * rest;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = e % s0, c = e / s0;
+    const int p = (int)(a / blk);
+    const int64_t lp = min(blk, s0 - (int64_t)p * blk);
+    const TV *src = reinterpret_cast<const TV *>(stage + (int64_t)p * chunk_bytes);
+    full[e] = src[(a - (int64_t)p * blk) + lp * c];
+  }
+}
+
+template <typename TV>
 __global__ void k_convert_rows(TV *__restrict__ dst, const double *__restrict__ src, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (int64_t)gridDim.x * blockDim.x)

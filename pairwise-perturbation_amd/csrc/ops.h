@@ -62,6 +62,11 @@ class Ops {
   // dst[c + cols*r] = src[r + rows*c] (same element type dt): builds the second resident layout
   // of the tensor (right-half modes fastest) so that BOTH first-level tree nodes are suffix scans
   virtual void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) = 0;
+  // full[a + s0*c] = stage_p[(a - p*blk) + l_p*c] for the rank p that owns row a (l_p rows each,
+  // element type dt); stage_p starts at byte offset p*chunk_bytes. Re-assembles the leading-mode
+  // shards of a tensor after an all-gather (Tucker HOSVD of the sharded mode).
+  virtual void unpack_shards(const void *stage, int dt, int64_t s0, int64_t rest, int64_t blk,
+                             int P, int64_t chunk_bytes, void *full) = 0;
   // alloc that returns nullptr instead of throwing when the device is out of memory
   virtual void *try_alloc(size_t bytes) { return alloc(bytes); }
 

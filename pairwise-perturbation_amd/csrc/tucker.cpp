@@ -3,6 +3,10 @@
 //   alsTucker_DT       als_Tucker.cxx:240-424  -> sweep_dt / run_dt
 //   hosvd              als_Tucker.cxx:12-70    -> hosvd
 //   TTMc               als_Tucker.cxx:76-110   -> ttmc_chain
+// Multi-GPU: V is block-partitioned along mode 0, factors are replicated. Every
+// contraction over mode 0 uses the local rows of W_0 and yields a PARTIAL sum that stays partial
+// down to the leaf tensor Y_i (TTMc is linear), where it is all-reduced (i != 0) or its rows are
+// all-gathered (i = 0); Gram + eigenvectors are then computed redundantly on every rank.
 // Order generalisation as for CP: a node is "first level" iff its parent is the root, which is
 // the reference's length test for N = 4,6,7,8 and defines N = 3 (BASELINE config 5).
 #include "tucker.h"
@@ -23,8 +27,8 @@ static double now() {
 
 TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int *ranks)
     : ops_(ops), comm_(comm), V_(V), N_(V.order) {
-  if (comm.size() > 1)
-    throw std::runtime_error("ppals: the Tucker engine is single-GPU in this version");
+  P_ = comm.size();
+  rank_ = comm.rank();
   int64_t maxs = 0;
   for (int i = 0; i < N_; i++) {
     if (ranks[i] <= 0 || ranks[i] > V_.glens[i])
@@ -61,6 +65,8 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(Yend_);
   ops_.free(G_);
   ops_.free(scal_);
+  ops_.free(Yfull_);
+  ops_.free(gather_);
 }
 
 void TuckerEngine::build_tree(int lo, int hi, int parent) {
@@ -85,25 +91,24 @@ void TuckerEngine::build_tree(int lo, int hi, int parent) {
 // a node [lo,hi] keeps modes lo..hi at full extent; every other mode is already contracted to rank
 int64_t TuckerEngine::node_elems(const Node &n) const {
   int64_t e = 1;
-  for (int m = 0; m < N_; m++) e *= (m >= n.lo && m <= n.hi) ? V_.glens[m] : r_[m];
+  for (int m = 0; m < N_; m++) e *= (m >= n.lo && m <= n.hi) ? ext(m) : r_[m];
   return e;
 }
 
 void TuckerEngine::compute_node(int idx) {
   Node &n = nodes_[idx];
   if (n.valid) return;
-  // dims of the source tensor
   std::vector<int64_t> dims(N_);
   const void *src;
   int dt;
   if (n.parent < 0) {
-    for (int m = 0; m < N_; m++) dims[m] = V_.glens[m];
+    for (int m = 0; m < N_; m++) dims[m] = ext(m);
     src = V_.data;
     dt = V_.dtype;
   } else {
     compute_node(n.parent);
     const Node &p = nodes_[n.parent];
-    for (int m = 0; m < N_; m++) dims[m] = (m >= p.lo && m <= p.hi) ? V_.glens[m] : r_[m];
+    for (int m = 0; m < N_; m++) dims[m] = (m >= p.lo && m <= p.hi) ? ext(m) : r_[m];
     src = p.buf;
     dt = F64;
   }
@@ -111,27 +116,37 @@ void TuckerEngine::compute_node(int idx) {
   double *tmp = nullptr;
   const void *cur = src;
   int cur_dt = dt;
+  // the sharded leaf of mode 0 is written with leading dimension blk (= rows per rank) so that it
+  // is directly one block of the all-gather buffer (rows beyond the local extent stay zero)
+  const bool leaf0_blocked = (P_ > 1 && n.lo == 0 && n.hi == 0);
+  const int64_t blk = block_rows(V_.glens[0], P_);
   for (int m = n.slo; m <= n.shi; m++) {
     int64_t L = 1, T = 1;
     for (int q = 0; q < m; q++) L *= dims[q];
     for (int q = m + 1; q < N_; q++) T *= dims[q];
-    const int64_t out_elems = L * r_[m] * T;
+    const bool last = (m == n.shi);
+    const int64_t Lout = (last && leaf0_blocked) ? blk : L;
+    const int64_t out_elems = Lout * r_[m] * T;
     double *dst;
-    if (m == n.shi) {
+    if (last) {
       if (n.cap < out_elems) {
         ops_.free(n.buf);
         n.buf = (double *)ops_.alloc(sizeof(double) * out_elems);
         n.cap = out_elems;
       }
       dst = n.buf;
+      if (leaf0_blocked) ops_.zero(dst, sizeof(double) * out_elems);
     } else {
       dst = (double *)ops_.alloc(sizeof(double) * out_elems);
     }
-    ops_.ttm_keep(cur, cur_dt, L, dims[m], T, W_[m], V_.glens[m], r_[m], dst);
-    if (tmp) {
-      ops_.free(tmp);  // synchronises before freeing
-    }
-    tmp = (m == n.shi) ? nullptr : dst;
+    FactorRef f;
+    f.ptr = wptr(m);
+    f.rows = dims[m];
+    f.ld = V_.glens[m];
+    // out[l + Lout*(k + r*t)]: the mode product that keeps the mode in place (als_Tucker.cxx:224)
+    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, Lout * r_[m], Lout);
+    if (tmp) ops_.free(tmp);  // synchronises before freeing
+    tmp = last ? nullptr : dst;
     cur = dst;
     cur_dt = F64;
     dims[m] = r_[m];
@@ -139,10 +154,37 @@ void TuckerEngine::compute_node(int idx) {
   n.valid = true;
 }
 
+// Make a leaf tensor complete on every rank. i == 0: the rows live on their owners -> all-gather
+// of the [blk x rest] blocks, re-assembled to [s0 x rest]. i != 0: partial sums -> all-reduce.
+double *TuckerEngine::complete_leaf(int i, double *Yloc, int64_t elems_local) {
+  if (P_ == 1) return Yloc;
+  if (i != 0) {
+    comm_.allreduce_sum(Yloc, elems_local);
+    return Yloc;
+  }
+  const int64_t s0 = V_.glens[0], blk = block_rows(s0, P_);
+  int64_t rest = 1;
+  for (int m = 1; m < N_; m++) rest *= r_[m];
+  if (gather_cap_ < blk * rest * P_) {
+    ops_.free(gather_);
+    gather_ = (double *)ops_.alloc(sizeof(double) * blk * rest * P_);
+    gather_cap_ = blk * rest * P_;
+  }
+  if (yfull_cap_ < s0 * rest) {
+    ops_.free(Yfull_);
+    Yfull_ = (double *)ops_.alloc(sizeof(double) * s0 * rest);
+    yfull_cap_ = s0 * rest;
+  }
+  ops_.d2d(gather_ + (size_t)rank_ * blk * rest, Yloc, sizeof(double) * blk * rest);
+  comm_.allgather(gather_ + (size_t)rank_ * blk * rest, gather_, blk * rest);
+  ops_.unpack_blocks(gather_, s0, s0, (int)rest, blk, P_, Yfull_);
+  return Yfull_;
+}
+
 // TTMc (als_Tucker.cxx:76-110): chain of mode products, skipping `skip`
 double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
   std::vector<int64_t> dims(N_);
-  for (int m = 0; m < N_; m++) dims[m] = V_.glens[m];
+  for (int m = 0; m < N_; m++) dims[m] = ext(m);
   const void *cur = V_.data;
   int cur_dt = V_.dtype;
   double *prev = nullptr;
@@ -152,7 +194,7 @@ double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
     for (int q = 0; q < m; q++) L *= dims[q];
     for (int q = m + 1; q < N_; q++) T *= dims[q];
     double *dst = (double *)ops_.alloc(sizeof(double) * L * r_[m] * T);
-    ops_.ttm_keep(cur, cur_dt, L, dims[m], T, W_[m], V_.glens[m], r_[m], dst);
+    ops_.ttm_keep(cur, cur_dt, L, dims[m], T, wptr(m), V_.glens[m], r_[m], dst);
     if (prev) ops_.free(prev);
     prev = dst;
     cur = dst;
@@ -168,6 +210,8 @@ double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
 int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
   int64_t e;
   double *Y = ttmc_chain(skip, &e);
+  // sharded: skip == 0 returns the local rows, every other result is summed over the ranks
+  if (P_ > 1 && skip != 0) comm_.allreduce_sum(Y, e);
   if (Yhost) ops_.d2h(Yhost, Y, sizeof(double) * e);
   ops_.free(Y);
   return e;
@@ -176,6 +220,7 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
 void TuckerEngine::compute_core_full() {
   int64_t e;
   double *Y = ttmc_chain(-1, &e);
+  if (P_ > 1) comm_.allreduce_sum(Y, ncore_);
   ops_.d2d(core_, Y, sizeof(double) * ncore_);
   ops_.free(Y);
 }
@@ -205,9 +250,29 @@ void TuckerEngine::get_factors(double *Wflat, double *core) {
 void TuckerEngine::hosvd() {
   for (int i = 0; i < N_; i++) {
     int64_t L = 1, T = 1;
-    for (int q = 0; q < i; q++) L *= V_.glens[q];
-    for (int q = i + 1; q < N_; q++) T *= V_.glens[q];
-    ops_.unfold_gram(V_.data, V_.dtype, L, V_.glens[i], T, G_);
+    for (int q = 0; q < i; q++) L *= ext(q);
+    for (int q = i + 1; q < N_; q++) T *= ext(q);
+    if (P_ > 1 && i == 0) {
+      // the Gram of the sharded mode needs every pair of rows: gather the shards once (needs room
+      // for two extra copies of the tensor; HOSVD is a one-off initialisation)
+      const int64_t s0 = V_.glens[0], blk = block_rows(s0, P_);
+      const size_t esz = dtype_size(V_.dtype);
+      const int64_t chunk_bytes = ((blk * T * (int64_t)esz + 7) / 8) * 8;
+      char *stage = (char *)ops_.alloc((size_t)chunk_bytes * P_);
+      void *full = ops_.alloc((size_t)s0 * T * esz);
+      ops_.zero(stage, (size_t)chunk_bytes * P_);
+      ops_.d2d(stage + (size_t)rank_ * chunk_bytes, V_.data, (size_t)V_.nloc * esz);
+      comm_.allgather((const double *)(stage + (size_t)rank_ * chunk_bytes), (double *)stage,
+                      chunk_bytes / 8);
+      ops_.unpack_shards(stage, V_.dtype, s0, T, blk, P_, chunk_bytes, full);
+      ops_.unfold_gram(full, V_.dtype, 1, s0, T, G_);
+      ops_.sync();
+      ops_.free(stage);
+      ops_.free(full);
+    } else {
+      ops_.unfold_gram(V_.data, V_.dtype, L, V_.glens[i], T, G_);
+      if (P_ > 1) comm_.allreduce_sum(G_, V_.glens[i] * V_.glens[i]);
+    }
     ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
   }
   compute_core_full();
@@ -223,8 +288,9 @@ void TuckerEngine::sweep_dt() {
     int64_t L = 1, T = 1;
     for (int q = 0; q < i; q++) L *= r_[q];
     for (int q = i + 1; q < N_; q++) T *= r_[q];
-    if (i == N_ - 1) ops_.d2d(Yend_, lf.buf, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
-    ops_.unfold_gram(lf.buf, F64, L, V_.glens[i], T, G_);                   // K12
+    double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
+    if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
+    ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);                   // K12
     ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
   }
   // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408)
@@ -254,12 +320,12 @@ double TuckerEngine::residual() {
     for (int q = m + 1; q < N_; q++) T *= dims[q];
     // expansion: out[l, a, t] = sum_k cur[l,k,t] * W_m[a,k]  ==  ttm_keep with W^T (J=r, K=s)
     // W^T as a column-major r x s matrix is W (s x r, ld = s) read with swapped strides; build it.
-    const int64_t s = V_.glens[m];
+    const int64_t sg = V_.glens[m], s = ext(m), r0 = (m == 0 ? V_.row0 : 0);
     const int rk = r_[m];
-    std::vector<double> Wh((size_t)s * rk), WT((size_t)s * rk);
-    ops_.d2h(Wh.data(), W_[m], sizeof(double) * s * rk);
-    for (int64_t a = 0; a < s; a++)
-      for (int k = 0; k < rk; k++) WT[k + (size_t)rk * a] = Wh[a + s * k];
+    std::vector<double> Wh((size_t)sg * rk), WT((size_t)s * rk);
+    ops_.d2h(Wh.data(), W_[m], sizeof(double) * sg * rk);
+    for (int64_t a = 0; a < s; a++)  // local rows of the sharded mode only
+      for (int k = 0; k < rk; k++) WT[k + (size_t)rk * a] = Wh[(a + r0) + sg * k];
     double *WTd = (double *)ops_.alloc(sizeof(double) * s * rk);
     ops_.h2d(WTd, WT.data(), sizeof(double) * s * rk);
     double *dst = (double *)ops_.alloc(sizeof(double) * L * s * T);
@@ -271,8 +337,9 @@ double TuckerEngine::residual() {
     dims[m] = s;
   }
   int64_t M = 1;
-  for (int m = 0; m < N_ - 1; m++) M *= V_.glens[m];
+  for (int m = 0; m < N_ - 1; m++) M *= ext(m);
   ops_.residual_sq(V_.data, V_.dtype, M, V_.glens[N_ - 1], cur, W_[N_ - 1], r_[N_ - 1], scal_ + 2);
+  if (P_ > 1) comm_.allreduce_sum(scal_ + 2, 1);
   double h = 0;
   ops_.d2h(&h, scal_ + 2, sizeof(double));
   if (prev) ops_.free(prev);
@@ -282,11 +349,12 @@ double TuckerEngine::residual() {
 int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
-  if (!o.csv_path.empty()) {
+  if (rank_ == 0 && !o.csv_path.empty()) {
     csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
     pcsv = &csv;
     if (!o.bench) csv << "[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]\n";
   }
+  const bool talk = o.verbose && rank_ == 0;
   double st_time = now();
   ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);  // Tensor<> core_prev(core)
   double diffnorm = 1000, diffnorm_V = 1000;
@@ -301,7 +369,7 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
       st_time += now() - st_time1;
       const double dtime = now() - st_time;
       if (!o.bench) {
-        if (o.verbose) {
+        if (talk) {
           std::cout.precision(13);
           std::cout << "  [dim]=  " << V_.glens[0] << "  [iter]=  " << iter << "  [diffnorm]  "
                     << diffnorm << "  [tol]  " << o.tol << "  [pp_update]  " << 0 << "  [diffV]  "
@@ -313,17 +381,17 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
           if (iter % 100 == 0 && iter != 0) (*pcsv) << std::endl;
         }
       } else {
-        if (o.verbose) std::cout << "  [dimension tree step time]  " << dtime << "\n";
+        if (talk) std::cout << "  [dimension tree step time]  " << dtime << "\n";
         if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
       }
       if (diffnorm < o.tol || now() - st_time > o.timelimit) break;
       ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
     }
     sweep_dt();
-    if (iter % 10 == 0 && o.verbose) printf(".");
+    if (iter % 10 == 0 && talk) printf(".");
   }
   ops_.sync();
-  if (o.verbose) {
+  if (talk) {
     printf("\nIter = %d Final Diff norm %E \n", iter, diffnorm);
     printf("tf took %lf seconds\n", now() - st_time);
   }

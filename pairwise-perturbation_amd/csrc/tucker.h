@@ -29,6 +29,11 @@ class TuckerEngine {
   // dims of a node's tensor: ranks on the contracted modes, full extent elsewhere
   void compute_node(int idx);
   double *ttmc_chain(int skip, int64_t *elems);  // returns a device buffer the caller frees
+  int64_t ext(int m) const { return m == 0 ? V_.llens[0] : V_.glens[m]; }
+  const double *wptr(int m) const { return W_[m] + (m == 0 ? V_.row0 : 0); }
+  // leaf tensor Y_i complete on every rank (all-gather of the leading-mode rows for i = 0,
+  // all-reduce of the partial sums otherwise); returns the buffer holding it
+  double *complete_leaf(int i, double *Yloc, int64_t elems_local);
   void compute_core_full();
   double core_norm();
   double residual();
@@ -45,6 +50,9 @@ class TuckerEngine {
   std::vector<Node> nodes_;
   std::vector<int> leaf_;
   std::vector<char> contracted_;  // scratch
+  int P_ = 1, rank_ = 0;
+  double *Yfull_ = nullptr, *gather_ = nullptr;
+  int64_t yfull_cap_ = 0, gather_cap_ = 0;
 };
 
 }  // namespace ppals

@@ -122,6 +122,16 @@ class HostOps : public Ops {
       for (int64_t a = 0; a < l0; a++) st(V, dt, a + l0 * c, host_full[row0 + a + g0 * c]);
   }
 
+  void unpack_shards(const void *stage, int dt, int64_t s0, int64_t rest, int64_t blk, int P,
+                     int64_t chunk_bytes, void *full) override {
+    for (int64_t c = 0; c < rest; c++)
+      for (int64_t a = 0; a < s0; a++) {
+        int p = (int)(a / blk);
+        int64_t lp = std::min(blk, s0 - (int64_t)p * blk);
+        const char *src = (const char *)stage + (int64_t)p * chunk_bytes;
+        st(full, dt, a + s0 * c, ld(src, dt, (a - (int64_t)p * blk) + lp * c));
+      }
+  }
   void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) override {
     for (int64_t c = 0; c < cols; c++)
       for (int64_t r = 0; r < rows; r++) st(dst, dt, c + cols * r, ld(src, dt, r + rows * c));

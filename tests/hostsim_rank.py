@@ -104,6 +104,42 @@ def main():
                 assert any(r[4] == 1 for r in r2)
         s.close()
         t.close()
+    # ---- Tucker (HOOI), sharded: hosvd + the DT driver against the unsharded oracle
+    def proj(U):
+        return U @ U.T
+
+    for lens, ranks, dtype in [([9, 8, 7], [3, 2, 3], 1), ([7, 6, 5, 6], [2, 3, 2, 2], 1),
+                               ([10, 6, 8], [3, 3, 2], 0)]:
+        V = O.fill_uniform(int(np.prod(lens)), 21, lo=0.5, hi=1.0).reshape(lens, order="F")
+        t = pp.Tensor(ctx, lens, dtype).upload(V)
+        tk = pp.Tucker(ctx, t, ranks)
+        tk.hosvd()
+        W, core = tk.get_factors()
+        W_ref, core_ref = O.hosvd(V, ranks)
+        tol = 1e-8 if dtype == 1 else 1e-4
+        for a, b in zip(W, W_ref):
+            assert np.linalg.norm(proj(a) - proj(b)) < tol * 10
+        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < tol * np.linalg.norm(core_ref)
+        tk.set_factors(W_ref)
+        csv = f"/tmp/ppals_gloo_tk_{os.getpid()}.csv"
+        _, it_ref, W2_ref, core2_ref = O.als_tucker_dt(V, W_ref, core_ref, tol=0.0, maxiter=3,
+                                                       csv=csv + ".ref", resprint=1)
+        rc, it = tk.run_dt(tol=0.0, maxiter=3, csv=csv if rank == 0 else None, resprint=1)
+        W2, core2 = tk.get_factors()
+        assert it == it_ref
+        for a, b in zip(W2, W2_ref):
+            assert np.linalg.norm(proj(a) - proj(b)) < tol * 100
+        assert abs(np.linalg.norm(core2) - np.linalg.norm(core2_ref)) < tol * 10 * np.linalg.norm(core2_ref)
+        if rank == 0:
+            _, r1 = O.read_csv(csv + ".ref")
+            _, r2 = O.read_csv(csv)
+            assert len(r1) == len(r2)
+            for a, b in zip(r1, r2):
+                assert a[1] == b[1] and abs(a[5] - b[5]) < (1e-6 if dtype == 1 else 1e-3) * np.linalg.norm(V)
+        for skip in (-1, 1):
+            assert np.linalg.norm(tk.ttmc(skip) - O.ttmc(V, W2, skip)) < tol * 10 * np.linalg.norm(V)
+        tk.close()
+        t.close()
     assert calls["rs"] > 0 and calls["ag"] > 0 and calls["ar"] > 0
     dist.barrier()
     dist.destroy_process_group()
