@@ -116,6 +116,7 @@ typedef struct {
   const char *csv_path; /* NULL: no CSV; the file is opened, written and closed by the callee */
   int csv_append;    /* bench mode appends to an existing file */
   int verbose;       /* 1: console output identical to the reference's rank-0 cout/printf */
+  double update_percentage; /* -pp 2 only (-update_percentage_pp): fraction of modes per sweep */
 } ppals_cp_opts;
 
 /* alsCP_DT (als_CP.h:30-32, als_CP.cxx:127-320). Returns 1 if it stopped before maxiter+1
@@ -123,6 +124,8 @@ typedef struct {
 int ppals_cp_dt(ppals_cp *s, const ppals_cp_opts *o, int *iters);
 /* alsCP_PP (als_CP.h:105-108, als_CP.cxx:1082-1137) */
 int ppals_cp_pp(ppals_cp *s, const ppals_cp_opts *o, int *iters);
+/* alsCP_PP_partupdate (als_CP.h:117-122, als_CP.cxx:1146-1207): `-pp 2` */
+int ppals_cp_pp_partupdate(ppals_cp *s, const ppals_cp_opts *o, int *iters);
 
 /* ---- Tucker sessions (als_Tucker.h) ---- */
 int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out);

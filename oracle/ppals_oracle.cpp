@@ -663,6 +663,100 @@ double cp_pp_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double r
   return diffnorm_V;
 }
 
+// alsCP_PP_partupdate_sub (als_CP.cxx:852-1073), bench == false: PP phase that updates only the
+// `update_size` modes with the largest relative MTTKRP perturbation ||dM_i|| / ||M_i|| per sweep
+// and propagates each update to the other modes' dM through the pair operators.
+double cp_pp_partupdate_sub(CPRun &c, vector<vector<double>> &dW, double tol_init,
+                            double ratio_step, double update_percentage, double &projnorm,
+                            int &iter) {
+  int N = c.N, R = c.R;
+  int init_iter = iter;
+  double diffnorm_V = 1000;
+  vector<vector<double>> W_init(N), dM(N), Mm(N);
+  for (int i = 0; i < N; i++) {
+    dM[i].assign((size_t)c.F.lens[i] * R, 0.0);
+    Mm[i].assign((size_t)c.F.lens[i] * R, 0.0);
+  }
+  vector<double> W_relative_perturbe(N, 0.);
+  PPMap pp;
+  pp.N = N;
+  pp.R = R;
+  pp.V = c.V;
+  pp.F = &c.F;
+  vector<double> S((size_t)R * R);
+  int update_size = (int)(N * update_percentage);
+  for (; iter <= c.maxiter; iter++) {
+    int num_dw_break = 0;
+    for (int i = 0; i < N; i++) {
+      i64 n = c.F.lens[i] * R;
+      double norm_dW = fro(dW[i].data(), n), norm_W = fro(c.F.W[i], n);
+      if (std::fabs(norm_dW / norm_W) > tol_init) num_dw_break++;
+    }
+    if ((iter - init_iter) % 15 == 0 || num_dw_break > 0) {
+      if (num_dw_break > 0 || iter != init_iter) return diffnorm_V;
+      for (int j = 0; j < N; j++) {
+        W_init[j].assign(c.F.W[j], c.F.W[j] + c.F.lens[j] * R);
+        std::fill(dW[j].begin(), dW[j].end(), 0.0);
+      }
+      pp.cache.clear();
+      for (int ii = 0; ii < N; ii++)
+        for (int jj = ii + 1; jj < N; jj++) pp.get(all_but(N, ii, jj));
+      for (int ii = 0; ii < N; ii++) pp.get(all_but(N, ii));
+    }
+    if (iter % c.resprint == 0 || iter == c.maxiter || iter == init_iter) {
+      if (print_block(c, iter, 1, projnorm, diffnorm_V)) break;
+    }
+    // sort_indexes (als_CP.cxx:835-843): descending by W_relative_perturbe, ties keep index order
+    vector<int> idx(N);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+      return W_relative_perturbe[a] > W_relative_perturbe[b];
+    });
+    if (c.log.verbose) std::cout << "new round" << std::endl;
+    for (int t = 0; t < update_size; t++) {
+      int i = idx[t];
+      if (c.log.verbose) std::cout << i << std::endl;
+      i64 si = c.F.lens[i];
+      const Ten &M0 = pp.get(all_but(N, i));
+      for (i64 e = 0; e < si * R; e++) Mm[i][e] = M0.d[e] + dM[i][e];
+      gram_hadamard(c.F, i, c.lambda != 0 ? c.lambda : 0.0, S.data());
+      gradient(si, R, Mm[i].data(), c.F.W[i], S.data(), c.G.W[i]);
+      svd_solve(si, R, Mm[i].data(), S.data(), c.F.W[i]);
+      for (i64 e = 0; e < si * R; e++) dW[i][e] = ratio_step * (c.F.W[i][e] - W_init[i][e]);
+      if (ratio_step != 1.)
+        for (i64 e = 0; e < si * R; e++) c.F.W[i][e] = W_init[i][e] + dW[i][e];
+      std::fill(dM[i].begin(), dM[i].end(), 0.0);
+      // propagate the change to the other modes (als_CP.cxx:1036-1053)
+      for (int ii = 0; ii < N; ii++) {
+        if (ii == i) continue;
+        const Ten &T = pp.get(all_but(N, std::min(i, ii), std::max(i, ii)));
+        i64 sj = c.F.lens[ii];
+        if (ii < i) {  // T[ii, i, r]: dM[ii][x,r] += sum_y T[x,y,r] dW[i][y,r]
+          for (int r = 0; r < R; r++)
+            for (i64 y = 0; y < si; y++) {
+              double w = dW[i][y + si * r];
+              for (i64 x = 0; x < sj; x++) dM[ii][x + sj * r] += T.d[x + sj * (y + si * r)] * w;
+            }
+        } else {  // T[i, ii, r]: dM[ii][y,r] += sum_x T[x,y,r] dW[i][x,r]
+          for (int r = 0; r < R; r++)
+            for (i64 y = 0; y < sj; y++) {
+              double acc = 0;
+              for (i64 x = 0; x < si; x++) acc += T.d[x + si * (y + sj * r)] * dW[i][x + si * r];
+              dM[ii][y + sj * r] += acc;
+            }
+        }
+      }
+    }
+    for (int i = 0; i < N; i++) {
+      i64 n = c.F.lens[i] * R;
+      W_relative_perturbe[i] = fro(dM[i].data(), n) / fro(Mm[i].data(), n);
+    }
+    normalize(c.F);
+    if (iter % 10 == 0 && c.log.verbose) printf(".");
+  }
+  return diffnorm_V;
+}
+
 // ---------------------------------------------------------------- Tucker helpers
 // unroll_tensor_contraction (common.cxx:205-223): G[p,q] = sum_rest T[..p..] T[..q..]
 vector<double> unfold_gram(const Ten &T, int pos) {
@@ -965,6 +1059,42 @@ int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wf
   if (verbose) {
     printf("\nIter = %d Final grad norm %E \n", iter, gradnorm);
     printf("tf took %lf seconds\n", now() - c.st_time);
+  }
+  if (c.log.has_csv) c.log.csv.close();
+  if (iters) *iters = iter;
+  return iter == maxiter + 1 ? 0 : 1;
+}
+
+// alsCP_PP_partupdate (als_CP.cxx:1146-1207), bench == false
+int ppo_als_cp_pp_partupdate(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                             double *gradWflat, double tol, double tol_init, double timelimit,
+                             int maxiter, double lambda, double ratio_step,
+                             double update_percentage, const char *csv_path, int resprint,
+                             int verbose, int *iters) {
+  CPRun c;
+  Ten Vt = view_of(N, lens, V);
+  c.V = &Vt;
+  c.F = factors(N, lens, R, Wflat);
+  c.G = factors(N, lens, R, gradWflat);
+  c.N = N;
+  c.R = R;
+  c.tol = tol;
+  c.timelimit = timelimit;
+  c.lambda = lambda;
+  c.maxiter = maxiter;
+  c.resprint = resprint;
+  c.log.verbose = verbose != 0;
+  c.log.open(csv_path);
+  c.log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
+  c.st_time = now();
+  int iter = 0;
+  double gradnorm = 10.;
+  vector<vector<double>> dW(N);
+  for (int j = 0; j < N; j++) dW[j].assign((size_t)lens[j] * R, 0.0);
+  while (gradnorm > tol && iter <= maxiter) {
+    cp_dt_sub(c, dW, tol_init, gradnorm, iter);
+    cp_pp_partupdate_sub(c, dW, tol_init, ratio_step, update_percentage, gradnorm, iter);
+    if (now() - c.st_time > timelimit) break;
   }
   if (c.log.has_csv) c.log.csv.close();
   if (iters) *iters = iter;

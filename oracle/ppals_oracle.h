@@ -62,6 +62,12 @@ int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wf
                   double lambda, double ratio_step, const char *csv_path, int resprint, int verbose,
                   int *iters); /* als_CP.cxx:1082 */
 
+int ppo_als_cp_pp_partupdate(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                             double *gradWflat, double tol, double tol_init, double timelimit,
+                             int maxiter, double lambda, double ratio_step,
+                             double update_percentage, const char *csv_path, int resprint,
+                             int verbose, int *iters); /* als_CP.cxx:1146 */
+
 /* Tucker. ranks[N]; Wflat holds lens[i] x ranks[i] matrices; core is prod(ranks) */
 void ppo_ttmc(int N, const int64_t *lens, const int *ranks, const double *V, const double *Wflat,
               int skip, double *Y);                                            /* als_Tucker.cxx:76 */

@@ -149,6 +149,8 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   Wprev_.assign(N_, nullptr);
   Winit_.assign(N_, nullptr);
   dW_.assign(N_, nullptr);
+  dM_.assign(N_, nullptr);
+  Mm_.assign(N_, nullptr);
   for (int i = 0; i < N_; i++) {
     size_t n = (size_t)V_.glens[i] * R_ * sizeof(double);
     W_[i] = (double *)ops_.alloc(n);
@@ -190,6 +192,8 @@ CpEngine::~CpEngine() {
   for (auto p : Wprev_) ops_.free(p);
   for (auto p : Winit_) ops_.free(p);
   for (auto p : dW_) ops_.free(p);
+  for (auto p : dM_) ops_.free(p);
+  for (auto p : Mm_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
   pp_clear();
   ops_.free(G_);
@@ -762,7 +766,83 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
   return diffV;
 }
 
-int CpEngine::run_pp(const CpOpts &o, int *iters) {
+// alsCP_PP_partupdate_sub (als_CP.cxx:852-1073): PP phase that updates only the modes with the
+// largest relative MTTKRP perturbation ||dM_i|| / ||M_i|| and propagates every update to the other
+// modes' dM through the cached pair operators. Single GPU (the norms of partial dM are not global).
+double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
+                                   std::ofstream *csv) {
+  const int init_iter = iter;
+  double diffV = 1000;
+  std::vector<double> nd, nw, relpert(N_, 0.0);
+  for (int i = 0; i < N_; i++) {
+    size_t n = sizeof(double) * V_.glens[i] * R_;
+    ops_.zero(dM_[i], n);
+    ops_.zero(Mm_[i], n);
+  }
+  const int update_size = (int)(N_ * o.update_percentage);
+  for (; iter <= o.maxiter; iter++) {
+    int num_dw_break = 0;
+    read_norms(false, nd, nw);
+    for (int i = 0; i < N_; i++)
+      if (std::fabs(nd[i] / nw[i]) > o.tol_init) num_dw_break++;
+    if ((iter - init_iter) % 15 == 0 || num_dw_break > 0) {
+      if (num_dw_break > 0 || iter != init_iter) return diffV;
+      for (int j = 0; j < N_; j++) {
+        size_t n = sizeof(double) * V_.glens[j] * R_;
+        ops_.d2d(Winit_[j], W_[j], n);
+        ops_.zero(dW_[j], n);
+      }
+      pp_build_all();
+    }
+    if (iter % o.resprint == 0 || iter == o.maxiter || iter == init_iter) {
+      if (print_block(o, iter, 1, projnorm, diffV, csv)) break;
+    }
+    // sort_indexes (als_CP.cxx:835-843): descending, ties keep index order
+    std::vector<int> idx(N_);
+    for (int i = 0; i < N_; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return relpert[a] > relpert[b]; });
+    if (rank_ == 0 && o.verbose) std::cout << "new round" << std::endl;
+    for (int t = 0; t < update_size; t++) {
+      const int i = idx[t];
+      if (rank_ == 0 && o.verbose) std::cout << i << std::endl;
+      const int64_t si = ext(i);
+      const PPOp &M0 = pp_get(all_but(N_, i));
+      ops_.d2d(Mm_[i], M0.buf, sizeof(double) * si * R_);
+      ops_.add_inplace(Mm_[i], dM_[i], si * R_);
+      mode_update(i, Mm_[i], si, o.lambda, true, o.ratio_step);
+      ops_.zero(dM_[i], sizeof(double) * si * R_);
+      for (int ii = 0; ii < N_; ii++) {  // propagate (als_CP.cxx:1036-1053)
+        if (ii == i) continue;
+        const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
+        FactorRef f = fref(i, dW_.data());
+        if (ii < i)  // T[ii, i, r], contract i
+          ops_.mttv(T.buf, ext(ii), si, 1, &f, 1, R_, dM_[ii], ext(ii), 1);
+        else  // T[i, ii, r], contract i
+          ops_.mttv(T.buf, 1, si, ext(ii), &f, 1, R_, dM_[ii], ext(ii), 1);
+      }
+    }
+    for (int i = 0; i < N_; i++) {
+      ops_.sumsq(dM_[i], ext(i) * R_, scal_ + 2 * i);
+      ops_.sumsq(Mm_[i], ext(i) * R_, scal_ + 2 * i + 1);
+    }
+    double h[2 * MAX_ORDER];
+    ops_.d2h(h, scal_, sizeof(double) * 2 * N_);
+    for (int i = 0; i < N_; i++) relpert[i] = std::sqrt(h[2 * i]) / std::sqrt(h[2 * i + 1]);
+    normalize();
+    grad_from_sweep_ = true;
+    if (iter % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+  return diffV;
+}
+
+int CpEngine::run_pp(const CpOpts &o, int *iters) { return run_pp_common(o, iters, false); }
+int CpEngine::run_pp_partupdate(const CpOpts &o, int *iters) {
+  if (P_ > 1)
+    throw std::runtime_error("ppals: -pp 2 (partial update) runs on a single GPU in this version");
+  return run_pp_common(o, iters, true);
+}
+
+int CpEngine::run_pp_common(const CpOpts &o, int *iters, bool partupdate) {
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
   if (rank_ == 0 && !o.csv_path.empty()) {
@@ -770,11 +850,14 @@ int CpEngine::run_pp(const CpOpts &o, int *iters) {
     pcsv = &csv;
     if (!o.bench) csv << "[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]\n";
   }
+  if (partupdate && rank_ == 0 && o.verbose) std::cout << "alsCP_PP_partupdate starts. " << std::endl;
   for (int i = 0; i < N_; i++) {
     size_t n = sizeof(double) * V_.glens[i] * R_;
     if (!Wprev_[i]) Wprev_[i] = (double *)ops_.alloc(n);
     if (!Winit_[i]) Winit_[i] = (double *)ops_.alloc(n);
     if (!dW_[i]) dW_[i] = (double *)ops_.alloc(n);
+    if (partupdate && !dM_[i]) dM_[i] = (double *)ops_.alloc(n);
+    if (partupdate && !Mm_[i]) Mm_[i] = (double *)ops_.alloc(n);
     ops_.zero(dW_[i], n);
   }
   st_time_ = now();
@@ -786,7 +869,10 @@ int CpEngine::run_pp(const CpOpts &o, int *iters) {
       dt_sub(o, gradnorm_v, iter, pcsv);
     }
     if (rank_ == 0 && o.verbose) printf("pairwise perturbation starts from %d\n", iter);
-    pp_sub(o, gradnorm_v, iter, pcsv);
+    if (partupdate)
+      pp_partupdate_sub(o, gradnorm_v, iter, pcsv);
+    else
+      pp_sub(o, gradnorm_v, iter, pcsv);
     // deviation from the reference: a timelimit hit terminates instead of looping forever
     // (als_CP.cxx:1105 with breaks at :496 and :750)
     if (now() - st_time_ > o.timelimit) break;

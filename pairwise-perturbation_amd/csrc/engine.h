@@ -38,6 +38,7 @@ struct CpOpts {
   int resprint = 10;
   int bench = 0;
   double tol_init = 1e-2, ratio_step = 1.0;
+  double update_percentage = 1.0;  // -pp 2: fraction of the modes updated per PP sweep
   std::string csv_path;
   bool csv_append = false;
   bool verbose = false;
@@ -66,6 +67,7 @@ class CpEngine {
   // drivers
   int run_dt(const CpOpts &o, int *iters);  // alsCP_DT, als_CP.cxx:127-320
   int run_pp(const CpOpts &o, int *iters);  // alsCP_PP, als_CP.cxx:1082-1137
+  int run_pp_partupdate(const CpOpts &o, int *iters);  // alsCP_PP_partupdate, als_CP.cxx:1146-1207
 
   int order() const { return N_; }
   int rank_r() const { return R_; }
@@ -104,12 +106,14 @@ class CpEngine {
                    std::ofstream *csv);
   double dt_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv);
   double pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv);
+  double pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstream *csv);
+  int run_pp_common(const CpOpts &o, int *iters, bool partupdate);
 
   Ops &ops_;
   Comm &comm_;
   TensorDesc V_;
   int N_, R_, P_, rank_;
-  std::vector<double *> W_, gradW_, Wprev_, Winit_, dW_;
+  std::vector<double *> W_, gradW_, Wprev_, Winit_, dW_, dM_, Mm_;
   double *G_ = nullptr;       // N Gram matrices, R*R each
   double *S_ = nullptr, *Sinv_ = nullptr;
   double *gradsq_ = nullptr;  // per-mode local sum of grad^2 (device)

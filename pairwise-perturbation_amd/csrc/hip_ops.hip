@@ -560,6 +560,10 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_take_top, dim3(grid_for(J * rank, 256)), dim3(256), 0, st_, G, J, rank, U);
     HIP_CHECK(hipGetLastError());
   }
+  void add_inplace(double *dst, const double *src, int64_t n) override {
+    hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, st_, dst, src, n);
+    HIP_CHECK(hipGetLastError());
+  }
   void sumsq(const double *x, int64_t n, double *out) override {
     int g = grid_for(n, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * g);

@@ -780,6 +780,12 @@ __global__ void k_take_top(const double *__restrict__ Z, int64_t J, int rank,
   }
 }
 
+__global__ void k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] += src[e];
+}
+
 __global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restrict__ partial) {
   __shared__ double lds[17];
   double s = 0;

@@ -146,6 +146,7 @@ class Ops {
   // U (J x rank, column-major) = leading eigenvectors of symmetric PSD G (J x J), descending
   virtual void top_eigvecs(double *G, int64_t J, int rank, double *U) = 0;
   virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
+  virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
 
   // profiling of the scan kernels (HIP events on the launch stream)
   virtual void profile_enable(bool) {}

@@ -297,6 +297,7 @@ static CpOpts to_opts(const ppals_cp_opts *o) {
   if (o->csv_path) c.csv_path = o->csv_path;
   c.csv_append = o->csv_append != 0;
   c.verbose = o->verbose != 0;
+  c.update_percentage = o->update_percentage;
   return c;
 }
 int ppals_cp_dt(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
@@ -309,6 +310,13 @@ int ppals_cp_pp(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
   if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_pp(to_opts(o), iters);
+  API_END(PPALS_ERR_HIP)
+}
+
+int ppals_cp_pp_partupdate(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  return s->eng->run_pp_partupdate(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
 

@@ -8,7 +8,7 @@
 // Extra flags (unknown flags are ignored by the reference's parser, so command lines stay
 // compatible): -prec 32|64 (tensor storage in HBM, default 32), -seed N (default 0),
 // -device N (default LOCAL_RANK).
-// Not supported (SURVEY.md §8f "next"): -tensor p/p2/c, -pp 2, -issparse 1, Tucker -pp 1.
+// Not supported (SURVEY.md §8f "next"): -tensor p/p2/c, -issparse 1, Tucker -pp 1.
 #include "driver_common.h"
 
 int main(int argc, char **argv) {
@@ -38,6 +38,7 @@ int main(int argc, char **argv) {
   opt.ratio_step = a.magni;
   opt.csv_path = a.filename;
   opt.verbose = 1;
+  opt.update_percentage = a.update_percentage_pp;
   int iters = 0;
 
   if (a.model[0] == 'C') {
@@ -54,8 +55,7 @@ int main(int argc, char **argv) {
     } else if (a.pp == 1) {
       CHECK(ppals_cp_pp(cp, &opt, &iters));
     } else {
-      fprintf(stderr, "test_ALS: -pp 2 (partial update) is not supported yet\n");
-      return 2;
+      CHECK(ppals_cp_pp_partupdate(cp, &opt, &iters));  // test_ALS.cxx:359-362
     }
     ppals_cp_destroy(cp);
   } else {

@@ -32,7 +32,8 @@ class _Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("timelimit", C.c_double), ("maxiter", C.c_int),
                 ("lambda_", C.c_double), ("resprint", C.c_int), ("bench", C.c_int),
                 ("tol_init", C.c_double), ("ratio_step", C.c_double), ("csv_path", C.c_char_p),
-                ("csv_append", C.c_int), ("verbose", C.c_int)]
+                ("csv_append", C.c_int), ("verbose", C.c_int),
+                ("update_percentage", C.c_double)]
 
 
 EXPORTS = [
@@ -44,7 +45,8 @@ EXPORTS = [
     "ppals_tensor_norm", "ppals_fill_uniform_host", "ppals_tree_node", "ppals_mttkrp",
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
-    "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_tucker_create",
+    "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_cp_pp_partupdate",
+    "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_hosvd", "ppals_tucker_ttmc", "ppals_tucker_sweeps_dt", "ppals_tucker_dt",
 ]
@@ -203,9 +205,9 @@ class Tensor:
 
 
 def _opts(tol=0.0, timelimit=5e3, maxiter=0, lam=0.0, resprint=10, bench=0, tol_init=1e-2,
-          ratio_step=1.0, csv=None, csv_append=0, verbose=0):
+          ratio_step=1.0, csv=None, csv_append=0, verbose=0, update_percentage=1.0):
     return _Opts(tol, timelimit, maxiter, lam, resprint, bench, tol_init, ratio_step,
-                 csv.encode() if csv else None, csv_append, verbose)
+                 csv.encode() if csv else None, csv_append, verbose, update_percentage)
 
 
 class CP:
@@ -281,6 +283,12 @@ class CP:
         o = _opts(**kw)
         it = C.c_int(0)
         rc = _check(lib().ppals_cp_pp(self._h, C.byref(o), C.byref(it)))
+        return rc, it.value
+
+    def run_pp_partupdate(self, **kw):
+        o = _opts(**kw)
+        it = C.c_int(0)
+        rc = _check(lib().ppals_cp_pp_partupdate(self._h, C.byref(o), C.byref(it)))
         return rc, it.value
 
     def close(self):

@@ -333,6 +333,9 @@ class HostOps : public Ops {
     for (int k = 0; k < rank; k++)
       for (int64_t i = 0; i < J; i++) U[i + J * k] = Q[i + (size_t)J * ord[k]];
   }
+  void add_inplace(double *dst, const double *src, int64_t n) override {
+    for (int64_t i = 0; i < n; i++) dst[i] += src[i];
+  }
   void sumsq(const double *x, int64_t n, double *out) override {
     double s = 0;
     for (int64_t i = 0; i < n; i++) s += x[i] * x[i];

@@ -220,6 +220,21 @@ def als_cp_pp(V, Ws, gradWs, tol, tol_init, maxiter, lam=0.0, ratio_step=1.0, cs
     return rc, iters.value, unflat(wf, lens, [R] * len(lens)), unflat(gf, lens, [R] * len(lens))
 
 
+def als_cp_pp_partupdate(V, Ws, gradWs, tol, tol_init, maxiter, update_percentage, lam=0.0,
+                         ratio_step=1.0, csv=None, resprint=10, timelimit=5e3, verbose=0):
+    lens = V.shape
+    R = Ws[0].shape[1]
+    wf, gf = flat(Ws), flat(gradWs)
+    Vf = np.asfortranarray(V)
+    iters = C.c_int(0)
+    rc = lib().ppo_als_cp_pp_partupdate(
+        len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf), C.c_double(tol),
+        C.c_double(tol_init), C.c_double(timelimit), maxiter, C.c_double(lam),
+        C.c_double(ratio_step), C.c_double(update_percentage), (csv.encode() if csv else None),
+        resprint, verbose, C.byref(iters))
+    return rc, iters.value, unflat(wf, lens, [R] * len(lens)), unflat(gf, lens, [R] * len(lens))
+
+
 def ttmc(V, Ws, skip):
     lens = V.shape
     ranks = [W.shape[1] for W in Ws]

@@ -28,6 +28,7 @@ test_jacobi_fallback_path = G.test_jacobi_fallback_path
 test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
+test_driver_pp_partupdate_matches_oracle = G.test_driver_pp_partupdate_matches_oracle
 
 import test_gpu_tucker as GT  # noqa: E402
 

@@ -243,3 +243,33 @@ def test_driver_pp_matches_oracle(pp, ctx, dtype, tmp_path):
     if dtype == 1:
         for a, b in zip(Wl, W_ref):
             assert relerr(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("pct", [1.0, 0.5])
+def test_driver_pp_partupdate_matches_oracle(pp, ctx, pct, tmp_path):
+    """`-pp 2` (alsCP_PP_partupdate, als_CP.cxx:852-1207): same phase pattern, trajectory and final
+    factors as the oracle's literal restatement (fp64 storage)"""
+    lens, R = [9, 8, 7, 6], 2
+    V, W = problem(lens, R, 12, "r")
+    G = O.init_factors(lens, R, 56)
+    Vn = np.linalg.norm(V)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    kw = dict(tol=1e-7 * Vn, tol_init=0.1, maxiter=60, resprint=1)
+    _, it_ref, W_ref, _ = O.als_cp_pp_partupdate(V, W, G, update_percentage=pct, csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    rc, it = s.run_pp_partupdate(csv=c_got, update_percentage=pct, **kw)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert any(r[4] == 1 for r in r2)
+    n = min(len(r1), len(r2))
+    assert n >= 10
+    for a, b in zip(r1[:n], r2[:n]):
+        if a[5] < 1e-5 * Vn:
+            break
+        assert a[1] == b[1] and a[4] == b[4], (a, b)
+        assert abs(a[5] - b[5]) <= 1e-4 * abs(a[5])
+    if it == it_ref:
+        for a, b in zip(s.get_factors(), W_ref):
+            assert relerr(a, b) < 1e-5
