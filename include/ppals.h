@@ -139,6 +139,8 @@ int ppals_tucker_ttmc(ppals_tucker *s, int skip, double *Y, int64_t *n);
 int ppals_tucker_sweeps_dt(ppals_tucker *s, int n);
 /* alsTucker_DT (als_Tucker.h:46-48, als_Tucker.cxx:240-424) */
 int ppals_tucker_dt(ppals_tucker *s, const ppals_cp_opts *o, int *iters);
+/* alsTucker_PP (als_Tucker.h:89-91, als_Tucker.cxx:906-962); o->tol_init = -pp_res_tol */
+int ppals_tucker_pp(ppals_tucker *s, const ppals_cp_opts *o, int *iters);
 
 #ifdef __cplusplus
 }

@@ -850,6 +850,177 @@ struct TuckerTree {
   }
 };
 
+// ---------------------------------------------------------------- Tucker PP
+// Build_ttmc_map (als_Tucker.cxx:426-466): key = contracted modes (ascending); the recursion drops
+// the last contracted mode; every contraction keeps the tensor order (mode extent s -> rank).
+struct TuckerPPMap {
+  int N;
+  const Ten *V;
+  const Factors *F;
+  map<string, Ten> cache;
+  const Ten &get(const string &args) {
+    auto it = cache.find(args);
+    if (it != cache.end()) return it->second;
+    int mode = args.back() - 'a';
+    const Ten &M = (args.size() == 1) ? *V : get(args.substr(0, args.size() - 1));
+    Ten out = ttm_keep(M, mode, F->W[mode], M.lens[mode], F->ranks[mode]);
+    cache[args] = std::move(out);
+    Ten &ref = cache[args];
+    ref.d = ref.own.data();
+    return ref;
+  }
+};
+
+// column sign alignment with a reference factor (als_Tucker.cxx:632-643, :874-885):
+// sign_k = +1 if <W[:,k], Wref[:,k]> > 0 else -1
+void sign_align(double *W, const double *Wref, i64 rows, int r) {
+  for (int k = 0; k < r; k++) {
+    double c = 0;
+    for (i64 j = 0; j < rows; j++) c += W[j + rows * k] * Wref[j + rows * k];
+    double sgn = c > 0 ? 1.0 : -1.0;
+    for (i64 j = 0; j < rows; j++) W[j + rows * k] *= sgn;
+  }
+}
+
+struct TuckerRun {
+  const Ten *V;
+  Factors F;
+  int N;
+  vector<int> ranks;
+  double *core;
+  vector<double> core_prev;
+  i64 ncore;
+  double tol, timelimit;
+  int maxiter, resprint;
+  Log log;
+  double st_time;
+};
+
+// print block shared by DT_sub / PP_sub (als_Tucker.cxx:521-564, :763-822)
+bool tucker_print(TuckerRun &c, int iter, int pp_flag, double &diffnorm, double &diffnorm_V,
+                  bool also_stop_at_maxiter) {
+  double st_time1 = now();
+  Ten cc = ttmc(*c.V, c.F, -1);
+  std::memcpy(c.core, cc.d, sizeof(double) * c.ncore);
+  diffnorm = std::fabs(fro(c.core, c.ncore) - fro(c.core_prev.data(), c.ncore));
+  Ten cview;
+  cview.lens.assign(c.ranks.begin(), c.ranks.end());
+  cview.modes.resize(c.N);
+  std::iota(cview.modes.begin(), cview.modes.end(), 0);
+  cview.d = c.core;
+  diffnorm_V = tucker_residual(*c.V, cview, c.F);
+  c.st_time += now() - st_time1;
+  double dtime = now() - c.st_time;
+  c.log.row(c.F.lens[0], iter, "diffnorm", diffnorm, c.tol, pp_flag, diffnorm_V, dtime);
+  if (diffnorm < c.tol || now() - c.st_time > c.timelimit ||
+      (also_stop_at_maxiter && iter == c.maxiter))
+    return true;
+  std::copy(c.core, c.core + c.ncore, c.core_prev.begin());
+  return false;
+}
+
+// alsTucker_DT_sub (als_Tucker.cxx:476-669)
+void tucker_dt_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, double &diffnorm,
+                   int &iter) {
+  int N = c.N;
+  vector<vector<double>> W_prev(N);
+  for (int i = 0; i < N; i++) W_prev[i].assign((size_t)c.F.lens[i] * c.ranks[i], 0.0);
+  double diffnorm_V = 1000;
+  TuckerTree tree;
+  tree.N = N;
+  tree.V = c.V;
+  tree.F = &c.F;
+  build_tree(tree.parent, tree.sibling, 0, N - 1);
+  Ten Y_end;
+  for (; iter <= c.maxiter; iter++) {
+    if ((iter % c.resprint == 0 && iter != 0) || iter == 1 || iter == c.maxiter) {
+      if (tucker_print(c, iter, 0, diffnorm, diffnorm_V, false)) break;
+    }
+    tree.cache.clear();
+    for (int i = 0; i < N; i++) {
+      string leaf(1, (char)('a' + i));
+      const Ten &Y = tree.node(leaf);
+      if (i == N - 1) {
+        Y_end = Y;
+        Y_end.d = Y_end.own.data();
+      }
+      vector<double> G = unfold_gram(Y, i);
+      tree.cache.erase(leaf);
+      top_left_vectors(G, c.F.lens[i], c.ranks[i], c.F.W[i]);
+      sign_align(c.F.W[i], W_prev[i].data(), c.F.lens[i], c.ranks[i]);
+    }
+    Ten cc = ttm_keep(Y_end, N - 1, c.F.W[N - 1], c.F.lens[N - 1], c.ranks[N - 1]);
+    std::memcpy(c.core, cc.d, sizeof(double) * c.ncore);
+    int num_dw_break = 0;
+    for (int i = 0; i < N; i++) {
+      i64 n = c.F.lens[i] * c.ranks[i];
+      for (i64 e = 0; e < n; e++) {
+        dW[i][e] = c.F.W[i][e] - W_prev[i][e];
+        W_prev[i][e] = c.F.W[i][e];
+      }
+      if (std::fabs(fro(dW[i].data(), n) / fro(c.F.W[i], n)) < tol_init) num_dw_break++;
+    }
+    if (num_dw_break == N) return;
+  }
+}
+
+// alsTucker_PP_sub (als_Tucker.cxx:679-896), bench == false
+void tucker_pp_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, double &diffnorm,
+                   int &iter) {
+  int N = c.N;
+  int init_iter = iter;
+  double diffnorm_V = 1000;
+  vector<vector<double>> W_init(N);
+  TuckerPPMap pp;
+  pp.N = N;
+  pp.V = c.V;
+  pp.F = &c.F;
+  Ten Y_end;
+  for (; iter <= c.maxiter; iter++) {
+    int num_dw_break = 0;
+    for (int i = 0; i < N; i++) {
+      i64 n = c.F.lens[i] * c.ranks[i];
+      if (std::fabs(fro(dW[i].data(), n) / fro(c.F.W[i], n)) > tol_init) num_dw_break++;
+    }
+    if (iter == init_iter || num_dw_break > 0) {
+      if (num_dw_break > 0) return;
+      for (int j = 0; j < N; j++) {
+        W_init[j].assign(c.F.W[j], c.F.W[j] + c.F.lens[j] * c.ranks[j]);
+        std::fill(dW[j].begin(), dW[j].end(), 0.0);
+      }
+      pp.cache.clear();
+      for (int ii = 0; ii < N; ii++)
+        for (int jj = ii + 1; jj < N; jj++) pp.get(all_but(N, ii, jj));
+      for (int ii = 0; ii < N; ii++) pp.get(all_but(N, ii));
+    }
+    if ((iter % c.resprint == 0 && iter != 0) || iter == 1 || iter == c.maxiter ||
+        iter == init_iter) {
+      if (tucker_print(c, iter, 1, diffnorm, diffnorm_V, true)) break;
+    }
+    for (int i = 0; i < N; i++) {
+      Ten Y = pp.get(all_but(N, i));  // copy
+      Y.d = Y.own.data();
+      // first-order correction: Y += T_{i,ii} x_ii dW[ii]  (als_Tucker.cxx:835-860)
+      for (int ii = 0; ii < N; ii++) {
+        if (ii == i) continue;
+        const Ten &T = pp.get(all_but(N, std::min(i, ii), std::max(i, ii)));
+        Ten add = ttm_keep(T, ii, dW[ii].data(), c.F.lens[ii], c.ranks[ii]);
+        for (size_t e = 0; e < Y.own.size(); e++) Y.own[e] += add.d[e];
+      }
+      if (i == N - 1) {
+        Y_end = Y;
+        Y_end.d = Y_end.own.data();
+      }
+      vector<double> G = unfold_gram(Y, i);
+      top_left_vectors(G, c.F.lens[i], c.ranks[i], c.F.W[i]);
+      sign_align(c.F.W[i], W_init[i].data(), c.F.lens[i], c.ranks[i]);
+      for (i64 e = 0; e < c.F.lens[i] * c.ranks[i]; e++) dW[i][e] = c.F.W[i][e] - W_init[i][e];
+    }
+    Ten cc = ttm_keep(Y_end, N - 1, c.F.W[N - 1], c.F.lens[N - 1], c.ranks[N - 1]);
+    std::memcpy(c.core, cc.d, sizeof(double) * c.ncore);
+  }
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -1215,6 +1386,43 @@ int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double
     printf("tf took %lf seconds\n", now() - st_time);
   }
   if (log.has_csv) log.csv.close();
+  if (iters) *iters = iter;
+  return iter == maxiter + 1 ? 0 : 1;
+}
+
+// alsTucker_PP (als_Tucker.cxx:906-962), bench == false
+int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
+                      double *core, double tol, double tol_init, double timelimit, int maxiter,
+                      const char *csv_path, int resprint, int verbose, int *iters) {
+  TuckerRun c;
+  Ten Vt = view_of(N, lens, V);
+  c.V = &Vt;
+  c.F = factors(N, lens, 0, Wflat, ranks);
+  c.N = N;
+  c.ranks.assign(ranks, ranks + N);
+  c.core = core;
+  c.ncore = 1;
+  for (int i = 0; i < N; i++) c.ncore *= ranks[i];
+  c.core_prev.assign(core, core + c.ncore);
+  c.tol = tol;
+  c.timelimit = timelimit;
+  c.maxiter = maxiter;
+  c.resprint = resprint;
+  c.log.verbose = verbose != 0;
+  c.log.open(csv_path);
+  c.log.header("[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]");
+  c.st_time = now();
+  int iter = 0;
+  double diffnorm = 10.;
+  vector<vector<double>> dW(N);
+  for (int j = 0; j < N; j++) dW[j].assign((size_t)lens[j] * ranks[j], 0.0);
+  while (diffnorm > tol && iter <= maxiter) {
+    tucker_dt_sub(c, dW, tol_init, diffnorm, iter);
+    tucker_pp_sub(c, dW, tol_init, diffnorm, iter);
+    if (tol_init > 5e-3) tol_init *= 0.9;
+    if (now() - c.st_time > timelimit) break;
+  }
+  if (c.log.has_csv) c.log.csv.close();
   if (iters) *iters = iter;
   return iter == maxiter + 1 ? 0 : 1;
 }

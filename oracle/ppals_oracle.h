@@ -80,6 +80,10 @@ int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double
                       double *core, double tol, double timelimit, int maxiter, const char *csv_path,
                       int resprint, int verbose, int *iters);                  /* als_Tucker.cxx:240 */
 
+int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
+                      double *core, double tol, double tol_init, double timelimit, int maxiter,
+                      const char *csv_path, int resprint, int verbose, int *iters); /* als_Tucker.cxx:906 */
+
 int ppo_num_threads(void);
 void ppo_set_num_threads(int n);
 

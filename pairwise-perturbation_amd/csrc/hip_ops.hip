@@ -560,6 +560,10 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_take_top, dim3(grid_for(J * rank, 256)), dim3(256), 0, st_, G, J, rank, U);
     HIP_CHECK(hipGetLastError());
   }
+  void sign_align(double *W, const double *Wref, int64_t rows, int r) override {
+    hipLaunchKernelGGL(k_sign_align, dim3((r + 3) / 4), dim3(256), 0, st_, W, Wref, rows, r);
+    HIP_CHECK(hipGetLastError());
+  }
   void add_inplace(double *dst, const double *src, int64_t n) override {
     hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, st_, dst, src, n);
     HIP_CHECK(hipGetLastError());

@@ -780,6 +780,22 @@ __global__ void k_take_top(const double *__restrict__ Z, int64_t J, int rank,
   }
 }
 
+// one wave per column: sign of the dot product with the reference column, then rescale
+__global__ void k_sign_align(double *__restrict__ W, const double *__restrict__ Wref, int64_t rows,
+                             int r) {
+  const int lane = threadIdx.x & 63;
+  const int col = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (col >= r) return;
+  double *w = W + rows * col;
+  const double *q = Wref + rows * col;
+  double c = 0;
+  for (int64_t j = lane; j < rows; j += 64) c += w[j] * q[j];
+  c = wave_sum(c);
+  c = __shfl(c, 0, 64);
+  if (!(c > 0))
+    for (int64_t j = lane; j < rows; j += 64) w[j] = -w[j];
+}
+
 __global__ void k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (int64_t)gridDim.x * blockDim.x)

@@ -147,6 +147,8 @@ class Ops {
   virtual void top_eigvecs(double *G, int64_t J, int rank, double *U) = 0;
   virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
   virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
+  // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)
+  virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
 
   // profiling of the scan kernels (HIP events on the launch stream)
   virtual void profile_enable(bool) {}

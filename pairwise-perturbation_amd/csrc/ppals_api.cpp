@@ -379,4 +379,11 @@ int ppals_tucker_dt(ppals_tucker *s, const ppals_cp_opts *o, int *iters) {
   API_END(PPALS_ERR_HIP)
 }
 
+int ppals_tucker_pp(ppals_tucker *s, const ppals_cp_opts *o, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  return s->eng->run_pp(to_opts(o), iters);
+  API_END(PPALS_ERR_HIP)
+}
+
 }  // extern "C"

@@ -44,7 +44,7 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   ops_.zero(core_, sizeof(double) * ncore_);
   ops_.zero(core_prev_, sizeof(double) * ncore_);
   G_ = (double *)ops_.alloc(sizeof(double) * maxs * maxs);
-  scal_ = (double *)ops_.alloc(sizeof(double) * 8);
+  scal_ = (double *)ops_.alloc(sizeof(double) * 64);
   yend_elems_ = ncore_ / r_[N_ - 1] * V_.glens[N_ - 1];
   Yend_ = (double *)ops_.alloc(sizeof(double) * yend_elems_);
   build_tree(0, N_ - 1, -1);
@@ -67,6 +67,12 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(scal_);
   ops_.free(Yfull_);
   ops_.free(gather_);
+  ops_.free(Ytmp_);
+  ops_.free(Yacc_);
+  for (auto p : Wprev_) ops_.free(p);
+  for (auto p : Winit_) ops_.free(p);
+  for (auto p : dW_) ops_.free(p);
+  pp_clear();
 }
 
 void TuckerEngine::build_tree(int lo, int hi, int parent) {
@@ -280,7 +286,11 @@ void TuckerEngine::hosvd() {
   ops_.sync();
 }
 
-void TuckerEngine::sweep_dt() {
+void TuckerEngine::sweep_dt() { sweep_body(nullptr); }
+
+// one HOOI sweep; align_ref != nullptr: column signs aligned with that factor set after every
+// eigen-step (alsTucker_DT_sub, als_Tucker.cxx:632-643)
+void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
   for (auto &n : nodes_) n.valid = false;  // ttmc_map.clear(), als_Tucker.cxx:340
   for (int i = 0; i < N_; i++) {
     compute_node(leaf_[i]);
@@ -292,6 +302,7 @@ void TuckerEngine::sweep_dt() {
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
     ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);                   // K12
     ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
+    if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
   }
   // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408)
   int64_t L = ncore_ / r_[N_ - 1];
@@ -392,6 +403,231 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
   }
   ops_.sync();
   if (talk) {
+    printf("\nIter = %d Final Diff norm %E \n", iter, diffnorm);
+    printf("tf took %lf seconds\n", now() - st_time);
+  }
+  if (pcsv) csv.close();
+  if (iters) *iters = iter;
+  return iter == o.maxiter + 1 ? 0 : 1;
+}
+
+// ============================================================================ Tucker PP
+static std::string tk_all_but(int N, int i, int j = -1) {
+  std::string s;
+  for (int m = 0; m < N; m++)
+    if (m != i && m != j) s.push_back((char)('a' + m));
+  return s;
+}
+
+// Build_ttmc_map (als_Tucker.cxx:426-466): key = contracted modes (ascending), recursion drops the
+// last one; every contraction keeps the tensor order. Level 1 scans V (K11), deeper levels
+// contract the cached fp64 intermediate.
+const TuckerEngine::PPOp &TuckerEngine::pp_get(const std::string &args) {
+  auto it = pp_.find(args);
+  if (it != pp_.end()) return it->second;
+  const int mode = args.back() - 'a';
+  PPOp op;
+  const void *src;
+  int dt;
+  if (args.size() == 1) {
+    op.dims.resize(N_);
+    for (int m = 0; m < N_; m++) op.dims[m] = ext(m);
+    src = V_.data;
+    dt = V_.dtype;
+  } else {
+    const PPOp &par = pp_get(args.substr(0, args.size() - 1));
+    op.dims = par.dims;
+    src = par.buf;
+    dt = F64;
+  }
+  int64_t L = 1, T = 1;
+  for (int q = 0; q < mode; q++) L *= op.dims[q];
+  for (int q = mode + 1; q < N_; q++) T *= op.dims[q];
+  const int64_t J = op.dims[mode];
+  op.dims[mode] = r_[mode];
+  op.elems = L * r_[mode] * T;
+  op.buf = (double *)ops_.alloc(sizeof(double) * op.elems);
+  ops_.ttm_keep(src, dt, L, J, T, wptr(mode), V_.glens[mode], r_[mode], op.buf);
+  pp_[args] = op;
+  return pp_[args];
+}
+void TuckerEngine::pp_clear() {
+  for (auto &kv : pp_) ops_.free(kv.second.buf);
+  pp_.clear();
+}
+
+// one approximate sweep (als_Tucker.cxx:824-891): Y_i = Y_i^0 + sum_{j != i} T_ij x_j dW_j
+void TuckerEngine::sweep_pp() {
+  for (int i = 0; i < N_; i++) {
+    const PPOp &Y0 = pp_get(tk_all_but(N_, i));
+    if (yacc_cap_ < Y0.elems) {
+      ops_.free(Yacc_);
+      Yacc_ = (double *)ops_.alloc(sizeof(double) * Y0.elems);
+      yacc_cap_ = Y0.elems;
+    }
+    if (ytmp_cap_ < Y0.elems) {
+      ops_.free(Ytmp_);
+      Ytmp_ = (double *)ops_.alloc(sizeof(double) * Y0.elems);
+      ytmp_cap_ = Y0.elems;
+    }
+    ops_.d2d(Yacc_, Y0.buf, sizeof(double) * Y0.elems);
+    for (int ii = 0; ii < N_; ii++) {
+      if (ii == i) continue;
+      const PPOp &Tp = pp_get(tk_all_but(N_, std::min(i, ii), std::max(i, ii)));
+      int64_t L = 1, T = 1;
+      for (int q = 0; q < ii; q++) L *= Tp.dims[q];
+      for (int q = ii + 1; q < N_; q++) T *= Tp.dims[q];
+      ops_.ttm_keep(Tp.buf, F64, L, V_.glens[ii], T, dW_[ii], V_.glens[ii], r_[ii], Ytmp_);
+      ops_.add_inplace(Yacc_, Ytmp_, Y0.elems);
+    }
+    int64_t L = 1, T = 1;
+    for (int q = 0; q < i; q++) L *= r_[q];
+    for (int q = i + 1; q < N_; q++) T *= r_[q];
+    if (i == N_ - 1) ops_.d2d(Yend_, Yacc_, sizeof(double) * yend_elems_);
+    ops_.unfold_gram(Yacc_, F64, L, V_.glens[i], T, G_);
+    ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
+    ops_.sign_align(W_[i], Winit_[i], V_.glens[i], r_[i]);  // als_Tucker.cxx:874-885
+    double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
+    int64_t n[1] = {V_.glens[i] * r_[i]};
+    ops_.diff_norms(A, B, n, 1, 1, D, 0, scal_ + 4);  // dW = W - W_init (als_Tucker.cxx:887)
+  }
+  int64_t L = ncore_ / r_[N_ - 1];
+  ops_.ttm_keep(Yend_, F64, L, V_.glens[N_ - 1], 1, W_[N_ - 1], V_.glens[N_ - 1], r_[N_ - 1],
+                core_);
+}
+
+bool TuckerEngine::print_block(const CpOpts &o, int iter, int pp_flag, double &diffnorm,
+                               double &diffV, std::ofstream *csv, double &st_time,
+                               bool stop_at_maxiter) {
+  ops_.sync();
+  const double st_time1 = now();
+  compute_core_full();
+  diffnorm = core_norm();
+  diffV = residual();
+  st_time += now() - st_time1;
+  const double dtime = now() - st_time;
+  if (rank_ == 0) {
+    if (o.verbose) {
+      std::cout.precision(13);
+      std::cout << "  [dim]=  " << V_.glens[0] << "  [iter]=  " << iter << "  [diffnorm]  "
+                << diffnorm << "  [tol]  " << o.tol << "  [pp_update]  " << pp_flag
+                << "  [diffV]  " << diffV << "  [dtime]  " << dtime << "\n";
+    }
+    if (csv) {
+      (*csv) << V_.glens[0] << "," << iter << "," << diffnorm << "," << o.tol << "," << pp_flag
+             << "," << diffV << "," << dtime << "\n";
+      if (iter % 100 == 0 && iter != 0) (*csv) << std::endl;
+    }
+  }
+  if (diffnorm < o.tol || now() - st_time > o.timelimit || (stop_at_maxiter && iter == o.maxiter))
+    return true;
+  ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
+  return false;
+}
+
+void TuckerEngine::read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw) {
+  int64_t n[MAX_ORDER];
+  for (int i = 0; i < N_; i++) n[i] = V_.glens[i] * r_[i];
+  if (dt_phase)
+    ops_.diff_norms(W_.data(), Wprev_.data(), n, N_, 1, dW_.data(), 1, scal_ + 8);
+  else
+    ops_.diff_norms(W_.data(), nullptr, n, N_, 0, dW_.data(), 0, scal_ + 8);
+  double h[2 * MAX_ORDER];
+  ops_.d2h(h, scal_ + 8, sizeof(double) * 2 * N_);
+  nd.resize(N_);
+  nw.resize(N_);
+  for (int i = 0; i < N_; i++) {
+    nd[i] = std::sqrt(h[2 * i]);
+    nw[i] = std::sqrt(h[2 * i + 1]);
+  }
+}
+
+// alsTucker_DT_sub (als_Tucker.cxx:476-669)
+void TuckerEngine::dt_sub(const CpOpts &o, double tol_init, double &diffnorm, int &iter,
+                          std::ofstream *csv, double &st_time) {
+  double diffV = 1000;
+  for (int i = 0; i < N_; i++) ops_.zero(Wprev_[i], sizeof(double) * V_.glens[i] * r_[i]);
+  std::vector<double> nd, nw;
+  for (; iter <= o.maxiter; iter++) {
+    if ((iter % o.resprint == 0 && iter != 0) || iter == 1 || iter == o.maxiter) {
+      if (print_block(o, iter, 0, diffnorm, diffV, csv, st_time, false)) break;
+    }
+    sweep_body(&Wprev_);
+    read_norms(true, nd, nw);
+    int num_dw_break = 0;
+    for (int i = 0; i < N_; i++)
+      if (std::fabs(nd[i] / nw[i]) < tol_init) num_dw_break++;
+    if (num_dw_break == N_) return;
+    if (iter % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+}
+
+// alsTucker_PP_sub (als_Tucker.cxx:679-896), bench == false
+void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, int &iter,
+                          std::ofstream *csv, double &st_time) {
+  const int init_iter = iter;
+  double diffV = 1000;
+  std::vector<double> nd, nw;
+  for (; iter <= o.maxiter; iter++) {
+    int num_dw_break = 0;
+    read_norms(false, nd, nw);
+    for (int i = 0; i < N_; i++)
+      if (std::fabs(nd[i] / nw[i]) > tol_init) num_dw_break++;
+    if (iter == init_iter || num_dw_break > 0) {
+      if (num_dw_break > 0) return;
+      for (int j = 0; j < N_; j++) {
+        size_t n = sizeof(double) * V_.glens[j] * r_[j];
+        ops_.d2d(Winit_[j], W_[j], n);
+        ops_.zero(dW_[j], n);
+      }
+      pp_clear();
+      for (int ii = 0; ii < N_; ii++)
+        for (int jj = ii + 1; jj < N_; jj++) pp_get(tk_all_but(N_, ii, jj));
+      for (int ii = 0; ii < N_; ii++) pp_get(tk_all_but(N_, ii));
+    }
+    if ((iter % o.resprint == 0 && iter != 0) || iter == 1 || iter == o.maxiter ||
+        iter == init_iter) {
+      if (print_block(o, iter, 1, diffnorm, diffV, csv, st_time, true)) break;
+    }
+    sweep_pp();
+  }
+}
+
+int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
+  if (P_ > 1)
+    throw std::runtime_error("ppals: Tucker -pp 1 runs on a single GPU in this version");
+  std::ofstream csv;
+  std::ofstream *pcsv = nullptr;
+  if (rank_ == 0 && !o.csv_path.empty()) {
+    csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
+    pcsv = &csv;
+    csv << "[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]\n";
+  }
+  if (Wprev_.empty()) {
+    for (int i = 0; i < N_; i++) {
+      size_t n = sizeof(double) * V_.glens[i] * r_[i];
+      Wprev_.push_back((double *)ops_.alloc(n));
+      Winit_.push_back((double *)ops_.alloc(n));
+      dW_.push_back((double *)ops_.alloc(n));
+    }
+  }
+  for (int i = 0; i < N_; i++) ops_.zero(dW_[i], sizeof(double) * V_.glens[i] * r_[i]);
+  double st_time = now();
+  int iter = 0;
+  ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);  // Tensor<> core_prev(core)
+  double diffnorm = 10.;
+  double tol_init = o.tol_init;
+  while (diffnorm > o.tol && iter <= o.maxiter) {
+    if (rank_ == 0 && o.verbose) printf("DT starts from %d\n", iter);
+    dt_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
+    if (rank_ == 0 && o.verbose) printf("pairwise perturbation starts from %d\n", iter);
+    pp_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
+    if (tol_init > 5e-3) tol_init *= 0.9;  // als_Tucker.cxx:947-948
+    if (now() - st_time > o.timelimit) break;
+  }
+  ops_.sync();
+  pp_clear();
+  if (rank_ == 0 && o.verbose) {
     printf("\nIter = %d Final Diff norm %E \n", iter, diffnorm);
     printf("tf took %lf seconds\n", now() - st_time);
   }

@@ -1,5 +1,7 @@
 // tucker.h — HOOI sweep engine for Tucker decomposition (als_Tucker.cxx) over abstract ops.
 #pragma once
+#include <fstream>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -17,6 +19,7 @@ class TuckerEngine {
   int64_t ttmc(int skip, double *Yhost);  // als_Tucker.cxx:76-110
   void sweep_dt();                       // als_Tucker.cxx:340-408
   int run_dt(const CpOpts &o, int *iters);  // alsTucker_DT, als_Tucker.cxx:240-424
+  int run_pp(const CpOpts &o, int *iters);  // alsTucker_PP, als_Tucker.cxx:906-962
 
  private:
   struct Node {
@@ -51,6 +54,27 @@ class TuckerEngine {
   std::vector<int> leaf_;
   std::vector<char> contracted_;  // scratch
   int P_ = 1, rank_ = 0;
+  // pairwise perturbation (als_Tucker.cxx:426-962)
+  struct PPOp {
+    double *buf = nullptr;
+    int64_t elems = 0;
+    std::vector<int64_t> dims;
+  };
+  std::map<std::string, PPOp> pp_;
+  std::vector<double *> Wprev_, Winit_, dW_;
+  double *Ytmp_ = nullptr, *Yacc_ = nullptr;
+  int64_t ytmp_cap_ = 0, yacc_cap_ = 0;
+  const PPOp &pp_get(const std::string &args);
+  void pp_clear();
+  void sweep_body(const std::vector<double *> *align_ref);
+  void sweep_pp();
+  bool print_block(const CpOpts &o, int iter, int pp_flag, double &diffnorm, double &diffV,
+                   std::ofstream *csv, double &st_time, bool stop_at_maxiter);
+  void read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw);
+  void dt_sub(const CpOpts &o, double tol_init, double &diffnorm, int &iter, std::ofstream *csv,
+              double &st_time);
+  void pp_sub(const CpOpts &o, double tol_init, double &diffnorm, int &iter, std::ofstream *csv,
+              double &st_time);
   double *Yfull_ = nullptr, *gather_ = nullptr;
   int64_t yfull_cap_ = 0, gather_cap_ = 0;
 };

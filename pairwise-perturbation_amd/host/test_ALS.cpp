@@ -8,7 +8,7 @@
 // Extra flags (unknown flags are ignored by the reference's parser, so command lines stay
 // compatible): -prec 32|64 (tensor storage in HBM, default 32), -seed N (default 0),
 // -device N (default LOCAL_RANK).
-// Not supported (SURVEY.md §8f "next"): -tensor p/p2/c, -issparse 1, Tucker -pp 1.
+// Not supported (SURVEY.md §8f "next"): -tensor p/p2/c, -issparse 1.
 #include "driver_common.h"
 
 int main(int argc, char **argv) {
@@ -68,8 +68,7 @@ int main(int argc, char **argv) {
     if (a.pp == 0) {
       CHECK(ppals_tucker_dt(tk, &opt, &iters));
     } else {
-      fprintf(stderr, "test_ALS: Tucker -pp 1 is not supported yet\n");
-      return 2;
+      CHECK(ppals_tucker_pp(tk, &opt, &iters));  // test_ALS.cxx:392-394
     }
     ppals_tucker_destroy(tk);
   }

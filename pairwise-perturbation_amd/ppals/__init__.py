@@ -49,6 +49,7 @@ EXPORTS = [
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_hosvd", "ppals_tucker_ttmc", "ppals_tucker_sweeps_dt", "ppals_tucker_dt",
+    "ppals_tucker_pp",
 ]
 
 
@@ -339,6 +340,12 @@ class Tucker:
         o = _opts(**kw)
         it = C.c_int(0)
         rc = _check(lib().ppals_tucker_dt(self._h, C.byref(o), C.byref(it)))
+        return rc, it.value
+
+    def run_pp(self, **kw):
+        o = _opts(**kw)
+        it = C.c_int(0)
+        rc = _check(lib().ppals_tucker_pp(self._h, C.byref(o), C.byref(it)))
         return rc, it.value
 
     def close(self):

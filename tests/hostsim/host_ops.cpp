@@ -333,6 +333,14 @@ class HostOps : public Ops {
     for (int k = 0; k < rank; k++)
       for (int64_t i = 0; i < J; i++) U[i + J * k] = Q[i + (size_t)J * ord[k]];
   }
+  void sign_align(double *W, const double *Wref, int64_t rows, int r) override {
+    for (int k = 0; k < r; k++) {
+      double c = 0;
+      for (int64_t j = 0; j < rows; j++) c += W[j + rows * k] * Wref[j + rows * k];
+      if (!(c > 0))
+        for (int64_t j = 0; j < rows; j++) W[j + rows * k] = -W[j + rows * k];
+    }
+  }
   void add_inplace(double *dst, const double *src, int64_t n) override {
     for (int64_t i = 0; i < n; i++) dst[i] += src[i];
   }

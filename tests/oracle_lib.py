@@ -281,6 +281,21 @@ def als_tucker_dt(V, Ws, core, tol, maxiter, csv=None, resprint=10, timelimit=5e
     return rc, iters.value, unflat(wf, lens, ranks), cf.reshape(ranks, order="F")
 
 
+def als_tucker_pp(V, Ws, core, tol, tol_init, maxiter, csv=None, resprint=10, timelimit=5e3,
+                  verbose=0):
+    lens = V.shape
+    ranks = [W.shape[1] for W in Ws]
+    wf = flat(Ws)
+    cf = np.asfortranarray(core).ravel(order="F").copy()
+    Vf = np.asfortranarray(V)
+    iters = C.c_int(0)
+    rc = lib().ppo_als_tucker_pp(len(lens), _lens(lens), _ranks(ranks), _dp(Vf), _dp(wf), _dp(cf),
+                                 C.c_double(tol), C.c_double(tol_init), C.c_double(timelimit),
+                                 maxiter, (csv.encode() if csv else None), resprint, verbose,
+                                 C.byref(iters))
+    return rc, iters.value, unflat(wf, lens, ranks), cf.reshape(ranks, order="F")
+
+
 def read_csv(path):
     """parse the reference-format CSV into (header, rows of floats); blank flush lines skipped"""
     with open(path) as f:

@@ -34,3 +34,4 @@ import test_gpu_tucker as GT  # noqa: E402
 
 test_ttmc_matches_oracle = GT.test_ttmc_matches_oracle
 test_hosvd_and_dt_sweeps = GT.test_hosvd_and_dt_sweeps
+test_tucker_pp_driver_matches_oracle = GT.test_tucker_pp_driver_matches_oracle

@@ -95,3 +95,31 @@ def test_large_mode_uses_vendor_eig(pp, ctx):
     W_ref, core_ref = O.hosvd(V, ranks)
     for a, b in zip(W, W_ref):
         assert np.linalg.norm(proj(a) - proj(b)) < 1e-7
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_tucker_pp_driver_matches_oracle(pp, ctx, dtype, tmp_path):
+    """alsTucker_PP (als_Tucker.cxx:906-962): DT/PP phase pattern, residual trajectory and final
+    subspaces vs the oracle's restatement"""
+    lens, ranks = [10, 9, 8], [3, 3, 2]
+    V = O.fill_uniform(int(np.prod(lens)), 4, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W0, c0 = O.hosvd(V, ranks)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    kw = dict(tol=0.0, tol_init=0.1, maxiter=12, resprint=1)
+    _, it_ref, W_ref, core_ref = O.als_tucker_pp(V, W0, c0, csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.hosvd()          # fills the core; then start from the oracle's factors
+    s.set_factors(W0)
+    rc, it = s.run_pp(csv=c_got, **kw)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert any(r[4] == 1 for r in r2), "PP phase never entered"
+    if dtype == 1:
+        assert it == it_ref and [r[1:2] + r[4:5] for r in r1] == [r[1:2] + r[4:5] for r in r2]
+    n = min(len(r1), len(r2))
+    for a, b in zip(r1[:n], r2[:n]):
+        assert abs(a[5] - b[5]) < (1e-4 if dtype == 0 else 1e-7) * np.linalg.norm(V)
+    W, core = s.get_factors()
+    for a, b in zip(W, W_ref):
+        assert np.linalg.norm(proj(a) - proj(b)) < (5e-2 if dtype == 0 else 1e-5)
