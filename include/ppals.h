@@ -70,6 +70,17 @@ int ppals_tensor_local_rows(const ppals_tensor *t, int64_t *lo, int64_t *n); /* 
 int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat);
 /* `-tensor r2` (test_ALS.cxx:272): V[e] = lo + (hi-lo)*u01(seed, e), e = global linear index */
 int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double hi);
+/* `-tensor p` / `p2` (laplacian_tensor, common.cxx:575-642; `p` is the same data folded to order
+ * dim/2 with extents size^2, fold_unfold common.cxx:870-880): the tensor must have been created
+ * with those lens; ndigits = -dim, s = -size */
+int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s);
+/* `-tensor c` (Gen_collinearity + U(-1,1) noise of relative norm ratio_noise, common.cxx:361-423,
+ * test_ALS.cxx:246-264) */
+int ppals_tensor_fill_collinear(ppals_tensor *t, int R, double col_min, double col_max,
+                                double ratio_noise, uint64_t seed);
+/* the factor vectors Gen_collinearity draws (host only; lambda folded into mode 0) */
+int ppals_collinear_factors(int order, const int64_t *lens, int R, double col_min, double col_max,
+                            uint64_t seed, double *Wflat);
 /* host data: the FULL tensor in fp64, first index fastest (the layout read_dense_from_file
  * implies, test_ALS.cxx:289-325); each rank keeps its own leading-mode rows */
 int ppals_tensor_upload(ppals_tensor *t, const double *host_full);

@@ -128,6 +128,82 @@ void tensor_fill_uniform(Ops &ops, const TensorDesc &V, uint64_t seed, double lo
 void tensor_upload(Ops &ops, const TensorDesc &V, const double *host_full) {
   ops.upload_shard(V.data, V.dtype, host_full, V.llens[0], V.glens[0], V.row0, rest_of(V));
 }
+void tensor_fill_laplacian(Ops &ops, const TensorDesc &V, int ndigits, int s) {
+  ops.fill_laplacian(V.data, V.dtype, V.llens[0], V.glens[0], V.row0, rest_of(V), ndigits, s);
+  ops.sync();
+}
+
+// host-side counter RNG identical to the device / oracle generator
+static inline uint64_t sm64_host(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline double u01_host(uint64_t seed, uint64_t idx) {
+  uint64_t h = sm64_host(sm64_host(seed) ^ idx);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Gen_collinearity (common.cxx:361-423): per mode j, the rank-i vector is re-drawn until its
+// collinearity with every earlier vector of that mode lies in [col_min, col_max]; component i is
+// weighted lambda_i = 0.2 + 0.6/R*(i+1) (folded into the mode-0 factor here).
+void collinear_factors(const int64_t *lens, int N, int R, double col_min, double col_max,
+                       uint64_t seed, double *Wflat) {
+  double *W = Wflat;
+  for (int j = 0; j < N; j++) {
+    const int64_t s = lens[j];
+    uint64_t draw = 0;
+    for (int i = 0; i < R; i++) {
+      double *vi = W + s * i;
+      for (int attempt = 0; attempt < 100000; attempt++) {
+        const uint64_t sd = seed + 7919ull * (uint64_t)j + 104729ull * (draw++);
+        for (int64_t e = 0; e < s; e++) vi[e] = u01_host(sd, (uint64_t)e);
+        bool ok = true;
+        for (int k = 0; k < i && ok; k++) {
+          const double *vk = W + s * k;
+          double ip = 0, n1 = 0, n2 = 0;
+          for (int64_t e = 0; e < s; e++) {
+            ip += vi[e] * vk[e];
+            n1 += vi[e] * vi[e];
+            n2 += vk[e] * vk[e];
+          }
+          const double col = ip / (std::sqrt(n1) * std::sqrt(n2));
+          if (col < col_min || col > col_max) ok = false;
+        }
+        if (ok) break;
+      }
+    }
+    W += s * R;
+  }
+  for (int i = 0; i < R; i++) {
+    const double lambda_ = 0.2 + 0.6 / R * (i + 1);
+    for (int64_t e = 0; e < lens[0]; e++) Wflat[e + lens[0] * i] *= lambda_;
+  }
+}
+
+void tensor_fill_collinear(Ops &ops, Comm &comm, const TensorDesc &V, int R, double col_min,
+                           double col_max, double ratio_noise, uint64_t seed) {
+  size_t tot = 0;
+  for (int i = 0; i < V.order; i++) tot += (size_t)V.glens[i] * R;
+  std::vector<double> W(tot);
+  collinear_factors(V.glens, V.order, R, col_min, col_max, seed, W.data());
+  tensor_fill_cp(ops, V, R, W.data());
+  // V += ratio_noise * ||V|| / ||noise|| * noise, noise ~ U(-1,1)   (test_ALS.cxx:259-264)
+  const double vnorm = tensor_norm(ops, comm, V);
+  double *d = (double *)ops.alloc(sizeof(double));
+  const uint64_t nseed = seed + 0x5eedull;
+  ops.uniform_sumsq(V.llens[0], V.glens[0], V.row0, rest_of(V), nseed, -1.0, 1.0, d);
+  if (comm.size() > 1) comm.allreduce_sum(d, 1);
+  double nsq = 0;
+  ops.d2h(&nsq, d, sizeof(double));
+  ops.free(d);
+  const double alpha = ratio_noise * vnorm / std::sqrt(nsq);
+  ops.add_uniform_noise(V.data, V.dtype, V.llens[0], V.glens[0], V.row0, rest_of(V), nseed, -1.0,
+                        1.0, alpha);
+  ops.sync();
+}
+
 double tensor_norm(Ops &ops, Comm &comm, const TensorDesc &V) {
   int64_t M, K;
   split_sizes(V, &M, &K);

@@ -118,6 +118,38 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
 
+  void fill_laplacian(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                      int ndigits, int s) override {
+    int g = grid_for(l0 * rest, 256, 16384);
+    if (dt == F32)
+      hipLaunchKernelGGL(k_fill_laplacian<float>, dim3(g), dim3(256), 0, st_, (float *)V, l0, g0,
+                         row0, rest, ndigits, s);
+    else
+      hipLaunchKernelGGL(k_fill_laplacian<double>, dim3(g), dim3(256), 0, st_, (double *)V, l0, g0,
+                         row0, rest, ndigits, s);
+    HIP_CHECK(hipGetLastError());
+  }
+  void add_uniform_noise(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                         uint64_t seed, double lo, double hi, double alpha) override {
+    int g = grid_for(l0 * rest, 256, 16384);
+    if (dt == F32)
+      hipLaunchKernelGGL((k_uniform_noise<float, 0>), dim3(g), dim3(256), 0, st_, (float *)V, l0,
+                         g0, row0, rest, seed, lo, hi, alpha, (double *)nullptr);
+    else
+      hipLaunchKernelGGL((k_uniform_noise<double, 0>), dim3(g), dim3(256), 0, st_, (double *)V, l0,
+                         g0, row0, rest, seed, lo, hi, alpha, (double *)nullptr);
+    HIP_CHECK(hipGetLastError());
+  }
+  void uniform_sumsq(int64_t l0, int64_t g0, int64_t row0, int64_t rest, uint64_t seed, double lo,
+                     double hi, double *out) override {
+    int g = grid_for(l0 * rest, 256, 4096);
+    double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * g);
+    hipLaunchKernelGGL((k_uniform_noise<double, 1>), dim3(g), dim3(256), 0, st_, (double *)nullptr,
+                       l0, g0, row0, rest, seed, lo, hi, 0.0, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, g, out);
+    HIP_CHECK(hipGetLastError());
+  }
+
   template <typename TV, int MODE>
   void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                    double *out) {

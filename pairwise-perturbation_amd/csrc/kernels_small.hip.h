@@ -66,6 +66,61 @@ __global__ void k_fill_uniform(TV *__restrict__ V, int64_t l0, int64_t g0, int64
   }
 }
 
+// `-tensor p / p2`: Laplacian (Poisson) operator tensor, elementwise closed form of
+// laplacian_tensor (common.cxx:575-642)
+__host__ __device__ inline double laplacian_value(uint64_t gi, int ndigits, int s) {
+  int mismatches = 0;
+  double dval = 0.0;
+  for (int k = 0; k < ndigits / 2; k++) {
+    const int a = (int)(gi % (uint64_t)s);
+    gi /= (uint64_t)s;
+    const int b = (int)(gi % (uint64_t)s);
+    gi /= (uint64_t)s;
+    if (a != b) {
+      mismatches++;
+      dval = (a - b == 1 || b - a == 1) ? -1.0 : 0.0;
+    }
+  }
+  if (mismatches == 0) return 2.0 * (ndigits / 2);
+  if (mismatches == 1) return dval;
+  return 0.0;
+}
+template <typename TV>
+__global__ void k_fill_laplacian(TV *__restrict__ V, int64_t l0, int64_t g0, int64_t row0,
+                                 int64_t rest, int ndigits, int s) {
+  const int64_t total = l0 * rest;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = e % l0, r = e / l0;
+    const uint64_t gi = (uint64_t)(row0 + a) + (uint64_t)g0 * (uint64_t)r;
+    V[e] = (TV)laplacian_value(gi, ndigits, s);
+  }
+}
+// MODE 0: V[e] += alpha*u(e);  MODE 1: partial[blk] = sum u(e)^2  (u regenerated on the fly)
+template <typename TV, int MODE>
+__global__ __launch_bounds__(256) void k_uniform_noise(TV *__restrict__ V, int64_t l0, int64_t g0,
+                                                       int64_t row0, int64_t rest, uint64_t seed,
+                                                       double lo, double hi, double alpha,
+                                                       double *__restrict__ partial) {
+  __shared__ double lds[17];
+  const int64_t total = l0 * rest;
+  double acc = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = e % l0, r = e / l0;
+    const uint64_t gi = (uint64_t)(row0 + a) + (uint64_t)g0 * (uint64_t)r;
+    const double u = lo + (hi - lo) * u01(seed, gi);
+    if (MODE == 0)
+      V[e] = (TV)((double)V[e] + alpha * u);
+    else
+      acc += u * u;
+  }
+  if (MODE == 1) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  }
+}
+
 // rank-R outer structure  vhat[m,k] = sum_r Q[m,r] P[k,r]; block = 256 rows m, KCH columns k.
 // MODE 0: V = vhat (build_V, common.cxx:135-197). MODE 1: partial[blk] = sum (V - vhat)^2
 // (als_CP.cxx:183-187, nothing materialised). MODE 2: partial[blk] = sum V^2.

@@ -49,6 +49,18 @@ class Ops {
   // of a leading mode of global extent g0; `rest` = product of the other extents
   virtual void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
                             uint64_t seed, double lo, double hi) = 0;
+  // `-tensor p/p2` (laplacian_tensor, common.cxx:575-642): the element with global linear index e
+  // has `ndigits` base-s digits (a_1,b_1,...,a_d,b_d); value = sum_k D[a_k,b_k] prod_{j!=k}
+  // [a_j==b_j], D = tridiag(-1,2,-1)
+  virtual void fill_laplacian(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                              int ndigits, int s) = 0;
+  // V[e] += alpha * (lo + (hi-lo)*u01(seed, global index))   (`-tensor c` noise, test_ALS.cxx:259-264)
+  virtual void add_uniform_noise(void *V, int dt, int64_t l0, int64_t g0, int64_t row0,
+                                 int64_t rest, uint64_t seed, double lo, double hi,
+                                 double alpha) = 0;
+  // *out = sum over the local elements of (lo + (hi-lo)*u01(seed, global index))^2
+  virtual void uniform_sumsq(int64_t l0, int64_t g0, int64_t row0, int64_t rest, uint64_t seed,
+                             double lo, double hi, double *out) = 0;
   // V[m,k] = sum_r Q[m,r]*P[k,r]  (Q: M x R, P: K x R, column-major fp64)   (build_V)
   virtual void fill_rank(void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
                          int R) = 0;

@@ -166,6 +166,33 @@ int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double 
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
+int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s) {
+  if (!t || ndigits < 2 || ndigits % 2 || s < 1) return fail(PPALS_ERR_ARG, "bad argument");
+  API_BEGIN
+  double total = 1, want = 1;
+  for (int i = 0; i < t->d.order; i++) total *= (double)t->d.glens[i];
+  for (int i = 0; i < ndigits; i++) want *= s;
+  if (total != want) return fail(PPALS_ERR_ARG, "tensor extents do not hold size^dim elements");
+  tensor_fill_laplacian(*t->ctx->ops, t->d, ndigits, s);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tensor_fill_collinear(ppals_tensor *t, int R, double col_min, double col_max,
+                                double ratio_noise, uint64_t seed) {
+  if (!t || R <= 0 || R > 64) return fail(PPALS_ERR_ARG, "bad argument (rank must be in 1..64)");
+  API_BEGIN
+  tensor_fill_collinear(*t->ctx->ops, t->ctx->c(), t->d, R, col_min, col_max, ratio_noise, seed);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_collinear_factors(int order, const int64_t *lens, int R, double col_min, double col_max,
+                            uint64_t seed, double *Wflat) {
+  if (!lens || !Wflat || order < 1 || R <= 0) return fail(PPALS_ERR_ARG, "bad argument");
+  API_BEGIN
+  collinear_factors(lens, order, R, col_min, col_max, seed, Wflat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_ARG)
+}
 int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
   if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN

@@ -159,7 +159,8 @@ static void init_factors_flat(const std::vector<int64_t> &lens, int R, uint64_t 
 // (test_ALS.cxx:272), (-1,1) in pp_bench. Returns 0 on success.
 static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **ctx_out,
                                ppals_tensor **V_out, std::vector<int64_t> &lens) {
-  if (a.dim < 2 || a.dim > PPALS_MAX_ORDER) {
+  const bool folded_p = a.tensor[0] == 'p' && !(strlen(a.tensor) > 1 && a.tensor[1] == '2');
+  if (a.dim < 2 || (!folded_p && a.dim > PPALS_MAX_ORDER) || (folded_p && a.dim > 2 * PPALS_MAX_ORDER)) {
     fprintf(stderr, "-dim must be in [2,%d] for this engine\n", PPALS_MAX_ORDER);
     return 2;
   }
@@ -178,6 +179,17 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
     CHECK(ppals_ctx_init_comm(ctx, a.rank, a.world, uid));
   }
   lens.assign(a.dim, (int64_t)a.s);
+  const int ndigits = a.dim;  // -tensor p / p2: number of base-`size` digits of an element index
+  if (a.tensor[0] == 'p' && !(strlen(a.tensor) > 1 && a.tensor[1] == '2')) {
+    // p: Poisson operator of order `dim`, folded to order dim/2 with extents size^2
+    // (test_ALS.cxx:231-245, fold_unfold common.cxx:870-880)
+    if (a.dim % 2) {
+      fprintf(stderr, "-tensor p needs an even -dim\n");
+      return 2;
+    }
+    a.dim = a.dim / 2;
+    lens.assign(a.dim, (int64_t)a.s * a.s);
+  }
   const int dtype = a.prec == 64 ? PPALS_F64 : PPALS_F32;
   const char *tensor = a.tensor;
   bool from_file = false;
@@ -217,8 +229,21 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
     std::vector<double> Wtrue;  // test_ALS.cxx:279-284
     init_factors_flat(lens, a.R, 1000 + 16 * a.seed, Wtrue);
     CHECK(ppals_tensor_fill_cp(V, a.R, Wtrue.data()));
+  } else if (tensor[0] == 'p') {
+    if (ndigits % 2) {
+      fprintf(stderr, "-tensor p2 needs an even -dim\n");
+      return 2;
+    }
+    CHECK(ppals_tensor_fill_laplacian(V, ndigits, a.s));  // test_ALS.cxx:222-245
+  } else if (tensor[0] == 'c') {
+    if (a.R > 64) {
+      fprintf(stderr, "this build supports -rank <= 64\n");
+      return 2;
+    }
+    CHECK(ppals_tensor_fill_collinear(V, a.R, a.col_min, a.col_max, a.ratio_noise,
+                                      5000 + a.seed));  // test_ALS.cxx:246-264
   } else {
-    fprintf(stderr, "-tensor %s is not supported by this engine yet (supported: r, r2, o1, o2)\n",
+    fprintf(stderr, "-tensor %s is not a tensor source of the reference (p, p2, c, r, r2, o1, o2)\n",
             tensor);
     return 2;
   }

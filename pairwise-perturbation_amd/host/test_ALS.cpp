@@ -8,7 +8,7 @@
 // Extra flags (unknown flags are ignored by the reference's parser, so command lines stay
 // compatible): -prec 32|64 (tensor storage in HBM, default 32), -seed N (default 0),
 // -device N (default LOCAL_RANK).
-// Not supported (SURVEY.md §8f "next"): -tensor p/p2/c, -issparse 1.
+// Not supported: -issparse 1 (the engine is dense).
 #include "driver_common.h"
 
 int main(int argc, char **argv) {

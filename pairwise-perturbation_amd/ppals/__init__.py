@@ -42,6 +42,7 @@ EXPORTS = [
     "ppals_ctx_sync", "ppals_profile_enable", "ppals_profile_read", "ppals_profile_reset",
     "ppals_tensor_create", "ppals_tensor_destroy", "ppals_tensor_local_rows",
     "ppals_tensor_fill_cp", "ppals_tensor_fill_uniform", "ppals_tensor_upload",
+    "ppals_tensor_fill_laplacian", "ppals_tensor_fill_collinear", "ppals_collinear_factors",
     "ppals_tensor_norm", "ppals_fill_uniform_host", "ppals_tree_node", "ppals_mttkrp",
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
@@ -100,6 +101,15 @@ def init_factors(lens, R, seed):
     """W_i[e] = u01(seed + i, e): the deterministic stand-in for CTF's W[i].fill_random(0,1)"""
     return [fill_uniform_host(s * R, seed + i).reshape((s, R), order="F")
             for i, s in enumerate(lens)]
+
+
+def collinear_factors(lens, R, col_min=0.5, col_max=0.9, seed=0):
+    """the factor vectors of `-tensor c` (Gen_collinearity, common.cxx:361-423), lambda in mode 0"""
+    wf = np.empty(sum(int(s) * R for s in lens))
+    arr = (C.c_int64 * len(lens))(*[int(x) for x in lens])
+    _check(lib().ppals_collinear_factors(len(lens), arr, R, C.c_double(col_min),
+                                         C.c_double(col_max), C.c_uint64(seed), _dp(wf)))
+    return unflat(wf, lens, [R] * len(lens))
 
 
 class Context:
@@ -180,6 +190,16 @@ class Tensor:
     def fill_uniform(self, seed, lo=0.5, hi=1.0):
         _check(lib().ppals_tensor_fill_uniform(self._h, C.c_uint64(seed), C.c_double(lo),
                                                C.c_double(hi)))
+        return self
+
+    def fill_laplacian(self, ndigits, s):
+        _check(lib().ppals_tensor_fill_laplacian(self._h, ndigits, s))
+        return self
+
+    def fill_collinear(self, R, col_min=0.5, col_max=0.9, ratio_noise=0.01, seed=0):
+        _check(lib().ppals_tensor_fill_collinear(self._h, R, C.c_double(col_min),
+                                                 C.c_double(col_max), C.c_double(ratio_noise),
+                                                 C.c_uint64(seed)))
         return self
 
     def upload(self, V):

@@ -94,6 +94,46 @@ class HostOps : public Ops {
       st(V, dt, e, lo + (hi - lo) * u01(seed, (uint64_t)(row0 + a) + (uint64_t)g0 * (uint64_t)r));
     }
   }
+  void fill_laplacian(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                      int ndigits, int s) override {
+    // independent of the device kernel's closed form: the defining sum over k of
+    // D[a_k,b_k] * prod_{j != k} delta(a_j,b_j)   (common.cxx:575-642)
+    for (int64_t e = 0; e < l0 * rest; e++) {
+      uint64_t gi = (uint64_t)(row0 + e % l0) + (uint64_t)g0 * (uint64_t)(e / l0);
+      std::vector<int> a(ndigits / 2), b(ndigits / 2);
+      for (int k = 0; k < ndigits / 2; k++) {
+        a[k] = (int)(gi % s);
+        gi /= s;
+        b[k] = (int)(gi % s);
+        gi /= s;
+      }
+      double v = 0;
+      for (int k = 0; k < ndigits / 2; k++) {
+        double term = a[k] == b[k] ? 2.0 : (std::abs(a[k] - b[k]) == 1 ? -1.0 : 0.0);
+        for (int j = 0; j < ndigits / 2; j++)
+          if (j != k && a[j] != b[j]) term = 0;
+        v += term;
+      }
+      st(V, dt, e, v);
+    }
+  }
+  void add_uniform_noise(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
+                         uint64_t seed, double lo, double hi, double alpha) override {
+    for (int64_t e = 0; e < l0 * rest; e++) {
+      uint64_t gi = (uint64_t)(row0 + e % l0) + (uint64_t)g0 * (uint64_t)(e / l0);
+      st(V, dt, e, ld(V, dt, e) + alpha * (lo + (hi - lo) * u01(seed, gi)));
+    }
+  }
+  void uniform_sumsq(int64_t l0, int64_t g0, int64_t row0, int64_t rest, uint64_t seed, double lo,
+                     double hi, double *out) override {
+    double acc = 0;
+    for (int64_t e = 0; e < l0 * rest; e++) {
+      uint64_t gi = (uint64_t)(row0 + e % l0) + (uint64_t)g0 * (uint64_t)(e / l0);
+      double u = lo + (hi - lo) * u01(seed, gi);
+      acc += u * u;
+    }
+    *out = acc;
+  }
   void fill_rank(void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
                  int R) override {
     for (int64_t k = 0; k < K; k++)

@@ -35,3 +35,5 @@ import test_gpu_tucker as GT  # noqa: E402
 test_ttmc_matches_oracle = GT.test_ttmc_matches_oracle
 test_hosvd_and_dt_sweeps = GT.test_hosvd_and_dt_sweeps
 test_tucker_pp_driver_matches_oracle = GT.test_tucker_pp_driver_matches_oracle
+test_tensor_p_laplacian = G.test_tensor_p_laplacian
+test_tensor_c_collinear = G.test_tensor_c_collinear

@@ -273,3 +273,63 @@ def test_driver_pp_partupdate_matches_oracle(pp, ctx, pct, tmp_path):
     if it == it_ref:
         for a, b in zip(s.get_factors(), W_ref):
             assert relerr(a, b) < 1e-5
+
+
+def _laplacian_numpy(N, s):
+    """laplacian_tensor (common.cxx:575-642) built the way the reference does: sum over k of
+    I x .. x D x .. x I with D = tridiag(-1, 2, -1); index order (a1, b1, a2, b2, ...)"""
+    d = N // 2
+    D = 2 * np.eye(s) - np.eye(s, k=1) - np.eye(s, k=-1)
+    I = np.eye(s)
+    V = np.zeros([s] * N)
+    letters = "abcdefghijklmnop"
+    for k in range(d):
+        ops, subs = [], []
+        for j in range(d):
+            ops.append(D if j == k else I)
+            subs.append(letters[2 * j] + letters[2 * j + 1])
+        V += np.einsum(",".join(subs) + "->" + letters[:N], *ops)
+    return V
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("N,s,folded", [(4, 4, False), (6, 3, False), (6, 3, True), (8, 2, True)])
+def test_tensor_p_laplacian(pp, ctx, N, s, folded, dtype):
+    """`-tensor p2` (order dim) and `-tensor p` (folded to order dim/2, extents size^2)"""
+    Vn = _laplacian_numpy(N, s)
+    if folded:
+        Vn = Vn.reshape([s * s] * (N // 2), order="F")
+    lens = list(Vn.shape)
+    t = pp.Tensor(ctx, lens, dtype).fill_laplacian(N, s)
+    assert abs(t.norm() - np.linalg.norm(Vn)) < 1e-6 * np.linalg.norm(Vn)
+    R = 2
+    W = O.init_factors(lens, R, 31)
+    c = pp.CP(ctx, t, R)
+    c.set_factors(W)
+    for mode in range(len(lens)):
+        assert relerr(c.mttkrp(mode), O.mttkrp(Vn, W, mode, 0)) < KTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_tensor_c_collinear(pp, ctx, dtype):
+    """`-tensor c`: factor collinearity inside [col_min, col_max], lambda weights, and the
+    noise term of relative norm ratio_noise (Gen_collinearity, test_ALS.cxx:246-264)"""
+    lens, R = [12, 10, 11, 9], 3
+    col_min, col_max, ratio, seed = 0.5, 0.9, 0.05, 3
+    W = pp.collinear_factors(lens, R, col_min, col_max, seed)
+    for j, w in enumerate(W):
+        wn = w / np.linalg.norm(w, axis=0)
+        Cm = wn.T @ wn
+        for a in range(R):
+            for b in range(a):
+                assert col_min <= Cm[a, b] <= col_max, (j, a, b, Cm[a, b])
+    clean = O.build_V([np.asfortranarray(w) for w in W])
+    noise = O.fill_uniform(clean.size, seed + 0x5EED, lo=-1.0, hi=1.0).reshape(lens, order="F")
+    want = clean + ratio * np.linalg.norm(clean) / np.linalg.norm(noise) * noise
+    t = pp.Tensor(ctx, lens, dtype).fill_collinear(R, col_min, col_max, ratio, seed)
+    assert abs(t.norm() - np.linalg.norm(want)) < 1e-6 * np.linalg.norm(want)
+    Wt = O.init_factors(lens, R, 77)
+    c = pp.CP(ctx, t, R)
+    c.set_factors(Wt)
+    for mode in range(4):
+        assert relerr(c.mttkrp(mode), O.mttkrp(want, Wt, mode, 0)) < KTOL[dtype] * 2

@@ -86,3 +86,23 @@ def test_pp_bench_lines(tmp_path):
     for ln in text:
         if "," in ln and not ln.startswith("[timetype]"):
             assert float(ln.split(",")[1]) > 0
+
+
+@pytest.mark.parametrize("args", [
+    ["-tensor", "p", "-dim", "6", "-size", "4", "-rank", "3"],        # folded Poisson, order 3
+    ["-tensor", "p2", "-dim", "4", "-size", "6", "-rank", "3"],       # Poisson operator, order 4
+    ["-tensor", "c", "-dim", "4", "-size", "10", "-rank", "3", "-pp", "1", "-pp_res_tol", "0.1"],
+    ["-tensor", "r", "-dim", "4", "-size", "10", "-rank", "2", "-pp", "2",
+     "-update_percentage_pp", "0.5", "-pp_res_tol", "0.1"],
+    ["-model", "Tucker", "-tensor", "r2", "-dim", "3", "-size", "12", "-rank", "3", "-pp", "1",
+     "-pp_res_tol", "0.1"],
+])
+def test_every_tensor_source_and_pp_mode_runs(tmp_path, args):
+    """the whole -tensor / -pp flag space of test_ALS.cxx:222-326,352-396 is accepted and decreases
+    the residual"""
+    csv = str(tmp_path / "o.csv")
+    run([os.path.join(BIN, "test_ALS"), "-maxiter", "25", "-resprint", "1", "-filename", csv,
+         "-prec", "64"] + args)
+    _, rows = O.read_csv(csv)
+    assert len(rows) >= 5
+    assert rows[-1][5] <= rows[0][5] * (1 + 1e-9)
