@@ -31,10 +31,15 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
-def sweep_flops(lens, R):
-    """algorithmic flops of one N=4 DT sweep: 4 s^4 R + 4 s^3 R + 8 s^2 R"""
+def sweep_flops(lens, R, schedule="msdt"):
+    """flops one exact N=4 sweep executes.
+    dt   (alsCP_DT's two-node tree): 4 s^4 R + 4 s^3 R + 8 s^2 R            
+    msdt (one first-level contraction per N-1 = 3 mode updates, 4/3 per sweep):
+         4/3 * (2 s^4 R  +  2*2 s^3 R  +  3*2 s^2 R)"""
     s = lens[0]
-    return 4.0 * s ** 4 * R + 4.0 * s ** 3 * R + 8.0 * s ** 2 * R
+    if schedule == "dt":
+        return 4.0 * s ** 4 * R + 4.0 * s ** 3 * R + 8.0 * s ** 2 * R
+    return (4.0 / 3.0) * (2.0 * s ** 4 * R + 4.0 * s ** 3 * R + 6.0 * s ** 2 * R)
 
 
 def cpu_baseline(lens, R, budget_s=20.0):
@@ -165,7 +170,8 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         sweeps_s = args.steps / elapsed
-        flops = sweep_flops(lens, R)
+        schedule = "dt" if os.environ.get("PPALS_DT_SCHEDULE", "msdt") == "dt" else "msdt"
+        flops = sweep_flops(lens, R, schedule)
         esz = 4 if args.dtype == "f32" else 8
         out = {
             "metric": "ALS sweeps/sec (exact dimension-tree sweep, CP order-4 "
@@ -183,7 +189,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CP order-4 s={lens[0]} R={R} dense `-tensor r` (V=[[W_true]], "
                                    "U(0,1) factors), -pp 0 exact DT sweep incl. Normalize; tensor "
-                                   f"stored {args.dtype} in HBM, factor/Gram/solve math fp64",
+                                   f"stored {args.dtype} in HBM, factor/Gram/solve math fp64; "
+                                   f"sweep schedule {schedule} (same ALS iterates either way)",
                        "lens": lens, "rank": R, "sharding": f"leading-mode block x{world}"},
             "mttkrp_tflops": flops * sweeps_s / 1e12,
             "sweep_flops": flops,
@@ -215,8 +222,10 @@ def main():
                 "algorithmic_bytes_per_launch": scan_bytes / launches,
                 "scan_ms_per_step": scan_ms / args.steps,
                 "other_profiled_ms_per_step": other_ms / args.steps,
+                "scan_launches_per_step": launches / args.steps,
                 "note": f"algorithmic bytes = one read of the local tensor shard "
-                        f"({esz} B/elem) per scan launch, 2 launches per sweep",
+                        f"({esz} B/elem) per scan launch; launches per sweep: 2 (dt) or N/(N-1) "
+                        f"(msdt: one first-level contraction serves N-1 mode updates)",
             }
         if world == 1 and not args.no_cpu_baseline:
             try:

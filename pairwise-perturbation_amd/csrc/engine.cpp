@@ -7,6 +7,11 @@
 //   Build_mttkrp_map          als_CP.cxx:352-409     -> pp_get
 //   alsCP_DT_sub / PP_sub     als_CP.cxx:418-833     -> dt_sub / pp_sub
 //   alsCP_PP                  als_CP.cxx:1082-1137   -> run_pp
+// Default sweep schedule: the multi-sweep dimension tree (MSDT) of the reference's class API
+// (src/optimizer/cp_msdt_optimizer.cxx:172-207): ONE first-level contraction V x_r W_r is reused
+// for the next N-1 mode updates, so an exact sweep costs N/(N-1) tensor scans instead of 2 — the
+// very same ALS iterates (same update order, same normal equations), 1.5x fewer tensor bytes at
+// N = 4. PPALS_DT_SCHEDULE=dt selects the two-first-level-node tree of alsCP_DT instead.
 // Multi-GPU: V is block-partitioned along mode 0; factors are replicated; each
 // mode update reduce-scatters the s x R partial MTTKRP rows, solves its row block, all-gathers.
 #include "engine.h"
@@ -251,6 +256,15 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ops_.zero(gatherbuf_, n);
   }
   if (const char *e = std::getenv("PPALS_COMM_SMALL_BYTES")) small_msg_bytes_ = std::atoll(e);
+  if (const char *e = std::getenv("PPALS_DT_SCHEDULE")) schedule_ = (std::string(e) == "dt") ? 0 : 1;
+  if (N_ < 3) schedule_ = 0;
+  if (schedule_ == 1) {
+    ms_build_tree(0, N_ - 2, -1);
+    ms_leaf_.assign(N_ - 1, -1);
+    for (size_t k = 0; k < ms_nodes_.size(); k++)
+      if (ms_nodes_[k].lo == ms_nodes_[k].hi) ms_leaf_[ms_nodes_[k].lo] = (int)k;
+    if (N_ == 2) ms_leaf_[0] = -1;
+  }
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = (P_ == 1);
   build_tree(0, N_ - 1, -1);
   leaf_.assign(N_, -1);
@@ -284,6 +298,13 @@ CpEngine::~CpEngine() {
   ops_.free(Qbuf_);
   ops_.free(Pbuf_);
   ops_.free(VT_);
+  ops_.free(ms_X_.buf);
+  ops_.free(ms_X_.scale);
+  for (auto &n : ms_nodes_) {
+    ops_.free(n.t.buf);
+    ops_.free(n.t.scale);
+    for (auto &t : n.tmp) ops_.free(t.buf);
+  }
 }
 
 // Second resident layout of the tensor for the RIGHT first-level node: V viewed as the matrix
@@ -361,21 +382,21 @@ void CpEngine::compute_node(int idx) {
   const bool sib_is_suffix = n.slo > n.hi;
   if (n.parent < 0) {
     if (sib_is_suffix) {
-      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, n.elems, n.elems);
+      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, F64, n.elems, n.elems);
     } else {
       ensure_transposed();
       if (vt_state_ == 1)  // V^T[(right modes), (left modes)]: the same contraction as a suffix scan
-        ops_.scan_contract(VT_, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, n.elems, n.elems);
+        ops_.scan_contract(VT_, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, F64, n.elems, n.elems);
       else
-        ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, 1, n.elems);
+        ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, F64, 1, n.elems);
     }
   } else {
     compute_node(n.parent);
     const Node &p = nodes_[n.parent];
     if (sib_is_suffix)
-      ops_.mttv(p.buf, n.elems, J, 1, f, nf, R_, n.buf, n.elems, 0);
+      ops_.mttv(p.buf, F64, n.elems, J, 1, f, nf, R_, n.buf, n.elems, 0, nullptr);
     else
-      ops_.mttv(p.buf, 1, J, n.elems, f, nf, R_, n.buf, n.elems, 0);
+      ops_.mttv(p.buf, F64, 1, J, n.elems, f, nf, R_, n.buf, n.elems, 0, nullptr);
   }
   n.valid = true;
 }
@@ -404,6 +425,7 @@ void CpEngine::set_factors(const double *Wflat, const double *gradWflat) {
   grad_from_sweep_ = false;
   refresh_grams();
   for (auto &n : nodes_) n.valid = false;
+  ms_invalidate();
 }
 
 void CpEngine::get_factors(double *Wflat, double *gradWflat) {
@@ -486,9 +508,166 @@ void CpEngine::normalize() {
   int64_t rows[MAX_ORDER];
   for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
   ops_.normalize(W_.data(), rows, N_, R_, G_);
+  if (schedule_ == 1 && ms_root_ >= 0) {
+    // cached MSDT tensors were built from the un-normalised factors of their contracted modes
+    const double *sc = ops_.normalize_scales();
+    if (ms_X_.valid) ops_.scale_update(ms_X_.scale, sc, ms_X_.contracted, 0);
+    for (auto &n : ms_nodes_)
+      if (n.t.valid) ops_.scale_update(n.t.scale, sc, n.t.contracted, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------- multi-sweep tree
+// Binary tree (same split rule as Construct_Dimension_Tree) over the POSITIONS 0..N-2 of the
+// step's mode list; node [lo,hi] = X contracted with the listed modes outside [lo,hi].
+void CpEngine::ms_build_tree(int lo, int hi, int parent) {
+  if (hi < lo) return;
+  if (hi == lo && parent < 0) {  // N == 2: single leaf directly under X
+    MsNode n;
+    n.lo = n.hi = lo;
+    n.parent = -1;
+    n.slo = 1;
+    n.shi = 0;
+    ms_nodes_.push_back(n);
+    return;
+  }
+  if (hi <= lo) return;
+  const int mid = (lo + hi) / 2;
+  const int ranges[2][2] = {{lo, mid}, {mid + 1, hi}};
+  int idx[2];
+  for (int c = 0; c < 2; c++) {
+    MsNode n;
+    n.lo = ranges[c][0];
+    n.hi = ranges[c][1];
+    n.parent = parent;
+    n.slo = ranges[1 - c][0];
+    n.shi = ranges[1 - c][1];
+    ms_nodes_.push_back(n);
+    idx[c] = (int)ms_nodes_.size() - 1;
+  }
+  ms_build_tree(lo, mid, idx[0]);
+  ms_build_tree(mid + 1, hi, idx[1]);
+}
+
+void CpEngine::ms_reserve(RTensor &t, size_t bytes) {
+  if (t.cap < bytes) {
+    ops_.free(t.buf);
+    t.buf = ops_.alloc(bytes);
+    t.cap = bytes;
+  }
+  if (!t.scale) t.scale = (double *)ops_.alloc(sizeof(double));
+}
+
+// new step: X = V x_root W_root (one tensor scan, K1-type on whichever resident layout keeps the
+// contracted mode away from the fastest index), stored in the tensor's own precision
+void CpEngine::ms_start_step(int root) {
+  ms_root_ = root;
+  ms_order_.clear();
+  for (int k = 1; k < N_; k++) ms_order_.push_back((root + k) % N_);
+  for (auto &n : ms_nodes_) n.t.valid = false;
+  const int mid = (N_ - 1) / 2;
+  std::vector<int> layout;  // storage order of the tensor copy that is scanned
+  const void *src = V_.data;
+  if (root <= mid) ensure_transposed();
+  if (root <= mid && vt_state_ == 1) {
+    for (int m = mid + 1; m < N_; m++) layout.push_back(m);
+    for (int m = 0; m <= mid; m++) layout.push_back(m);
+    src = VT_;
+  } else {
+    for (int m = 0; m < N_; m++) layout.push_back(m);
+  }
+  int64_t L = 1, T = 1;
+  bool before = true;
+  ms_X_.modes.clear();
+  for (int m : layout) {
+    if (m == root) {
+      before = false;
+      continue;
+    }
+    (before ? L : T) *= ext(m);
+    ms_X_.modes.push_back(m);
+  }
+  ms_X_.dt = V_.dtype;
+  ms_X_.contracted = 1u << root;
+  ms_reserve(ms_X_, (size_t)L * T * R_ * dtype_size(ms_X_.dt));
+  FactorRef f = fref(root, W_.data());
+  ops_.scan_contract(src, V_.dtype, L, ext(root), T, &f, 1, R_, ms_X_.buf, ms_X_.dt, L, L * T);
+  ops_.scale_update(ms_X_.scale, nullptr, 0, 1);
+  ms_X_.valid = true;
+}
+
+// dst = src contracted with `mode` (rank index shared), fp64 result; in_scale = pending factor of
+// src folded into dst, so dst starts with a clean scale of its own
+void CpEngine::ms_contract(const RTensor &src, int mode, RTensor &dst, const double *in_scale) {
+  int64_t L = 1, T = 1;
+  bool before = true;
+  dst.modes.clear();
+  for (int m : src.modes) {
+    if (m == mode) {
+      before = false;
+      continue;
+    }
+    (before ? L : T) *= ext(m);
+    dst.modes.push_back(m);
+  }
+  dst.dt = F64;
+  dst.contracted = src.contracted | (1u << mode);
+  ms_reserve(dst, sizeof(double) * (size_t)L * T * R_);
+  FactorRef f = fref(mode, W_.data());
+  ops_.mttv(src.buf, src.dt, L, ext(mode), T, &f, 1, R_, (double *)dst.buf, L * T, 0, in_scale);
+}
+
+void CpEngine::ms_compute(int idx) {
+  MsNode &n = ms_nodes_[idx];
+  if (n.t.valid) return;
+  const RTensor *src;
+  if (n.parent < 0) {
+    src = &ms_X_;
+  } else {
+    ms_compute(n.parent);
+    src = &ms_nodes_[n.parent].t;
+  }
+  // contract the sibling's modes; the one stored slowest first (longest contiguous runs)
+  std::vector<int> sib;
+  for (int pos = n.slo; pos <= n.shi; pos++) sib.push_back(ms_order_[pos]);
+  auto storage_pos = [&](int mode) {
+    for (size_t k = 0; k < src->modes.size(); k++)
+      if (src->modes[k] == mode) return (int)k;
+    return -1;
+  };
+  std::sort(sib.begin(), sib.end(), [&](int a, int b) { return storage_pos(a) > storage_pos(b); });
+  if (n.tmp.size() + 1 < sib.size()) n.tmp.resize(sib.size() - 1);
+  const RTensor *cur = src;
+  for (size_t k = 0; k < sib.size(); k++) {
+    RTensor &dst = (k + 1 == sib.size()) ? n.t : n.tmp[k];
+    ms_contract(*cur, sib[k], dst, k == 0 ? src->scale : nullptr);
+    cur = &dst;
+  }
+  if (sib.empty()) throw std::runtime_error("ppals: empty sibling set in the multi-sweep tree");
+  ops_.scale_update(n.t.scale, nullptr, 0, 1);
+  n.t.valid = true;
+}
+
+void CpEngine::sweep_msdt(double lambda) {
+  for (int i = 0; i < N_; i++) {
+    if (ms_root_ < 0 || ms_root_ == i) ms_start_step((i - 1 + N_) % N_);
+    int pos = -1;
+    for (int k = 0; k < N_ - 1; k++)
+      if (ms_order_[k] == i) pos = k;
+    const int leaf = ms_leaf_[pos];
+    ms_compute(leaf);
+    mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
+    ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update
+  }
+  normalize();
+  grad_from_sweep_ = true;
 }
 
 void CpEngine::sweep_dt(double lambda) {
+  if (schedule_ == 1) {
+    sweep_msdt(lambda);
+    return;
+  }
   for (auto &n : nodes_) n.valid = false;  // mttkrp_map.clear(), als_CP.cxx:215
   for (int i = 0; i < N_; i++) {
     compute_node(leaf_[i]);
@@ -602,7 +781,7 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     }
     op.elems = L * T;
     op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, L, op.elems);
+    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, F64, L, op.elems);
   } else {
     const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
     int64_t L = 1, T = 1;
@@ -613,7 +792,7 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     }
     op.elems = L * T;
     op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.mttv(par.buf, L, ext(mode), T, &f, 1, R_, op.buf, op.elems, 0);
+    ops_.mttv(par.buf, F64, L, ext(mode), T, &f, 1, R_, op.buf, op.elems, 0, nullptr);
   }
   pp_[seq] = op;
   return pp_[seq];
@@ -651,6 +830,7 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
 
 // one approximate sweep: als_CP.cxx:754-825
 void CpEngine::sweep_pp(double lambda, double ratio) {
+  ms_invalidate();  // PP moves the factors without touching the multi-sweep cache
   if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
   for (int i = 0; i < N_; i++) {
     const int64_t si = ext(i);
@@ -661,9 +841,9 @@ void CpEngine::sweep_pp(double lambda, double ratio) {
       const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
       FactorRef f = fref(ii, dW_.data());
       if (ii < i)  // T[ii, i, r]   (als_CP.cxx:785)
-        ops_.mttv(T.buf, 1, ext(ii), si, &f, 1, R_, Mbuf_, si, 1);
+        ops_.mttv(T.buf, F64, 1, ext(ii), si, &f, 1, R_, Mbuf_, si, 1, nullptr);
       else  // T[i, ii, r]   (als_CP.cxx:793)
-        ops_.mttv(T.buf, si, ext(ii), 1, &f, 1, R_, Mbuf_, si, 1);
+        ops_.mttv(T.buf, F64, si, ext(ii), 1, &f, 1, R_, Mbuf_, si, 1, nullptr);
     }
     mode_update(i, Mbuf_, si, lambda, true, ratio);
   }
@@ -878,6 +1058,7 @@ double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
     for (int i = 0; i < N_; i++) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return relpert[a] > relpert[b]; });
     if (rank_ == 0 && o.verbose) std::cout << "new round" << std::endl;
+    ms_invalidate();
     for (int t = 0; t < update_size; t++) {
       const int i = idx[t];
       if (rank_ == 0 && o.verbose) std::cout << i << std::endl;
@@ -892,9 +1073,9 @@ double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
         const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
         FactorRef f = fref(i, dW_.data());
         if (ii < i)  // T[ii, i, r], contract i
-          ops_.mttv(T.buf, ext(ii), si, 1, &f, 1, R_, dM_[ii], ext(ii), 1);
+          ops_.mttv(T.buf, F64, ext(ii), si, 1, &f, 1, R_, dM_[ii], ext(ii), 1, nullptr);
         else  // T[i, ii, r], contract i
-          ops_.mttv(T.buf, 1, si, ext(ii), &f, 1, R_, dM_[ii], ext(ii), 1);
+          ops_.mttv(T.buf, F64, 1, si, ext(ii), &f, 1, R_, dM_[ii], ext(ii), 1, nullptr);
       }
     }
     for (int i = 0; i < N_; i++) {

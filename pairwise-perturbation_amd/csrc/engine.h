@@ -94,6 +94,36 @@ class CpEngine {
     std::vector<int> modes;  // remaining modes (ascending)
   };
 
+  // a cached intermediate of the multi-sweep schedule: modes in storage order (first fastest),
+  // rank index last; `scale` (device scalar) is the Normalize factor still owed to its contents
+  struct RTensor {
+    void *buf = nullptr;
+    size_t cap = 0;  // bytes
+    int dt = F64;
+    std::vector<int> modes;
+    unsigned contracted = 0;
+    double *scale = nullptr;
+    bool valid = false;
+  };
+  struct MsNode {
+    int lo, hi, parent, slo, shi;  // ranges over positions of the step's cyclic mode list
+    RTensor t;
+    std::vector<RTensor> tmp;
+  };
+  void ms_build_tree(int lo, int hi, int parent);
+  void ms_start_step(int root);
+  void ms_compute(int idx);
+  void ms_reserve(RTensor &t, size_t bytes);
+  void ms_contract(const RTensor &src, int mode, RTensor &dst, const double *in_scale);
+  void sweep_msdt(double lambda);
+  void ms_invalidate() { ms_root_ = -1; }
+  int schedule_ = 1;  // 1: multi-sweep dimension tree (default), 0: the reference's two-node tree
+  int ms_root_ = -1;
+  RTensor ms_X_;
+  std::vector<MsNode> ms_nodes_;
+  std::vector<int> ms_order_;  // the N-1 modes of the step in update order
+  std::vector<int> ms_leaf_;   // node index of each list position
+
   int64_t ext(int m) const { return m == 0 ? V_.llens[0] : V_.glens[m]; }
   FactorRef fref(int m, double *const *W) const;
   int64_t prod_ext(int lo, int hi) const;

@@ -283,7 +283,7 @@ class HipOps : public Ops {
   // ------------------------------------------------------------------ scans
   template <typename TV>
   void scan_t(const TV *V, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
-              double *out, int64_t out_tstride, int64_t out_rstride) {
+              double *out, int64_t out_tstride, int64_t out_rstride, int out32) {
     constexpr int VEC = ScanTraits<TV>::VEC;
     int64_t Jc;
     KrpArgs a = krp_args(f, nf, &Jc);
@@ -301,7 +301,8 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_krp_pack<TV>, dim3(grid_for((int64_t)nblk * NT * 64 * VEC, 256)),
                          dim3(256), 0, st_, P, nblk, NT, prefix ? 1 : 0, a, J, col0, ncols);
       HIP_CHECK(hipGetLastError());
-      double *o = out + (int64_t)col0 * out_rstride;
+      double *o = out32 ? (double *)((float *)out + (int64_t)col0 * out_rstride)
+                        : out + (int64_t)col0 * out_rstride;
       const double bytes = (double)L * (double)J * (double)T * sizeof(TV);
       if (prefix) {
         // out[t + rs*n] = sum_j V[j + J*t] * B[j,n]      (M = J rows reduced, K = T columns)
@@ -316,8 +317,10 @@ class HipOps : public Ops {
         const int per = (nblk + nsplit - 1) / nsplit;
         nsplit = (nblk + per - 1) / per;
         double *dst = o;
+        int dst32 = out32;
         int64_t dst_ks = out_tstride, dst_ns = out_rstride, dst_ss = 0;
         if (nsplit > 1) {
+          dst32 = 0;
           dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * K);
           dst_ks = 1;
           dst_ns = K;
@@ -328,10 +331,10 @@ class HipOps : public Ops {
         prof_begin(0, bytes);
 #define LAUNCH_PREFIX(NTv, ALv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix<TV, NTv, ALv, 4>), grid, dim3(256), 0, st_, V, M, K, P, per, \
-                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
+                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols, dst32)
 #define LAUNCH_PREFIX_FAST(NTv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv, 12>), grid_il, dim3(256), 0, st_, V, M, K, P, per, \
-                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols)
+                     nblk, dst, dst_ks, dst_ns, dst_ss, ncols, dst32)
         if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_PREFIX_FAST(1);
           else if (NT == 2) LAUNCH_PREFIX_FAST(2);
@@ -351,7 +354,7 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(K * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, K, ncols, o, out_tstride, out_rstride);
+                             nsplit, dst_ss, K, ncols, o, out_tstride, out_rstride, out32);
           HIP_CHECK(hipGetLastError());
         }
       } else {
@@ -369,8 +372,10 @@ class HipOps : public Ops {
         const int per = (nblk + nsplit - 1) / nsplit;
         nsplit = (nblk + per - 1) / per;
         double *dst = o;
+        int dst32 = out32;
         int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = out_tstride;
         if (nsplit > 1) {
+          dst32 = 0;
           dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M);
           dst_ns = M;
           dst_ss = (int64_t)ncols * M;
@@ -382,13 +387,13 @@ class HipOps : public Ops {
         prof_begin(0, bytes);
 #define LAUNCH_SUFFIX(NTv, ALv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
 #define LAUNCH_SUFFIX_BUF(NTv)                                                                   \
   hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
         // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
@@ -417,24 +422,52 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride);
+                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32);
           HIP_CHECK(hipGetLastError());
         }
       }
     }
   }
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
-                     int nf, int R, double *out, int64_t out_tstride,
+                     int nf, int R, void *out, int out_dt, int64_t out_tstride,
                      int64_t out_rstride) override {
+    const int out32 = out_dt == F32 ? 1 : 0;
     if (dt == F32)
-      scan_t<float>((const float *)V, L, J, T, f, nf, R, out, out_tstride, out_rstride);
+      scan_t<float>((const float *)V, L, J, T, f, nf, R, (double *)out, out_tstride, out_rstride,
+                    out32);
     else
-      scan_t<double>((const double *)V, L, J, T, f, nf, R, out, out_tstride, out_rstride);
+      scan_t<double>((const double *)V, L, J, T, f, nf, R, (double *)out, out_tstride,
+                     out_rstride, out32);
   }
 
   // ------------------------------------------------------------------ mttv
-  void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
-            double *out, int64_t out_rstride, int accumulate) override {
+  template <typename TX>
+  void mttv_t(const TX *X, int64_t L, int64_t J, int64_t T, int R, const double *B, int64_t ldb,
+              double *out, int64_t rs, int accumulate, const double *scale) {
+    constexpr int VL = 16 / sizeof(TX);
+    prof_begin(1, (double)L * J * T * R * sizeof(TX));
+    if (L == 1) {
+      int64_t nw = T * R;
+      int g = grid_for(nw * 64, 256, 16384);
+      hipLaunchKernelGGL(k_mttv_1<TX>, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out, rs,
+                         accumulate, scale);
+    } else if (L % VL == 0 && L >= 16 * VL && ((uintptr_t)X & 15) == 0) {
+      int64_t nb = ((L + 64 * VL - 1) / (64 * VL)) * T * R;
+      int g = (int)std::min<int64_t>(nb, 1 << 20);
+      hipLaunchKernelGGL(k_mttv_vec<TX>, dim3(g), dim3(64), 0, st_, X, L, J, T, R, B, ldb, out, rs,
+                         accumulate, scale);
+    } else {
+      int64_t nb = ((L + 63) / 64) * T * R;
+      int g = (int)std::min<int64_t>(nb, 32768);
+      hipLaunchKernelGGL(k_mttv_l<TX>, dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb, out, rs,
+                         accumulate, scale);
+    }
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+  }
+  void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
+            int R, double *out, int64_t out_rstride, int accumulate,
+            const double *out_scale) override {
     const double *B;
     int64_t ldb;
     if (nf == 1) {
@@ -447,21 +480,17 @@ class HipOps : public Ops {
       B = kb;
       ldb = J;
     }
-    prof_begin(1, (double)L * J * T * R * 8.0);
-    if (L == 1) {
-      int64_t nw = T * R;
-      int g = grid_for(nw * 64, 256, 8192);
-      hipLaunchKernelGGL(k_mttv_1, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out,
-                         out_rstride, accumulate);
-    } else {
-      int64_t nb = ((L + 63) / 64) * T * R;
-      int g = (int)std::min<int64_t>(nb, 32768);
-      hipLaunchKernelGGL(k_mttv_l, dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb, out,
-                         out_rstride, accumulate);
-    }
-    prof_end();
+    if (xdt == F32)
+      mttv_t<float>((const float *)X, L, J, T, R, B, ldb, out, out_rstride, accumulate, out_scale);
+    else
+      mttv_t<double>((const double *)X, L, J, T, R, B, ldb, out, out_rstride, accumulate,
+                     out_scale);
+  }
+  void scale_update(double *dst, const double *scales, unsigned mask, int set_one) override {
+    hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(64), 0, st_, dst, scales, mask, set_one);
     HIP_CHECK(hipGetLastError());
   }
+  const double *normalize_scales() override { return small(MAX_ORDER); }
 
   // ------------------------------------------------------------------ R x R side
   void gram(const double *W, int64_t rows, int64_t ld, int R, double *G) override {
@@ -568,7 +597,7 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
     if (nsplit > 1) {
       hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(J * J, 256)), dim3(256), 0, st_, dst, nsplit,
-                         J * J, J * J, 1, G, (int64_t)1, (int64_t)0);
+                         J * J, J * J, 1, G, (int64_t)1, (int64_t)0, 0);
       HIP_CHECK(hipGetLastError());
     }
   }

@@ -59,6 +59,15 @@ struct ScanTraits<double> {
   __device__ static inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 
+// typed result store: the scans accumulate in fp64 and write fp64 (tree nodes, slabs) or fp32
+// (the first-level intermediate of the multi-sweep schedule, stored in the tensor's own precision)
+__device__ inline void scan_store(double *base, int64_t idx, double v, int out32) {
+  if (out32)
+    reinterpret_cast<float *>(base)[idx] = (float)v;
+  else
+    base[idx] = v;
+}
+
 constexpr int SCAN_FLUSH = 4;  // k-blocks between fp32 -> fp64 flushes (chains of <= 64 terms)
 
 template <typename TV, bool ALIGNED>
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols) {
+    int64_t out_batch_stride, int ncols, int out32) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
     }
   }
 
-  double *__restrict__ o = out + split * out_split_stride + batch * out_batch_stride;
+  const int64_t obase = split * out_split_stride + batch * out_batch_stride;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
         for (int jj = 0; jj < VEC; jj++) {
           double val = (double)acc[jj][nt][r];
           if constexpr (TR::NEEDS_FLUSH) val += acc64[jj][nt][r];
-          if (m + jj < M) o[(int64_t)n * out_nstride + m + jj] = val;
+          if (m + jj < M) scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
         }
       }
     }
@@ -190,7 +199,7 @@ template <typename TV, int NT, bool ALIGNED, int UNROLL>
 __global__ __launch_bounds__(256) void k_scan_prefix(
     const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
     int nmb, double *__restrict__ out, int64_t out_kstride, int64_t out_nstride,
-    int64_t out_split_stride, int ncols) {
+    int64_t out_split_stride, int ncols, int out32) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix(
     }
   }
 
-  double *__restrict__ o = out + split * out_split_stride;
+  const int64_t obase = split * out_split_stride;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix(
       if (n < ncols && k_ok) {
         double val = (double)acc[0][nt][r] + (double)acc[1][nt][r];
         if constexpr (TR::NEEDS_FLUSH) val += acc64[nt][r];
-        o[(int64_t)n * out_nstride + k * out_kstride] = val;
+        scan_store(out, obase + (int64_t)n * out_nstride + k * out_kstride, val, out32);
       }
     }
 }
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols) {
+    int64_t out_batch_stride, int ncols, int out32) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   }
 #undef PPALS_LOAD_BLOCK
 
-  double *__restrict__ o = out + split * out_split_stride + batch * out_batch_stride;
+  const int64_t obase = split * out_split_stride + batch * out_batch_stride;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
             val = acc64[jj][nt][r];
           else
             val = (double)acc[jj][nt][r];
-          o[(int64_t)n * out_nstride + m + jj] = val;
+          scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
         }
       }
     }
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols) {
+    int64_t out_batch_stride, int ncols, int out32) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
   }
 #undef PPALS_BUF_LOAD
 
-  double *__restrict__ o = out + split * out_split_stride + batch * out_batch_stride;
+  const int64_t obase = split * out_split_stride + batch * out_batch_stride;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             val = acc64[jj][nt][r];
           else
             val = (double)acc[jj][nt][r];
-          o[(int64_t)n * out_nstride + m + jj] = val;
+          scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
         }
       }
     }
@@ -561,7 +570,7 @@ template <typename TV, int NT, int OPT = 0>
 __global__ __launch_bounds__(256) void k_scan_prefix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,
     int nmb, double *__restrict__ out, int64_t out_kstride, int64_t out_nstride,
-    int64_t out_split_stride, int ncols) {
+    int64_t out_split_stride, int ncols, int out32) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
   }
 #undef PPALS_LOAD_STEP
 
-  double *__restrict__ o = out + split * out_split_stride;
+  const int64_t obase = split * out_split_stride;
   double val[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
@@ -718,7 +727,8 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int n = 16 * nt + TR::row(lane, r);
-      if (n < ncols && k_ok) o[(int64_t)n * out_nstride + k * out_kstride] = val[nt][r];
+      if (n < ncols && k_ok)
+        scan_store(out, obase + (int64_t)n * out_nstride + k * out_kstride, val[nt][r], out32);
     }
 }
 
@@ -766,7 +776,7 @@ __global__ void k_krp_pack(TV *__restrict__ P, int nblk, int NT, int prefix_layo
 // out[m*out_mstride + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols
 __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64_t split_stride,
                               int64_t M, int ncols, double *__restrict__ out, int64_t out_mstride,
-                              int64_t out_rstride) {
+                              int64_t out_rstride, int out32) {
   const int64_t total = M * ncols;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -774,7 +784,7 @@ __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64
     const int64_t n = e / M;
     double s = 0;
     for (int sp = 0; sp < nsplit; sp++) s += slab[sp * split_stride + e];
-    out[m * out_mstride + out_rstride * n] = s;
+    scan_store(out, m * out_mstride + out_rstride * n, s, out32);
   }
 }
 

@@ -223,37 +223,91 @@ __global__ void k_krp(double *__restrict__ out, KrpArgs a, int64_t J, int col0, 
 }
 
 // ------------------------------------------------------------------ mttv (K3, K9, deeper tree nodes)
-// out[l + L*t + rs*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j + ldb*r]
+// out[l + L*t + rs*r] (+)= scale * sum_j X[l + L*(j + J*(t + T*r))] * B[j + ldb*r]
+// X is a cached intermediate that already carries the rank index: fp64 (tree nodes, PP operators)
+// or fp32 (the first-level intermediate of the multi-sweep schedule). `scale` (device scalar,
+// may be null) is the pending Normalize factor of a cached tensor (see engine.cpp, MSDT).
+__device__ inline double mttv_scale(const double *scale) { return scale ? *scale : 1.0; }
+
+// variant V (large L, L % VL == 0): one wave per (256*VL/4.. l-tile, t, r), 16-byte loads along l,
+// B[j,r] is wave-uniform. This is the streaming kernel for the s^(N-1) R intermediates.
+template <typename TX>
+__global__ __launch_bounds__(64) void k_mttv_vec(const TX *__restrict__ X, int64_t L, int64_t J,
+                                                 int64_t T, int R, const double *__restrict__ B,
+                                                 int64_t ldb, double *__restrict__ out, int64_t rs,
+                                                 int accumulate, const double *__restrict__ scale) {
+  constexpr int VL = 16 / sizeof(TX);
+  typedef TX vecx __attribute__((ext_vector_type(VL)));
+  const int lane = threadIdx.x;
+  const int64_t ltiles = (L + 64 * VL - 1) / (64 * VL);
+  const int64_t total = ltiles * T * R;
+  const double sc = mttv_scale(scale);
+  for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const int64_t lt = blk % ltiles;
+    const int64_t t = (blk / ltiles) % T;
+    const int r = (int)(blk / (ltiles * T));
+    const int64_t l = lt * 64 * VL + (int64_t)lane * VL;
+    if (l >= L) continue;
+    const TX *x = X + l + L * J * (t + T * (int64_t)r);
+    const double *b = B + ldb * r;
+    double acc[VL];
+#pragma unroll
+    for (int e = 0; e < VL; e++) acc[e] = 0;
+    int64_t j = 0;
+    for (; j + 3 < J; j += 4) {
+      vecx v0 = *reinterpret_cast<const vecx *>(x + L * j);
+      vecx v1 = *reinterpret_cast<const vecx *>(x + L * (j + 1));
+      vecx v2 = *reinterpret_cast<const vecx *>(x + L * (j + 2));
+      vecx v3 = *reinterpret_cast<const vecx *>(x + L * (j + 3));
+      const double b0 = b[j], b1 = b[j + 1], b2 = b[j + 2], b3 = b[j + 3];
+#pragma unroll
+      for (int e = 0; e < VL; e++)
+        acc[e] += ((double)v0[e] * b0 + (double)v1[e] * b1) + ((double)v2[e] * b2 + (double)v3[e] * b3);
+    }
+    for (; j < J; j++) {
+      vecx v0 = *reinterpret_cast<const vecx *>(x + L * j);
+      const double b0 = b[j];
+#pragma unroll
+      for (int e = 0; e < VL; e++) acc[e] += (double)v0[e] * b0;
+    }
+    double *o = out + l + L * t + rs * r;
+#pragma unroll
+    for (int e = 0; e < VL; e++) o[e] = accumulate ? (o[e] + sc * acc[e]) : sc * acc[e];
+  }
+}
+
 // variant L: block = 64 consecutive l for one (t,r); the 4 waves split the j range and combine
 // through LDS, so even a 200 x 200 x R leaf contraction spreads over hundreds of waves.
-__global__ __launch_bounds__(256) void k_mttv_l(const double *__restrict__ X, int64_t L, int64_t J,
+template <typename TX>
+__global__ __launch_bounds__(256) void k_mttv_l(const TX *__restrict__ X, int64_t L, int64_t J,
                                                 int64_t T, int R, const double *__restrict__ B,
                                                 int64_t ldb, double *__restrict__ out, int64_t rs,
-                                                int accumulate) {
+                                                int accumulate, const double *__restrict__ scale) {
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ltiles = (L + 63) / 64;
   const int64_t total = ltiles * T * R;
+  const double sc = mttv_scale(scale);
   for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
     const int64_t lt = blk % ltiles;
     const int64_t t = (blk / ltiles) % T;
     const int r = (int)(blk / (ltiles * T));
     const int64_t l = lt * 64 + lane;
-    const double *x = X + l + L * J * (t + T * (int64_t)r);
+    const TX *x = X + l + L * J * (t + T * (int64_t)r);
     const double *b = B + ldb * r;
     double s0 = 0, s1 = 0;
     if (l < L) {
       int64_t j = wave;
       for (; j + 4 < J; j += 8) {
-        s0 += x[L * j] * b[j];
-        s1 += x[L * (j + 4)] * b[j + 4];
+        s0 += (double)x[L * j] * b[j];
+        s1 += (double)x[L * (j + 4)] * b[j + 4];
       }
-      for (; j < J; j += 4) s0 += x[L * j] * b[j];
+      for (; j < J; j += 4) s0 += (double)x[L * j] * b[j];
     }
     part[wave][lane] = s0 + s1;
     __syncthreads();
     if (wave == 0 && l < L) {
-      const double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      const double s = sc * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
       double *o = out + l + L * t + rs * r;
       *o = accumulate ? (*o + s) : s;
     }
@@ -261,25 +315,38 @@ __global__ __launch_bounds__(256) void k_mttv_l(const double *__restrict__ X, in
   }
 }
 // variant 1 (L == 1): one wave per (t,r), lanes stride the contiguous j.
-__global__ void k_mttv_1(const double *__restrict__ X, int64_t J, int64_t T, int R,
+template <typename TX>
+__global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
                          const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
-                         int64_t rs, int accumulate) {
+                         int64_t rs, int accumulate, const double *__restrict__ scale) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t total = T * R;
+  const double sc = mttv_scale(scale);
   for (int64_t e = wid; e < total; e += nw) {
     const int64_t t = e % T;
     const int r = (int)(e / T);
-    const double *x = X + J * (t + T * (int64_t)r);
+    const TX *x = X + J * (t + T * (int64_t)r);
     const double *b = B + ldb * r;
     double s = 0;
-    for (int64_t j = lane; j < J; j += 64) s += x[j] * b[j];
+    for (int64_t j = lane; j < J; j += 64) s += (double)x[j] * b[j];
     s = wave_sum(s);
     if (lane == 0) {
       double *o = out + t + rs * r;
-      *o = accumulate ? (*o + s) : s;
+      *o = accumulate ? (*o + sc * s) : sc * s;
     }
+  }
+}
+
+// *dst *= prod_{m in mask} scales[m]  (pending Normalize factor of a cached tensor); set_one: 1.0
+__global__ void k_scale_update(double *__restrict__ dst, const double *__restrict__ scales,
+                               unsigned mask, int set_one) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double v = set_one ? 1.0 : *dst;
+    for (int m = 0; m < MAX_ORDER; m++)
+      if (mask & (1u << m)) v *= scales[m];
+    *dst = v;
   }
 }
 

@@ -92,9 +92,11 @@ class Ops {
   // single-mode TTM of the PP operator build (tstride=L, rstride=L*T: rank index last) and the
   // Tucker mode product that keeps the mode in place (tstride=L*R, rstride=L). V may also be a
   // cached fp64 intermediate (dt = F64).
+  // The result is written as fp64 (out_dt = F64) or fp32 (out_dt = F32, used for the large
+  // first-level intermediate of the multi-sweep schedule).
   virtual void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T,
-                             const FactorRef *f, int nf, int R, double *out, int64_t out_tstride,
-                             int64_t out_rstride) = 0;
+                             const FactorRef *f, int nf, int R, void *out, int out_dt,
+                             int64_t out_tstride, int64_t out_rstride) = 0;
   // Tucker mode product keeping the mode in place (fp64 in/out or V-typed in):
   //   out[l + L*(k + Kc*t)] = sum_j X[l,j,t] * W[j + ldw*k]      (als_Tucker.cxx:102,224)
   virtual void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
@@ -103,14 +105,20 @@ class Ops {
     f.ptr = W;
     f.rows = J;
     f.ld = ldw;
-    scan_contract(X, dt, L, J, T, &f, 1, Kc, out, L * Kc, L);
+    scan_contract(X, dt, L, J, T, &f, 1, Kc, out, F64, L * Kc, L);
   }
 
   // ---- contraction of a cached intermediate (fp64) that already carries the rank index ----
   //   out[l + L*t + out_rstride*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j,r]
   // B = KRP of `nf` factor refs (combined extent J). accumulate!=0: add into out.
-  virtual void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
-                    int R, double *out, int64_t out_rstride, int accumulate) = 0;
+  // X is fp64 or fp32 (xdt); out_scale (device scalar or nullptr) multiplies the contribution.
+  virtual void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
+                    int nf, int R, double *out, int64_t out_rstride, int accumulate,
+                    const double *out_scale) = 0;
+  // pending-Normalize bookkeeping of cached tensors: *dst = (set_one ? 1 : *dst) * prod_{m in
+  // mask} scales[m]; `scales` is what normalize() last applied (see normalize_scales()).
+  virtual void scale_update(double *dst, const double *scales, unsigned mask, int set_one) = 0;
+  virtual const double *normalize_scales() = 0;  // device array [N] written by normalize()
 
   // ---- R x R normal-equation side ----
   // G = W^T W  (rows x R, ld)  ->  G[R*R]

@@ -150,7 +150,7 @@ void TuckerEngine::compute_node(int idx) {
     f.rows = dims[m];
     f.ld = V_.glens[m];
     // out[l + Lout*(k + r*t)]: the mode product that keeps the mode in place (als_Tucker.cxx:224)
-    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, Lout * r_[m], Lout);
+    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, F64, Lout * r_[m], Lout);
     if (tmp) ops_.free(tmp);  // synchronises before freeing
     tmp = last ? nullptr : dst;
     cur = dst;

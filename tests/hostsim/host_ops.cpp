@@ -200,7 +200,7 @@ class HostOps : public Ops {
     std::copy(B.begin(), B.end(), out);
   }
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
-                     int nf, int R, double *out, int64_t ts, int64_t rs) override {
+                     int nf, int R, void *out, int out_dt, int64_t ts, int64_t rs) override {
     int64_t Jc;
     std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
     if (Jc != J) throw std::runtime_error("hostsim: scan_contract extent mismatch");
@@ -211,7 +211,7 @@ class HostOps : public Ops {
         for (int64_t l = 0; l < L; l++) {
           double acc = 0;
           for (int64_t j = 0; j < J; j++) acc += ld(V, dt, l + L * (j + J * t)) * B[j + J * r];
-          out[l + ts * t + rs * r] = acc;
+          st(out, out_dt, l + ts * t + rs * r, acc);
         }
   }
   void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
@@ -224,8 +224,9 @@ class HostOps : public Ops {
           out[l + L * (k + (int64_t)Kc * t)] = acc;
         }
   }
-  void mttv(const double *X, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
-            double *out, int64_t rs, int accumulate) override {
+  void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
+            int R, double *out, int64_t rs, int accumulate, const double *out_scale) override {
+    const double sc = out_scale ? *out_scale : 1.0;
     int64_t Jc;
     std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
     if (Jc != J) throw std::runtime_error("hostsim: mttv extent mismatch");
@@ -233,9 +234,10 @@ class HostOps : public Ops {
       for (int64_t t = 0; t < T; t++)
         for (int64_t l = 0; l < L; l++) {
           double acc = 0;
-          for (int64_t j = 0; j < J; j++) acc += X[l + L * (j + J * (t + T * r))] * B[j + J * r];
+          for (int64_t j = 0; j < J; j++)
+            acc += ld(X, xdt, l + L * (j + J * (t + T * r))) * B[j + J * r];
           double *o = out + l + L * t + rs * r;
-          *o = accumulate ? *o + acc : acc;
+          *o = accumulate ? *o + sc * acc : sc * acc;
         }
   }
   void gram(const double *W, int64_t rows, int64_t ldw, int R, double *G) override {
@@ -300,6 +302,14 @@ class HostOps : public Ops {
     for (int j = 0; j < R; j++)
       for (int64_t i = 0; i < rows; i++) Wnew[i + ldn * j] = out[i + rows * j];
   }
+  double nscales_[MAX_ORDER];
+  const double *normalize_scales() override { return nscales_; }
+  void scale_update(double *dst, const double *scales, unsigned mask, int set_one) override {
+    double v = set_one ? 1.0 : *dst;
+    for (int m = 0; m < MAX_ORDER; m++)
+      if (mask & (1u << m)) v *= scales[m];
+    *dst = v;
+  }
   void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) override {
     std::vector<double> nrm(N);
     double prod = 1;
@@ -312,6 +322,7 @@ class HostOps : public Ops {
     double c = std::pow(prod, 1.0 / N);
     for (int i = 0; i < N; i++) {
       double f = c / nrm[i];
+      nscales_[i] = f;
       for (int64_t e = 0; e < rows[i] * R; e++) W[i][e] *= f;
       for (int e = 0; e < R * R; e++) Gall[(size_t)i * R * R + e] *= f * f;
     }

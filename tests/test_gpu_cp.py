@@ -163,13 +163,16 @@ def test_jacobi_fallback_path(pp, tmp_path):
     c2.close()
 
 
+@pytest.mark.parametrize("schedule", ["msdt", "dt"])
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R,kind", [([12, 10, 9, 11], 4, "r"), ([12, 10, 9, 11], 4, "r2"),
                                          ([16, 16, 16, 16], 10, "r"), ([14, 9, 11], 3, "r"),
-                                         ([6, 5, 4, 5, 4, 3], 2, "r")])
-def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype):
+                                         ([6, 5, 4, 5, 4, 3], 2, "r"), ([9, 7, 8, 6, 5], 2, "r")])
+def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule, monkeypatch):
     """K sweeps of the HIP engine == K sweeps of alsCP_DT in the oracle (factor matrices within
-    1e-5 relative Frobenius for fp32 storage)"""
+    1e-5 relative Frobenius for fp32 storage), for both sweep schedules: the multi-sweep tree
+    (default: one tensor scan per N-1 mode updates) and the reference's two-node tree"""
+    monkeypatch.setenv("PPALS_DT_SCHEDULE", schedule)
     V, W = problem(lens, R, 3, kind)
     G = O.init_factors(lens, R, 99)
     K = 5

@@ -86,19 +86,19 @@ int main(int argc, char **argv) {
 #define SUFFIX(KERN, ns, per)                                                                     \
   [=]() {                                                                                         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)(n_mtiles * ns)), dim3(256), 0, 0, V, M, K, M * K, P, \
-                       n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * NT * M, (int64_t)0, R);    \
+                       n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * NT * M, (int64_t)0, R, 0); \
   }
 #define PREFIXI(KERN, nsp)                                                                        \
   [=]() {                                                                                         \
     int per_ = (nblk + (nsp)-1) / (nsp);                                                          \
     hipLaunchKernelGGL(KERN, dim3((unsigned)((K + 15) / 16), (unsigned)(nsp)), dim3(256), 0, 0, V, \
-                       M, K, P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R);        \
+                       M, K, P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R, 0);     \
   }
 #define PREFIX(KERN, nsp)                                                                        \
   [=]() {                                                                                        \
     int per_ = (nblk + (nsp)-1) / (nsp);                                                         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)ncolgrp, (unsigned)(nsp)), dim3(256), 0, 0, V, M, K, \
-                       P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R);             \
+                       P, per_, nblk, slab, (int64_t)1, K, (int64_t)16 * NT * K, R, 0);          \
   }
   if (NT == 1) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
