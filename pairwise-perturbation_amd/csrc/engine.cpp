@@ -263,7 +263,10 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ms_leaf_.assign(N_ - 1, -1);
     for (size_t k = 0; k < ms_nodes_.size(); k++)
       if (ms_nodes_[k].lo == ms_nodes_[k].hi) ms_leaf_[ms_nodes_[k].lo] = (int)k;
-    if (N_ == 2) ms_leaf_[0] = -1;
+    if (ms_nodes_.size() + 1 > 32) throw std::runtime_error("ppals: tensor order too large");
+    ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
+    ms_X_.slot = 0;
+    for (size_t k = 0; k < ms_nodes_.size(); k++) ms_nodes_[k].t.slot = (int)k + 1;
   }
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = (P_ == 1);
   build_tree(0, N_ - 1, -1);
@@ -299,10 +302,9 @@ CpEngine::~CpEngine() {
   ops_.free(Pbuf_);
   ops_.free(VT_);
   ops_.free(ms_X_.buf);
-  ops_.free(ms_X_.scale);
+  ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
     ops_.free(n.t.buf);
-    ops_.free(n.t.scale);
     for (auto &t : n.tmp) ops_.free(t.buf);
   }
 }
@@ -509,11 +511,19 @@ void CpEngine::normalize() {
   for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
   ops_.normalize(W_.data(), rows, N_, R_, G_);
   if (schedule_ == 1 && ms_root_ >= 0) {
-    // cached MSDT tensors were built from the un-normalised factors of their contracted modes
-    const double *sc = ops_.normalize_scales();
-    if (ms_X_.valid) ops_.scale_update(ms_X_.scale, sc, ms_X_.contracted, 0);
-    for (auto &n : ms_nodes_)
-      if (n.t.valid) ops_.scale_update(n.t.scale, sc, n.t.contracted, 0);
+    // cached MSDT tensors were built from the un-normalised factors of their contracted modes:
+    // one launch multiplies every live tensor's pending scalar by prod_{m contracted} f_m
+    unsigned masks[32] = {0}, active = 0, fresh = 0;
+    auto visit = [&](RTensor &t) {
+      if (!t.valid) return;
+      masks[t.slot] = t.contracted;
+      active |= 1u << t.slot;
+      if (!t.pending) fresh |= 1u << t.slot;
+      t.pending = true;
+    };
+    visit(ms_X_);
+    for (auto &n : ms_nodes_) visit(n.t);
+    if (active) ops_.scale_update_many(ms_scales_, ops_.normalize_scales(), masks, active, fresh);
   }
 }
 
@@ -555,7 +565,6 @@ void CpEngine::ms_reserve(RTensor &t, size_t bytes) {
     t.buf = ops_.alloc(bytes);
     t.cap = bytes;
   }
-  if (!t.scale) t.scale = (double *)ops_.alloc(sizeof(double));
 }
 
 // new step: X = V x_root W_root (one tensor scan, K1-type on whichever resident layout keeps the
@@ -592,7 +601,7 @@ void CpEngine::ms_start_step(int root) {
   ms_reserve(ms_X_, (size_t)L * T * R_ * dtype_size(ms_X_.dt));
   FactorRef f = fref(root, W_.data());
   ops_.scan_contract(src, V_.dtype, L, ext(root), T, &f, 1, R_, ms_X_.buf, ms_X_.dt, L, L * T);
-  ops_.scale_update(ms_X_.scale, nullptr, 0, 1);
+  ms_X_.pending = false;
   ms_X_.valid = true;
 }
 
@@ -640,11 +649,11 @@ void CpEngine::ms_compute(int idx) {
   const RTensor *cur = src;
   for (size_t k = 0; k < sib.size(); k++) {
     RTensor &dst = (k + 1 == sib.size()) ? n.t : n.tmp[k];
-    ms_contract(*cur, sib[k], dst, k == 0 ? src->scale : nullptr);
+    ms_contract(*cur, sib[k], dst, k == 0 ? ms_scale_of(*src) : nullptr);
     cur = &dst;
   }
   if (sib.empty()) throw std::runtime_error("ppals: empty sibling set in the multi-sweep tree");
-  ops_.scale_update(n.t.scale, nullptr, 0, 1);
+  n.t.pending = false;
   n.t.valid = true;
 }
 

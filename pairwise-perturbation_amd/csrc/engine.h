@@ -102,7 +102,8 @@ class CpEngine {
     int dt = F64;
     std::vector<int> modes;
     unsigned contracted = 0;
-    double *scale = nullptr;
+    int slot = -1;         // index into ms_scales_ (device scalars)
+    bool pending = false;  // a Normalize happened after this tensor was built: scale is owed
     bool valid = false;
   };
   struct MsNode {
@@ -123,6 +124,8 @@ class CpEngine {
   std::vector<MsNode> ms_nodes_;
   std::vector<int> ms_order_;  // the N-1 modes of the step in update order
   std::vector<int> ms_leaf_;   // node index of each list position
+  double *ms_scales_ = nullptr;  // one pending-Normalize scalar per cached tensor (<= 32)
+  const double *ms_scale_of(const RTensor &t) const { return t.pending ? ms_scales_ + t.slot : nullptr; }
 
   int64_t ext(int m) const { return m == 0 ? V_.llens[0] : V_.glens[m]; }
   FactorRef fref(int m, double *const *W) const;

@@ -303,7 +303,9 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       double *o = out32 ? (double *)((float *)out + (int64_t)col0 * out_rstride)
                         : out + (int64_t)col0 * out_rstride;
-      const double bytes = (double)L * (double)J * (double)T * sizeof(TV);
+      // algorithmic bytes of the launch: one read of the scanned tensor + the result it must write
+      const double bytes = (double)L * (double)J * (double)T * sizeof(TV) +
+                           (double)L * (double)T * ncols * (out32 ? 4.0 : 8.0);
       if (prefix) {
         // out[t + rs*n] = sum_j V[j + J*t] * B[j,n]      (M = J rows reduced, K = T columns)
         const int64_t M = J, K = T;
@@ -488,6 +490,14 @@ class HipOps : public Ops {
   }
   void scale_update(double *dst, const double *scales, unsigned mask, int set_one) override {
     hipLaunchKernelGGL(k_scale_update, dim3(1), dim3(64), 0, st_, dst, scales, mask, set_one);
+    HIP_CHECK(hipGetLastError());
+  }
+  void scale_update_many(double *dst, const double *scales, const unsigned *masks, unsigned active,
+                         unsigned fresh) override {
+    ScaleMasks sm;
+    for (int k = 0; k < 32; k++) sm.m[k] = masks[k];
+    hipLaunchKernelGGL(k_scale_update_many, dim3(1), dim3(64), 0, st_, dst, scales, sm, active,
+                       fresh);
     HIP_CHECK(hipGetLastError());
   }
   const double *normalize_scales() override { return small(MAX_ORDER); }

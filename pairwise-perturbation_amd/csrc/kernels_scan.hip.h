@@ -414,21 +414,40 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   }
 #undef PPALS_LOAD_BLOCK
 
+  // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per column
+  // (16 lanes x VEC rows = 16*VEC contiguous elements); scalar stores only for unaligned strides
   const int64_t obase = split * out_split_stride + batch * out_batch_stride;
+  const bool vec_ok = (((obase | out_nstride) & (VEC - 1)) == 0);
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int n = 16 * nt + TR::row(lane, r);
       if (n < ncols && m < M) {
+        double val[VEC];
 #pragma unroll
         for (int jj = 0; jj < VEC; jj++) {
-          double val;
           if constexpr (TR::NEEDS_FLUSH)
-            val = acc64[jj][nt][r];
+            val[jj] = acc64[jj][nt][r];
           else
-            val = (double)acc[jj][nt][r];
-          scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
+            val[jj] = (double)acc[jj][nt][r];
+        }
+        const int64_t idx = obase + (int64_t)n * out_nstride + m;
+        if (vec_ok && out32) {
+          typedef float ovec_t __attribute__((ext_vector_type(VEC)));
+          ovec_t ov;
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
+          *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+        } else if (vec_ok) {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj += 2) {
+            f64x2 ov = {val[jj], val[jj + 1]};
+            *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
         }
       }
     }
@@ -546,21 +565,40 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
   }
 #undef PPALS_BUF_LOAD
 
+  // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per column
+  // (16 lanes x VEC rows = 16*VEC contiguous elements); scalar stores only for unaligned strides
   const int64_t obase = split * out_split_stride + batch * out_batch_stride;
+  const bool vec_ok = (((obase | out_nstride) & (VEC - 1)) == 0);
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int n = 16 * nt + TR::row(lane, r);
       if (n < ncols && m < M) {
+        double val[VEC];
 #pragma unroll
         for (int jj = 0; jj < VEC; jj++) {
-          double val;
           if constexpr (TR::NEEDS_FLUSH)
-            val = acc64[jj][nt][r];
+            val[jj] = acc64[jj][nt][r];
           else
-            val = (double)acc[jj][nt][r];
-          scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
+            val[jj] = (double)acc[jj][nt][r];
+        }
+        const int64_t idx = obase + (int64_t)n * out_nstride + m;
+        if (vec_ok && out32) {
+          typedef float ovec_t __attribute__((ext_vector_type(VEC)));
+          ovec_t ov;
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
+          *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+        } else if (vec_ok) {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj += 2) {
+            f64x2 ov = {val[jj], val[jj + 1]};
+            *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
         }
       }
     }

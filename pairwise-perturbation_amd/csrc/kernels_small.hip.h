@@ -340,6 +340,19 @@ __global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
 }
 
 // *dst *= prod_{m in mask} scales[m]  (pending Normalize factor of a cached tensor); set_one: 1.0
+struct ScaleMasks {
+  unsigned m[32];
+};
+__global__ void k_scale_update_many(double *__restrict__ dst, const double *__restrict__ scales,
+                                    ScaleMasks masks, unsigned active, unsigned fresh) {
+  const int k = threadIdx.x;
+  if (k < 32 && ((active >> k) & 1u)) {
+    double v = ((fresh >> k) & 1u) ? 1.0 : dst[k];
+    for (int m = 0; m < MAX_ORDER; m++)
+      if (masks.m[k] & (1u << m)) v *= scales[m];
+    dst[k] = v;
+  }
+}
 __global__ void k_scale_update(double *__restrict__ dst, const double *__restrict__ scales,
                                unsigned mask, int set_one) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

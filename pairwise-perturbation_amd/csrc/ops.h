@@ -118,6 +118,13 @@ class Ops {
   // pending-Normalize bookkeeping of cached tensors: *dst = (set_one ? 1 : *dst) * prod_{m in
   // mask} scales[m]; `scales` is what normalize() last applied (see normalize_scales()).
   virtual void scale_update(double *dst, const double *scales, unsigned mask, int set_one) = 0;
+  // the same for up to 32 scalars in one launch: dst[k] for every k with (active >> k) & 1;
+  // entries with (fresh >> k) & 1 start from 1.0 instead of their old value
+  virtual void scale_update_many(double *dst, const double *scales, const unsigned *masks,
+                                 unsigned active, unsigned fresh) {
+    for (int k = 0; k < 32; k++)
+      if ((active >> k) & 1u) scale_update(dst + k, scales, masks[k], (fresh >> k) & 1u);
+  }
   virtual const double *normalize_scales() = 0;  // device array [N] written by normalize()
 
   // ---- R x R normal-equation side ----
