@@ -60,6 +60,7 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
+    if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
   }
   ~HipOps() override {
     hipSetDevice(dev_);
@@ -393,9 +394,11 @@ class HipOps : public Ops {
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
-#define LAUNCH_SUFFIX_BUF(NTv)                                                                   \
-  hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
+        // persistent launch: each workgroup walks over ~4+ tiles when there are many
+        dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
+#define LAUNCH_SUFFIX_BUF(NTv)                                                                     \
+  hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks)
         // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
@@ -722,7 +725,7 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0;
+  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 20;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
 typedef unsigned int scan_u32x4 __attribute__((vector_size(16)));
 
 template <typename TV, int NT, int OPT = 1>
-__global__ __launch_bounds__(256) void k_scan_suffix_buf(
+__global__ __launch_bounds__(256) void k_scan_suffix_buf_v1(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
@@ -602,6 +602,181 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
         }
       }
     }
+}
+
+// Persistent form: a workgroup walks over tiles id = blockIdx.x, blockIdx.x + gridDim.x, ... and the
+// first block of the NEXT tile is requested while the last block of the current one is multiplied
+// and its results are stored, so the load pipeline never drains at a tile boundary. This matters
+// for the single-mode contractions of the multi-sweep schedule, where a tile has only K/16 = 13
+// blocks (cfg2) and pipeline fill + drain + workgroup launch were ~10 % of its lifetime.
+template <typename TV, int NT, int OPT = 1>
+__global__ __launch_bounds__(256) void k_scan_suffix_buf(
+    const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
+    const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
+    double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
+    int64_t out_batch_stride, int ncols, int out32, int64_t ntiles) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  typedef typename TR::acc acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int KB = 4 * VEC;
+  constexpr int FLUSH = 4;
+  constexpr int AUXV = (OPT & 1) ? 2 : 0;  // nt: streamed once, keep the packed operand in L2
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const int voffP = (int)((g * 16 + j16) * VEC * (int)sizeof(TV));
+  const int64_t block_bytes = (int64_t)KB * M * (int64_t)sizeof(TV);
+  const int64_t total_bytes = K * M * (int64_t)sizeof(TV);
+  const int ustep = (int)((int64_t)4 * M * (int64_t)sizeof(TV));
+  const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)P, 0, (int)((int64_t)nkb * NT * (4 * 16 * VEC) * (int64_t)sizeof(TV)), 0x00020000);
+
+  // per-tile state: rows of this lane, its byte offset, the block range and the batch base
+  struct Tile {
+    int64_t m, obase;
+    const TV *vbase;
+    int voff, kb0, kb1;
+    bool live;
+  };
+  auto decode = [&](int64_t id, Tile &t) {
+    int64_t b = id;
+    const int mtile = (int)(b % n_mtiles);
+    b /= n_mtiles;
+    const int split = (int)(b % nsplit);
+    const int64_t batch = b / nsplit;
+    const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
+    t.live = m0 < M;  // wave-uniform
+    t.m = m0 + (int64_t)VEC * j16;
+    const int64_t m_ld = t.live ? min(t.m, M - VEC) : 0;  // clamped: lanes past the edge re-read
+    t.voff = (int)(((int64_t)g * M + m_ld) * (int64_t)sizeof(TV));
+    t.kb0 = split * kb_per_split;
+    t.kb1 = min(nkb, t.kb0 + kb_per_split);
+    t.vbase = V + batch * batch_stride;
+    t.obase = split * out_split_stride + batch * out_batch_stride;
+  };
+#define PPALS_BUF_LOAD(vbase_, voff_, kb_, vv_, bb_)                                           \
+  {                                                                                            \
+    const int64_t boff_ = (int64_t)(kb_)*block_bytes;                                          \
+    const int64_t rem_ = total_bytes - boff_;                                                  \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                      \
+        (void *)((const char *)(vbase_) + boff_), 0, (int)min(rem_, block_bytes), 0x00020000); \
+    _Pragma("unroll") for (int u = 0; u < VEC; u++) vv_[u] = __builtin_bit_cast(               \
+        vec, __builtin_amdgcn_raw_buffer_load_b128(rs_, voff_, u * ustep, AUXV));              \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bb_[nt] = __builtin_bit_cast(            \
+        vec, __builtin_amdgcn_raw_buffer_load_b128(                                            \
+                 rsrcP, voffP, (int)(((kb_)*NT + nt) * (4 * 16 * VEC) * (int)sizeof(TV)), 0)); \
+  }
+
+  Tile cur, nxt;
+  int64_t id = blockIdx.x;
+  for (; id < ntiles; id += gridDim.x) {  // first live tile of this wave
+    decode(id, cur);
+    if (cur.live && cur.kb0 < cur.kb1) break;
+  }
+  if (id >= ntiles) return;
+  vec cv[VEC], cb[NT];
+  PPALS_BUF_LOAD(cur.vbase, cur.voff, cur.kb0, cv, cb);
+
+  for (;;) {
+    bool has_next = false;
+    int64_t nid = id + gridDim.x;
+    for (; nid < ntiles; nid += gridDim.x) {
+      decode(nid, nxt);
+      if (nxt.live && nxt.kb0 < nxt.kb1) {
+        has_next = true;
+        break;
+      }
+    }
+    acc_t acc[VEC][NT];
+    double acc64[TR::NEEDS_FLUSH ? VEC : 1][TR::NEEDS_FLUSH ? NT : 1][4];
+#pragma unroll
+    for (int a = 0; a < VEC; a++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
+        if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
+        }
+      }
+    for (int kc = cur.kb0; kc < cur.kb1; kc += FLUSH) {
+      const int ke = min(cur.kb1, kc + FLUSH);
+      for (int kb = kc; kb < ke; kb++) {
+        vec nv[VEC], nb[NT];
+        // what to request next: the following block of this tile, else the first block of the
+        // next tile, else (very last block of the wave) this block again
+        const bool same = kb + 1 < cur.kb1;
+        const TV *pv = (same || !has_next) ? cur.vbase : nxt.vbase;
+        const int po = (same || !has_next) ? cur.voff : nxt.voff;
+        const int pk = same ? kb + 1 : (has_next ? nxt.kb0 : kb);
+        PPALS_BUF_LOAD(pv, po, pk, nv, nb);
+#pragma unroll
+        for (int u = 0; u < VEC; u++)
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+              acc[jj][nt] = TR::mfma(cb[nt][u], cv[u][jj], acc[jj][nt]);
+#pragma unroll
+        for (int u = 0; u < VEC; u++) cv[u] = nv[u];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) cb[nt] = nb[nt];
+      }
+      if constexpr (TR::NEEDS_FLUSH) {
+#pragma unroll
+        for (int a = 0; a < VEC; a++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              acc64[a][nt][r] += (double)acc[a][nt][r];
+              acc[a][nt][r] = 0;
+            }
+      }
+    }
+    // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per
+    // column (16 lanes x VEC rows contiguous); scalar stores only for unaligned strides
+    const bool vec_ok = (((cur.obase | out_nstride) & (VEC - 1)) == 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = 16 * nt + TR::row(lane, r);
+        if (n < ncols && cur.m < M) {
+          double val[VEC];
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) {
+            if constexpr (TR::NEEDS_FLUSH)
+              val[jj] = acc64[jj][nt][r];
+            else
+              val[jj] = (double)acc[jj][nt][r];
+          }
+          const int64_t idx = cur.obase + (int64_t)n * out_nstride + cur.m;
+          if (vec_ok && out32) {
+            typedef float ovec_t __attribute__((ext_vector_type(VEC)));
+            ovec_t ov;
+#pragma unroll
+            for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
+            *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+          } else if (vec_ok) {
+#pragma unroll
+            for (int jj = 0; jj < VEC; jj += 2) {
+              f64x2 ov = {val[jj], val[jj + 1]};
+              *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
+            }
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
+          }
+        }
+      }
+    if (!has_next) break;
+    cur = nxt;
+    id = nid;
+  }
+#undef PPALS_BUF_LOAD
 }
 
 template <typename TV, int NT, int OPT = 0>

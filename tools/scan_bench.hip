@@ -104,9 +104,8 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 1, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf nt           x8", SUFFIX((k_scan_suffix_buf<float, 1, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf              x8", SUFFIX((k_scan_suffix_buf<float, 1, 0>), ns8, per8), {}});
-    vs.push_back({"suffix buf nt          x12", SUFFIX((k_scan_suffix_buf<float, 1, 1>), ns12, per12), {}});
+    vs.push_back({"suffix buf v1 nt        x8", SUFFIX((k_scan_suffix_buf_v1<float, 1, 1>), ns8, per8), {}});
+    vs.push_back({"suffix buf v1 nt       x12", SUFFIX((k_scan_suffix_buf_v1<float, 1, 1>), ns12, per12), {}});
     vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 1, 3>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x4", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns4, per4), {}});
     vs.push_back({"suffix fast nt         x16", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns16, per16), {}});
@@ -125,13 +124,38 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 2, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf nt           x8", SUFFIX((k_scan_suffix_buf<float, 2, 1>), ns8, per8), {}});
+    vs.push_back({"suffix buf v1 nt        x8", SUFFIX((k_scan_suffix_buf_v1<float, 2, 1>), ns8, per8), {}});
     vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 2, true, 4>), 1), {}});
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
     vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 2, 4>), 1), {}});
     vs.push_back({"prefix fast perm    split2", PREFIX((k_scan_prefix_fast<float, 2, 4>), 2), {}});
     vs.push_back({"prefix fast il+perm split1", PREFIXI((k_scan_prefix_fast<float, 2, 12>), 1), {}});
     vs.push_back({"prefix fast il+p+nt split1", PREFIXI((k_scan_prefix_fast<float, 2, 13>), 1), {}});
+  }
+  // single-mode TTM regime of the multi-sweep schedule: M = s^3 rows, K = s, fp32 result
+  if (argc > 4 && NT == 1) {
+    vs.clear();
+    const int64_t M3 = (int64_t)s * s * s, K1 = s;
+    const int nblk1 = (int)((K1 + 15) / 16);
+    const int n_mt = (int)((M3 + 255) / 256);
+    auto ttm = [=](int which, int mult) {
+      return [=]() {
+        if (which == 0)
+          hipLaunchKernelGGL((k_scan_suffix_buf_v1<float, 1, 1>), dim3((unsigned)n_mt), dim3(256), 0,
+                             0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3, (int64_t)0,
+                             (int64_t)0, R, 1);
+        else
+          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
+                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
+                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
+                             (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);
+      };
+    };
+    vs.push_back({"ttm buf v1 (1 tile/WG)  x1", ttm(0, 0), {}});
+    vs.push_back({"ttm buf persistent      x5", ttm(1, 5), {}});
+    vs.push_back({"ttm buf persistent     x10", ttm(1, 10), {}});
+    vs.push_back({"ttm buf persistent     x20", ttm(1, 20), {}});
+    vs.push_back({"ttm buf persistent     x40", ttm(1, 40), {}});
   }
   // a plain streaming read of V as the practical ceiling on this device
   hipEvent_t e0, e1;
@@ -156,7 +180,9 @@ int main(int argc, char **argv) {
   printf("%-28s %9s %9s %10s %12s\n", "variant", "med ms", "min ms", "GB/s(med)", "max rel diff");
   for (auto &v : vs) {
     v.kind = v.name.rfind("prefix", 0) == 0 ? 1 : 0;
-    if (v.kind == 0) {
+    if (v.name.rfind("ttm", 0) == 0) {
+      v.nsplit = 1;
+    } else if (v.kind == 0) {
       int mult = atoi(v.name.c_str() + v.name.rfind('x') + 1);
       int ns, per;
       suffix_cfg(mult, ns, per);
@@ -169,10 +195,15 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     std::vector<double> acc(NCHK, 0.0), tmp(NCHK);
     const int64_t stride = (int64_t)16 * NT * (v.kind == 0 ? M : K);
-    for (int sp = 0; sp < v.nsplit; sp++) {
-      CK(hipMemcpy(tmp.data(), slab + sp * stride, sizeof(double) * NCHK, hipMemcpyDeviceToHost));
-      for (int i = 0; i < NCHK; i++) acc[i] += tmp[i];
-    }
+    if (v.name.rfind("ttm", 0) == 0) {  // fp32 result, one slab
+      std::vector<float> tf(NCHK);
+      CK(hipMemcpy(tf.data(), slab, sizeof(float) * NCHK, hipMemcpyDeviceToHost));
+      for (int i = 0; i < NCHK; i++) acc[i] = tf[i];
+    } else
+      for (int sp = 0; sp < v.nsplit; sp++) {
+        CK(hipMemcpy(tmp.data(), slab + sp * stride, sizeof(double) * NCHK, hipMemcpyDeviceToHost));
+        for (int i = 0; i < NCHK; i++) acc[i] += tmp[i];
+      }
     double maxrel = 0;
     if (ref[v.kind].empty())
       ref[v.kind] = acc;
