@@ -117,7 +117,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PPALS_FORCE_COMM=1 (tests): take the N > 1 route — process group, unique-id broadcast, RCCL
+    # communicator, sharded engine paths — even with a single rank
+    use_comm = world > 1 or os.environ.get("PPALS_FORCE_COMM", "0") == "1"
+    if use_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -125,7 +130,7 @@ def main():
     lens, R = WORKLOADS[args.workload]
     dtype = ppals.F32 if args.dtype == "f32" else ppals.F64
     ctx = ppals.Context(local_rank)
-    if world > 1:
+    if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(ppals.Context.unique_id()), dtype=torch.uint8))
@@ -191,7 +196,8 @@ def main():
                                    "U(0,1) factors), -pp 0 exact DT sweep incl. Normalize; tensor "
                                    f"stored {args.dtype} in HBM, factor/Gram/solve math fp64; "
                                    f"sweep schedule {schedule} (same ALS iterates either way)",
-                       "lens": lens, "rank": R, "sharding": f"leading-mode block x{world}"},
+                       "lens": lens, "rank": R, "sharding": f"leading-mode block x{world}",
+                       "comm": "rccl" if use_comm else "none"},
             "mttkrp_tflops": flops * sweeps_s / 1e12,
             "sweep_flops": flops,
             "final_gradnorm": gradnorm,

@@ -224,6 +224,7 @@ double tensor_norm(Ops &ops, Comm &comm, const TensorDesc &V) {
 // ============================================================================ CpEngine
 CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     : ops_(ops), comm_(comm), V_(V), N_(V.order), R_(R), P_(comm.size()), rank_(comm.rank()) {
+  dist_ = P_ > 1 || (force_comm_path() && !comm.is_self());
   if (R <= 0) throw std::runtime_error("ppals: rank must be positive");
   W_.resize(N_);
   gradW_.resize(N_);
@@ -247,7 +248,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   gradsq_ = (double *)ops_.alloc(sizeof(double) * MAX_ORDER);
   scal_ = (double *)ops_.alloc(sizeof(double) * 4 * MAX_ORDER);
   ops_.zero(gradsq_, sizeof(double) * MAX_ORDER);
-  if (P_ > 1) {
+  if (dist_) {
     size_t n = sizeof(double) * (size_t)maxblk_ * P_ * R_;
     sendbuf_ = (double *)ops_.alloc(n);
     recvbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxblk_ * R_);
@@ -268,7 +269,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ms_X_.slot = 0;
     for (size_t k = 0; k < ms_nodes_.size(); k++) ms_nodes_[k].t.slot = (int)k + 1;
   }
-  for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = (P_ == 1);
+  for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
   leaf_.assign(N_, -1);
   for (size_t k = 0; k < nodes_.size(); k++)
@@ -439,7 +440,7 @@ void CpEngine::get_factors(double *Wflat, double *gradWflat) {
       w += n;
     }
     if (g) {
-      if (P_ > 1 && grad_from_sweep_ && !grad_replicated_[i]) {
+      if (dist_ && grad_from_sweep_ && !grad_replicated_[i]) {
         // every rank holds only its own row block of grad_W: gather it
         const int64_t blk = block_rows(V_.glens[i], P_);
         ops_.pack_blocks(gradW_[i], V_.glens[i], V_.glens[i], R_, blk, P_, gatherbuf_);
@@ -458,7 +459,7 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
                            double ratio) {
   const int64_t s = V_.glens[i];
   double *Gi = G_ + (size_t)i * R_ * R_;
-  if (P_ == 1) {
+  if (!dist_) {
     ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
                         pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
     return;
@@ -690,7 +691,7 @@ void CpEngine::sweep_dt(double lambda) {
 }
 
 double CpEngine::allreduce_scalar(double x) {
-  if (P_ == 1) return x;
+  if (!dist_) return x;
   ops_.h2d(scal_, &x, sizeof(double));
   comm_.allreduce_sum(scal_, 1);
   double y = 0;
@@ -714,7 +715,7 @@ double CpEngine::residual() {
   if (!Pbuf_) Pbuf_ = (double *)ops_.alloc(sizeof(double) * K * R_);
   split_krp(ops_, V_, R_, W_.data(), Qbuf_, Pbuf_, &M, &K);
   ops_.residual_sq(V_.data, V_.dtype, M, K, Qbuf_, Pbuf_, R_, scal_);
-  if (P_ > 1) comm_.allreduce_sum(scal_, 1);
+  if (dist_) comm_.allreduce_sum(scal_, 1);
   double h = 0;
   ops_.d2h(&h, scal_, sizeof(double));
   return std::sqrt(h);
@@ -746,7 +747,7 @@ void CpEngine::mttkrp(int mode, double *M_host) {
   compute_node(leaf_[mode]);
   const Node &lf = nodes_[leaf_[mode]];
   const int64_t s = V_.glens[mode];
-  if (P_ == 1) {
+  if (!dist_) {
     ops_.d2h(M_host, lf.buf, sizeof(double) * s * R_);
     return;
   }

@@ -3,6 +3,7 @@
 // which collective, when to restart — the part the reference implements in als_CP.cxx.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -23,6 +24,12 @@ struct TensorDesc {
 
 // leading-mode block partition shared by the tensor shard and the factor-matrix row blocks
 inline int64_t block_rows(int64_t s, int P) { return (s + P - 1) / P; }
+// PPALS_FORCE_COMM=1: run the sharded code paths (pack, reduce-scatter, all-gather, all-reduce) even
+// with one rank, so a single-GPU box exercises the RCCL plumbing end to end (tests only)
+inline bool force_comm_path() {
+  const char *v = getenv("PPALS_FORCE_COMM");
+  return v && atoi(v) != 0;
+}
 
 int tensor_create(Ops &ops, Comm &comm, int order, const int64_t *glens, int dtype,
                   TensorDesc *out, std::string *err);
@@ -153,6 +160,7 @@ class CpEngine {
   Comm &comm_;
   TensorDesc V_;
   int N_, R_, P_, rank_;
+  bool dist_ = false;  // take the collective code paths (P_ > 1, or PPALS_FORCE_COMM=1 for tests)
   std::vector<double *> W_, gradW_, Wprev_, Winit_, dW_, dM_, Mm_;
   double *G_ = nullptr;       // N Gram matrices, R*R each
   double *S_ = nullptr, *Sinv_ = nullptr;

@@ -759,7 +759,10 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             ovec_t ov;
 #pragma unroll
             for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
-            *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+            if constexpr (OPT & 8)  // result is consumed much later and exceeds the L2: stream it
+              __builtin_nontemporal_store(ov, reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx));
+            else
+              *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
           } else if (vec_ok) {
 #pragma unroll
             for (int jj = 0; jj < VEC; jj += 2) {

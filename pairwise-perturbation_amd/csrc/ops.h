@@ -188,6 +188,7 @@ class Comm {
   virtual ~Comm() {}
   virtual int rank() const = 0;
   virtual int size() const = 0;
+  virtual bool is_self() const { return false; }  // the no-op single-process communicator
   // all on "device" pointers of the paired Ops, fp64, stream-ordered with the Ops' stream
   virtual void allreduce_sum(double *buf, int64_t n) = 0;
   virtual void reduce_scatter_sum(const double *send, double *recv, int64_t recvcount) = 0;
@@ -198,6 +199,7 @@ class SelfComm : public Comm {
  public:
   int rank() const override { return 0; }
   int size() const override { return 1; }
+  bool is_self() const override { return true; }
   void allreduce_sum(double *, int64_t) override {}
   void reduce_scatter_sum(const double *, double *, int64_t) override {}
   void allgather(const double *, double *, int64_t) override {}

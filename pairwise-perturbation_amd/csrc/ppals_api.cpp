@@ -82,7 +82,9 @@ int ppals_get_unique_id(void *out128) {
 int ppals_ctx_init_comm(ppals_ctx *ctx, int rank, int nranks, const void *uid) {
   if (!ctx) return fail(PPALS_ERR_ARG, "ctx is NULL");
   API_BEGIN
-  if (nranks <= 1) return PPALS_OK;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PPALS_ERR_ARG, "bad rank / nranks");
+  // one rank needs no communicator; PPALS_FORCE_COMM=1 (tests) still builds a real one
+  if (nranks == 1 && !force_comm_path()) return PPALS_OK;
   ctx->comm = backend_make_comm(ctx->ops, rank, nranks, uid);
   return PPALS_OK;
   API_END(PPALS_ERR_COMM)

@@ -28,6 +28,7 @@ static double now() {
 TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int *ranks)
     : ops_(ops), comm_(comm), V_(V), N_(V.order) {
   P_ = comm.size();
+  dist_ = P_ > 1 || (force_comm_path() && !comm.is_self());
   rank_ = comm.rank();
   int64_t maxs = 0;
   for (int i = 0; i < N_; i++) {
@@ -124,7 +125,7 @@ void TuckerEngine::compute_node(int idx) {
   int cur_dt = dt;
   // the sharded leaf of mode 0 is written with leading dimension blk (= rows per rank) so that it
   // is directly one block of the all-gather buffer (rows beyond the local extent stay zero)
-  const bool leaf0_blocked = (P_ > 1 && n.lo == 0 && n.hi == 0);
+  const bool leaf0_blocked = (dist_ && n.lo == 0 && n.hi == 0);
   const int64_t blk = block_rows(V_.glens[0], P_);
   for (int m = n.slo; m <= n.shi; m++) {
     int64_t L = 1, T = 1;
@@ -163,7 +164,7 @@ void TuckerEngine::compute_node(int idx) {
 // Make a leaf tensor complete on every rank. i == 0: the rows live on their owners -> all-gather
 // of the [blk x rest] blocks, re-assembled to [s0 x rest]. i != 0: partial sums -> all-reduce.
 double *TuckerEngine::complete_leaf(int i, double *Yloc, int64_t elems_local) {
-  if (P_ == 1) return Yloc;
+  if (!dist_) return Yloc;
   if (i != 0) {
     comm_.allreduce_sum(Yloc, elems_local);
     return Yloc;
@@ -217,7 +218,7 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
   int64_t e;
   double *Y = ttmc_chain(skip, &e);
   // sharded: skip == 0 returns the local rows, every other result is summed over the ranks
-  if (P_ > 1 && skip != 0) comm_.allreduce_sum(Y, e);
+  if (dist_ && skip != 0) comm_.allreduce_sum(Y, e);
   if (Yhost) ops_.d2h(Yhost, Y, sizeof(double) * e);
   ops_.free(Y);
   return e;
@@ -226,7 +227,7 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
 void TuckerEngine::compute_core_full() {
   int64_t e;
   double *Y = ttmc_chain(-1, &e);
-  if (P_ > 1) comm_.allreduce_sum(Y, ncore_);
+  if (dist_) comm_.allreduce_sum(Y, ncore_);
   ops_.d2d(core_, Y, sizeof(double) * ncore_);
   ops_.free(Y);
 }
@@ -258,7 +259,7 @@ void TuckerEngine::hosvd() {
     int64_t L = 1, T = 1;
     for (int q = 0; q < i; q++) L *= ext(q);
     for (int q = i + 1; q < N_; q++) T *= ext(q);
-    if (P_ > 1 && i == 0) {
+    if (dist_ && i == 0) {
       // the Gram of the sharded mode needs every pair of rows: gather the shards once (needs room
       // for two extra copies of the tensor; HOSVD is a one-off initialisation)
       const int64_t s0 = V_.glens[0], blk = block_rows(s0, P_);
@@ -277,7 +278,7 @@ void TuckerEngine::hosvd() {
       ops_.free(full);
     } else {
       ops_.unfold_gram(V_.data, V_.dtype, L, V_.glens[i], T, G_);
-      if (P_ > 1) comm_.allreduce_sum(G_, V_.glens[i] * V_.glens[i]);
+      if (dist_) comm_.allreduce_sum(G_, V_.glens[i] * V_.glens[i]);
     }
     ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
   }
@@ -350,7 +351,7 @@ double TuckerEngine::residual() {
   int64_t M = 1;
   for (int m = 0; m < N_ - 1; m++) M *= ext(m);
   ops_.residual_sq(V_.data, V_.dtype, M, V_.glens[N_ - 1], cur, W_[N_ - 1], r_[N_ - 1], scal_ + 2);
-  if (P_ > 1) comm_.allreduce_sum(scal_ + 2, 1);
+  if (dist_) comm_.allreduce_sum(scal_ + 2, 1);
   double h = 0;
   ops_.d2h(&h, scal_ + 2, sizeof(double));
   if (prev) ops_.free(prev);

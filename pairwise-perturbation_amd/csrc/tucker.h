@@ -54,6 +54,7 @@ class TuckerEngine {
   std::vector<int> leaf_;
   std::vector<char> contracted_;  // scratch
   int P_ = 1, rank_ = 0;
+  bool dist_ = false;
   // pairwise perturbation (als_Tucker.cxx:426-962)
   struct PPOp {
     double *buf = nullptr;

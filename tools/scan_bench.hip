@@ -151,7 +151,50 @@ int main(int argc, char **argv) {
                              (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);
       };
     };
+    // same bytes as T = s batches of [s^2 x s] (the root = N-2 / root = 0 case), and with a row
+    // count that breaks the 2^11-byte alignment of the k stride (memory-channel aliasing probe)
+    auto ttm_b = [=](int mult) {
+      const int64_t M2 = (int64_t)s * s;
+      const int n_mt2 = (int)((M2 + 255) / 256);
+      const int64_t nt2 = (int64_t)n_mt2 * s;
+      return [=]() {
+        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
+                           dim3((unsigned)std::min<int64_t>(nt2, (int64_t)ncu * mult)), dim3(256), 0,
+                           0, V, M2, K1, M2 * K1, P, n_mt2, 1, nblk1, nblk1, slab, M2 * s,
+                           (int64_t)0, M2, R, 1, nt2);
+      };
+    };
+    auto ttm_pad = [=](int mult, int64_t pad) {
+      const int64_t Mp = M3 + pad, Kp = K1 - 1;
+      const int n_mtp = (int)((Mp + 255) / 256);
+      return [=]() {
+        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
+                           dim3((unsigned)std::min<int64_t>(n_mtp, (int64_t)ncu * mult)), dim3(256),
+                           0, 0, V, Mp, Kp, Mp * Kp, P, n_mtp, 1, nblk1, nblk1, slab, Mp, (int64_t)0,
+                           (int64_t)0, R, 1, (int64_t)n_mtp);
+      };
+    };
     vs.push_back({"ttm buf v1 (1 tile/WG)  x1", ttm(0, 0), {}});
+    vs.push_back({"ttmB batched s x [s2 x s] x40", ttm_b(40), {}});
+    auto ttm_x = [=](int mult, int ncols_, int ntst) {  // no stores at all / nontemporal stores
+      return [=]() {
+        if (ntst)
+          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 9>),
+                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
+                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
+                             (int64_t)0, (int64_t)0, ncols_, 1, (int64_t)n_mt);
+        else
+          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
+                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
+                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
+                             (int64_t)0, (int64_t)0, ncols_, 1, (int64_t)n_mt);
+      };
+    };
+    vs.push_back({"ttmP no stores         x40", ttm_x(40, 0, 0), {}});
+    vs.push_back({"ttm buf nt-stores      x40", ttm_x(40, R, 1), {}});
+    vs.push_back({"ttm buf nt-stores       x3", ttm_x(3, R, 1), {}});
+    vs.push_back({"ttm buf persistent      x3", ttm(1, 3), {}});
+    vs.push_back({"ttm buf persistent      x6", ttm(1, 6), {}});
     vs.push_back({"ttm buf persistent      x5", ttm(1, 5), {}});
     vs.push_back({"ttm buf persistent     x10", ttm(1, 10), {}});
     vs.push_back({"ttm buf persistent     x20", ttm(1, 20), {}});
@@ -205,7 +248,9 @@ int main(int argc, char **argv) {
         for (int i = 0; i < NCHK; i++) acc[i] += tmp[i];
       }
     double maxrel = 0;
-    if (ref[v.kind].empty())
+    if (v.name.rfind("ttmB", 0) == 0 || v.name.rfind("ttmP", 0) == 0)
+      ;  // different problem shape: timing only
+    else if (ref[v.kind].empty())
       ref[v.kind] = acc;
     else
       for (int i = 0; i < NCHK; i++)
