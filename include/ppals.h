@@ -55,8 +55,10 @@ int ppals_ctx_rank(const ppals_ctx *ctx);
 int ppals_ctx_nranks(const ppals_ctx *ctx);
 int ppals_ctx_sync(ppals_ctx *ctx);
 /* HIP-event kernel timing on the engine's own stream (bench.py roofline leg).
- * which: 0 = tensor-scan kernels (K1/K2/K8), 1 = everything else */
-int ppals_profile_enable(ppals_ctx *ctx, int on);
+ * which: 0 = tensor-scan kernels (K1/K2/K8), 1 = the other bracketed kernels.
+ * level: 0 off, 1 = bracket the tensor scans only (an event pair costs ~10 us of stream time, so
+ * the timed region of bench.py pays it on the dominant kernel alone), 2 = bracket both groups */
+int ppals_profile_enable(ppals_ctx *ctx, int level);
 int ppals_profile_read(ppals_ctx *ctx, int which, int64_t *launches, double *total_ms,
                        double *algo_bytes);
 int ppals_profile_reset(ppals_ctx *ctx);

@@ -510,11 +510,10 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
 void CpEngine::normalize() {
   int64_t rows[MAX_ORDER];
   for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
-  ops_.normalize(W_.data(), rows, N_, R_, G_);
+  unsigned masks[32] = {0}, active = 0, fresh = 0;
   if (schedule_ == 1 && ms_root_ >= 0) {
     // cached MSDT tensors were built from the un-normalised factors of their contracted modes:
-    // one launch multiplies every live tensor's pending scalar by prod_{m contracted} f_m
-    unsigned masks[32] = {0}, active = 0, fresh = 0;
+    // every live tensor's pending scalar is multiplied by prod_{m contracted} f_m (same launch)
     auto visit = [&](RTensor &t) {
       if (!t.valid) return;
       masks[t.slot] = t.contracted;
@@ -524,8 +523,8 @@ void CpEngine::normalize() {
     };
     visit(ms_X_);
     for (auto &n : ms_nodes_) visit(n.t);
-    if (active) ops_.scale_update_many(ms_scales_, ops_.normalize_scales(), masks, active, fresh);
   }
+  ops_.normalize_ms(W_.data(), rows, N_, R_, G_, ms_scales_, masks, active, fresh);
 }
 
 // ---------------------------------------------------------------------------- multi-sweep tree

@@ -57,8 +57,11 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_top_eig_small,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update,
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    if (const char *v = getenv("PPALS_UPDATE_STAGE")) stage_update_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
   }
@@ -456,7 +459,9 @@ class HipOps : public Ops {
       int g = grid_for(nw * 64, 256, 16384);
       hipLaunchKernelGGL(k_mttv_1<TX>, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out, rs,
                          accumulate, scale);
-    } else if (L % VL == 0 && L >= 16 * VL && ((uintptr_t)X & 15) == 0) {
+    } else if (L % VL == 0 && L >= 16 * VL && ((uintptr_t)X & 15) == 0 &&
+               ((L + 64 * VL - 1) / (64 * VL)) * T * R >= 1024) {
+      // streaming regime: enough (l-tile, t, r) waves to fill the chip on their own
       int64_t nb = ((L + 64 * VL - 1) / (64 * VL)) * T * R;
       int g = (int)std::min<int64_t>(nb, 1 << 20);
       hipLaunchKernelGGL(k_mttv_vec<TX>, dim3(g), dim3(64), 0, st_, X, L, J, T, R, B, ldb, out, rs,
@@ -464,8 +469,12 @@ class HipOps : public Ops {
     } else {
       int64_t nb = ((L + 63) / 64) * T * R;
       int g = (int)std::min<int64_t>(nb, 32768);
-      hipLaunchKernelGGL(k_mttv_l<TX>, dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb, out, rs,
-                         accumulate, scale);
+      if (nb * 4 < 1024)  // few blocks: split the j loop 16 ways instead of 4
+        hipLaunchKernelGGL((k_mttv_l<TX, 16>), dim3(g), dim3(1024), 0, st_, X, L, J, T, R, B, ldb,
+                           out, rs, accumulate, scale);
+      else
+        hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb,
+                           out, rs, accumulate, scale);
     }
     prof_end();
     HIP_CHECK(hipGetLastError());
@@ -532,8 +541,15 @@ class HipOps : public Ops {
     }
     size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
                  sizeof(int) * 64;
-    hipLaunchKernelGGL(k_cp_mode_update, dim3(1), dim3(1024), lds, st_, Gall, N, mode, R, lambda, M,
-                       ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio, S, Sinv);
+    const size_t stage = 2 * sizeof(double) * (size_t)rows * R;
+    if (stage_update_ && lds + stage <= 150 * 1024)
+      hipLaunchKernelGGL(k_cp_mode_update<true>, dim3(1), dim3(1024), lds + stage, st_, Gall, N, mode,
+                         R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd,
+                         ratio, S, Sinv);
+    else
+      hipLaunchKernelGGL(k_cp_mode_update<false>, dim3(1), dim3(1024), lds, st_, Gall, N, mode, R,
+                         lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio,
+                         S, Sinv);
     HIP_CHECK(hipGetLastError());
   }
   void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
@@ -558,6 +574,26 @@ class HipOps : public Ops {
     }
     hipLaunchKernelGGL(k_scale_factors, dim3(grid_for(mx, 256, 64), N), dim3(256), 0, st_, w, N,
                        scales);
+    HIP_CHECK(hipGetLastError());
+  }
+  void normalize_ms(double *const *W, const int64_t *rows, int N, int R, double *Gall,
+                    double *ms_dst, const unsigned *masks, unsigned active,
+                    unsigned fresh) override {
+    int64_t tot = 0;
+    for (int i = 0; i < N; i++) tot += rows[i] * R;
+    if (tot > 65536) {  // big factors: the grid-wide scaling kernel pays off
+      Ops::normalize_ms(W, rows, N, R, Gall, ms_dst, masks, active, fresh);
+      return;
+    }
+    PtrsN w;
+    for (int i = 0; i < N; i++) {
+      w.p[i] = W[i];
+      w.n[i] = rows[i] * R;
+    }
+    ScaleMasks sm;
+    for (int k = 0; k < 32; k++) sm.m[k] = masks ? masks[k] : 0u;
+    hipLaunchKernelGGL(k_normalize_fused, dim3(1), dim3(1024), 0, st_, Gall, N, R, w,
+                       small(MAX_ORDER), active ? ms_dst : nullptr, sm, active, fresh);
     HIP_CHECK(hipGetLastError());
   }
   void diff_norms(double *const *A, double *const *B, const int64_t *n, int N, int store_diff,
@@ -651,7 +687,7 @@ class HipOps : public Ops {
   }
 
   // ------------------------------------------------------------------ profiling
-  void profile_enable(bool on) override { profiling_ = on; }
+  void profile_enable(int level) override { profiling_ = level; }
   void profile_collect() override {
     HIP_CHECK(hipStreamSynchronize(st_));
     for (size_t i = 0; i < nev_; i++) {
@@ -694,7 +730,7 @@ class HipOps : public Ops {
   };
   void prof_begin(int slot, double bytes) {
     cur_ = -1;
-    if (!profiling_) return;
+    if (profiling_ < 1 + slot) return;  // level 1: tensor scans only, level 2: every timed slot
     if (nev_ == events_.size()) {
       if (events_.size() >= 16384) return;
       Ev e;
@@ -725,12 +761,12 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 20;
+  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 20, stage_update_ = 1;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;
   size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0;
-  bool profiling_ = false;
+  int profiling_ = 0;
   std::vector<Ev> events_;
   size_t nev_ = 0;
   int cur_ = -1;

@@ -739,6 +739,25 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per
     // column (16 lanes x VEC rows contiguous); scalar stores only for unaligned strides
     const bool vec_ok = (((cur.obase | out_nstride) & (VEC - 1)) == 0);
+    if constexpr ((OPT & 16) != 0 && TR::NEEDS_FLUSH) {
+      // rank-fastest fp32 result X[m * pitch + n] (pitch = out_nstride, a multiple of 4 floats):
+      // a lane holds 4 consecutive n of each of its rows -> one 16-byte store per row, and the
+      // wave's 64 rows form ONE contiguous span instead of `ncols` spans 4*M bytes apart
+      float *o32 = reinterpret_cast<float *>(out) + cur.obase;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int n0 = 16 * nt + 4 * g;
+        if (n0 < ncols) {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++)
+            if (cur.m + jj < M) {
+              f32x4 ov = {(float)acc64[jj][nt][0], (float)acc64[jj][nt][1],
+                          (float)acc64[jj][nt][2], (float)acc64[jj][nt][3]};
+              *reinterpret_cast<f32x4 *>(o32 + (cur.m + jj) * out_nstride + n0) = ov;
+            }
+        }
+      }
+    } else
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll

@@ -276,14 +276,16 @@ __global__ __launch_bounds__(64) void k_mttv_vec(const TX *__restrict__ X, int64
   }
 }
 
-// variant L: block = 64 consecutive l for one (t,r); the 4 waves split the j range and combine
-// through LDS, so even a 200 x 200 x R leaf contraction spreads over hundreds of waves.
-template <typename TX>
-__global__ __launch_bounds__(256) void k_mttv_l(const TX *__restrict__ X, int64_t L, int64_t J,
-                                                int64_t T, int R, const double *__restrict__ B,
-                                                int64_t ldb, double *__restrict__ out, int64_t rs,
-                                                int accumulate, const double *__restrict__ scale) {
-  __shared__ double part[4][64];
+// variant L: block = 64 consecutive l for one (t,r); the NW waves split the j range and combine
+// through LDS in a fixed order, so even a 200 x 200 x R leaf contraction spreads over hundreds of
+// waves (NW = 16 for the small fp64 nodes, where the j loop is the whole latency of the launch).
+template <typename TX, int NW>
+__global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, int64_t L, int64_t J,
+                                                    int64_t T, int R, const double *__restrict__ B,
+                                                    int64_t ldb, double *__restrict__ out,
+                                                    int64_t rs, int accumulate,
+                                                    const double *__restrict__ scale) {
+  __shared__ double part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ltiles = (L + 63) / 64;
   const int64_t total = ltiles * T * R;
@@ -295,19 +297,24 @@ __global__ __launch_bounds__(256) void k_mttv_l(const TX *__restrict__ X, int64_
     const int64_t l = lt * 64 + lane;
     const TX *x = X + l + L * J * (t + T * (int64_t)r);
     const double *b = B + ldb * r;
-    double s0 = 0, s1 = 0;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (l < L) {
       int64_t j = wave;
-      for (; j + 4 < J; j += 8) {
+      for (; j + 3 * NW < J; j += 4 * NW) {
         s0 += (double)x[L * j] * b[j];
-        s1 += (double)x[L * (j + 4)] * b[j + 4];
+        s1 += (double)x[L * (j + NW)] * b[j + NW];
+        s2 += (double)x[L * (j + 2 * NW)] * b[j + 2 * NW];
+        s3 += (double)x[L * (j + 3 * NW)] * b[j + 3 * NW];
       }
-      for (; j < J; j += 4) s0 += (double)x[L * j] * b[j];
+      for (; j < J; j += NW) s0 += (double)x[L * j] * b[j];
     }
-    part[wave][lane] = s0 + s1;
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && l < L) {
-      const double s = sc * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+      double s = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) s += part[w][lane];
+      s *= sc;
       double *o = out + l + L * t + rs * r;
       *o = accumulate ? (*o + s) : s;
     }
@@ -644,6 +651,12 @@ __global__ __launch_bounds__(1024) void k_cp_update(
 // fallback), gradient with the pre-update W + ||grad||^2 (K5), W = M S^{-1} (K6, optional
 // SVD_solve_mod tail), and the refreshed Gram G_mode = W^T W. Replaces three launches per mode.
 // dynamic LDS: red[32] | sS[R*R] | sI[R*R] | A[R*(R+1)] | Q[R*(R+1)] | cs[64] | pq[64 ints]
+// STAGE: M and the pre-update W are copied into LDS by waves 1..15 WHILE wave 0 factorises S, the
+// gradient / solve / Gram phases then run out of LDS (the new W replaces the old one there) and
+// global memory sees one read of M, W and one write of grad, W — the launch is a chain of
+// dependent phases, so every global round trip removed is ~1-2 us off a ~23 us kernel.
+// extra dynamic LDS with STAGE: sM[rows*R] | sW[rows*R] after the areas listed above.
+template <bool STAGE>
 __global__ __launch_bounds__(1024) void k_cp_mode_update(
     double *__restrict__ Gall, int N, int mode, int R, double lambda, const double *__restrict__ M,
     int64_t ldm, double *W, int64_t ldw, double *__restrict__ grad, int64_t ldg, int64_t rows,
@@ -660,6 +673,9 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   double *cs = Q + R * ldA;
   int *pq = (int *)(cs + 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *sM = (double *)(pq + 64);
+  double *sW = sM + (STAGE ? rows * R : 0);
+  const int64_t total = rows * R;
 
   for (int e = tid; e < R * R; e += blockDim.x) {
     const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
@@ -675,6 +691,13 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       wave_sync();
       jacobi_inverse_wave(A, Q, cs, pq, R, sI);
     }
+  } else if (STAGE) {
+    for (int64_t e = tid - 64; e < total; e += blockDim.x - 64) {
+      const int64_t i = e % rows;
+      const int j = (int)(e / rows);
+      sM[e] = M[i + ldm * j];
+      sW[e] = W[i + ldw * j];
+    }
   }
   __syncthreads();
   if (S_out)
@@ -683,14 +706,17 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       Sinv_out[e] = sI[e];
     }
 
-  const int64_t total = rows * R;
   double gs = 0;
   for (int64_t e = tid; e < total; e += blockDim.x) {
     const int64_t i = e % rows;
     const int j = (int)(e / rows);
     double acc = 0;
-    for (int k = 0; k < R; k++) acc += W[i + ldw * k] * sS[k + R * j];
-    const double gv = -M[i + ldm * j] + acc;
+    if (STAGE) {
+      for (int k = 0; k < R; k++) acc += sW[i + rows * k] * sS[k + R * j];
+    } else {
+      for (int k = 0; k < R; k++) acc += W[i + ldw * k] * sS[k + R * j];
+    }
+    const double gv = -(STAGE ? sM[e] : M[i + ldm * j]) + acc;
     grad[i + ldg * j] = gv;
     gs += gv * gv;
   }
@@ -700,7 +726,11 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     const int64_t i = e % rows;
     const int j = (int)(e / rows);
     double acc = 0;
-    for (int k = 0; k < R; k++) acc += M[i + ldm * k] * sI[k + R * j];
+    if (STAGE) {
+      for (int k = 0; k < R; k++) acc += sM[i + rows * k] * sI[k + R * j];
+    } else {
+      for (int k = 0; k < R; k++) acc += M[i + ldm * k] * sI[k + R * j];
+    }
     if (Winit) {
       const double wi = Winit[i + ldi * j];
       const double d = ratio * (acc - wi);
@@ -708,8 +738,9 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       if (ratio != 1.0) acc = wi + d;
     }
     W[i + ldw * j] = acc;
+    if (STAGE) sW[e] = acc;  // old W is dead since the block_sum barrier
   }
-  __syncthreads();  // W_new visible to the whole workgroup (same CU, shared L1)
+  __syncthreads();  // W_new visible to the whole workgroup (LDS, or same CU's L1)
   // G_mode = W^T W: one wave per (p <= q) pair
   double *G = Gall + (int64_t)mode * R * R;
   const int nw = blockDim.x >> 6;
@@ -721,7 +752,8 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       p++;
     }
     const int q = p + rem;
-    const double *a = W + ldw * p, *b = W + ldw * q;
+    const double *a = STAGE ? sW + rows * p : W + ldw * p;
+    const double *b = STAGE ? sW + rows * q : W + ldw * q;
     double sacc = 0;
     for (int64_t i = lane; i < rows; i += 64) sacc += a[i] * b[i];
     sacc = wave_sum(sacc);
@@ -768,6 +800,46 @@ __global__ void k_scale_factors(PtrsN w, int N, const double *__restrict__ scale
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < w.n[i];
        e += (int64_t)gridDim.x * blockDim.x)
     p[e] = f * p[e];
+}
+
+// Normalize in ONE launch for small factor sets (one block): the scales (same arithmetic as
+// k_norm_scales), the Gram rescale, the factor rescale and the pending-scale update of the cached
+// multi-sweep tensors (k_scale_update_many) — three ~5 us launches folded into one.
+__global__ __launch_bounds__(1024) void k_normalize_fused(double *__restrict__ Gall, int N, int R,
+                                                          PtrsN w, double *__restrict__ scales,
+                                                          double *__restrict__ ms_dst,
+                                                          ScaleMasks masks, unsigned active,
+                                                          unsigned fresh) {
+  __shared__ double nrm[MAX_ORDER], fs[MAX_ORDER];
+  const int tid = threadIdx.x;
+  if (tid < N) {
+    double tr = 0;
+    for (int k = 0; k < R; k++) tr += Gall[(int64_t)tid * R * R + k + R * k];
+    nrm[tid] = sqrt(tr);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double prod = 1;
+    for (int i = 0; i < N; i++) prod = prod * nrm[i];
+    const double c = pow(prod, 1.0 / N);
+    for (int i = 0; i < N; i++) {
+      fs[i] = c / nrm[i];
+      scales[i] = fs[i];
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < N; i++) {
+    const double f = fs[i];
+    for (int e = tid; e < R * R; e += blockDim.x) Gall[(int64_t)i * R * R + e] *= f * f;
+    double *p = w.p[i];
+    for (int64_t e = tid; e < w.n[i]; e += blockDim.x) p[e] = f * p[e];
+  }
+  if (ms_dst && tid < 32 && ((active >> tid) & 1u)) {
+    double v = ((fresh >> tid) & 1u) ? 1.0 : ms_dst[tid];
+    for (int m = 0; m < MAX_ORDER; m++)
+      if (masks.m[tid] & (1u << m)) v *= fs[m];
+    ms_dst[tid] = v;
+  }
 }
 
 // ------------------------------------------------------------------ PP bookkeeping

@@ -125,6 +125,14 @@ class Ops {
     for (int k = 0; k < 32; k++)
       if ((active >> k) & 1u) scale_update(dst + k, scales, masks[k], (fresh >> k) & 1u);
   }
+  // Normalize + the pending-scale update of the cached multi-sweep tensors (active == 0: none);
+  // back ends may fold both into one launch
+  virtual void normalize_ms(double *const *W, const int64_t *rows, int N, int R, double *Gall,
+                            double *ms_dst, const unsigned *masks, unsigned active,
+                            unsigned fresh) {
+    normalize(W, rows, N, R, Gall);
+    if (active) scale_update_many(ms_dst, normalize_scales(), masks, active, fresh);
+  }
   virtual const double *normalize_scales() = 0;  // device array [N] written by normalize()
 
   // ---- R x R normal-equation side ----
@@ -178,7 +186,7 @@ class Ops {
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
 
   // profiling of the scan kernels (HIP events on the launch stream)
-  virtual void profile_enable(bool) {}
+  virtual void profile_enable(int /*level*/) {}
   virtual void profile_collect() {}
   ProfileSlot prof[2];
 };

@@ -99,7 +99,7 @@ int ppals_ctx_sync(ppals_ctx *ctx) {
 }
 int ppals_profile_enable(ppals_ctx *ctx, int on) {
   API_BEGIN
-  ctx->ops->profile_enable(on != 0);
+  ctx->ops->profile_enable(on < 0 ? 0 : on);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }

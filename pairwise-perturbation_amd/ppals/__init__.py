@@ -140,8 +140,9 @@ class Context:
     def sync(self):
         _check(lib().ppals_ctx_sync(self._h))
 
-    def profile_enable(self, on=True):
-        _check(lib().ppals_profile_enable(self._h, int(on)))
+    def profile_enable(self, level=1):
+        """0 off, 1 tensor scans only, 2 scans + the other bracketed kernels"""
+        _check(lib().ppals_profile_enable(self._h, int(level)))
 
     def profile_reset(self):
         _check(lib().ppals_profile_reset(self._h))

@@ -81,6 +81,8 @@ def run(ppals, ctx):
 
 def main():
     import torch  # noqa: F401  (first: libppals shares torch's HIP runtime and librccl)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "pairwise-perturbation_amd"))
     import ppals
     ctx = ppals.Context(0)
     ctx.init_comm(0, 1, ppals.Context.unique_id())

@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
   double *slab, *out;
   CK(hipMalloc(&V, sizeof(float) * M * K));
   CK(hipMalloc(&P, sizeof(float) * (size_t)nblk * NT * 256 * VEC));
-  CK(hipMalloc(&slab, sizeof(double) * 64 * 16 * NT * M));
+  CK(hipMalloc(&slab, std::max<size_t>(sizeof(double) * 64 * 16 * NT * M, sizeof(float) * 16 * (size_t)M * (size_t)s + 4096)));  // also holds the s^3 x 16 fp32 result of the ttm probes
   CK(hipMalloc(&out, sizeof(double) * 16 * NT * M));
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, V, M * K, 1u);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, P, (int64_t)nblk * NT * 256 * VEC, 2u);
@@ -190,6 +190,17 @@ int main(int argc, char **argv) {
                              (int64_t)0, (int64_t)0, ncols_, 1, (int64_t)n_mt);
       };
     };
+    auto ttm_rf = [=](int mult, int pitch) {  // rank-fastest result layout
+      return [=]() {
+        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 17>),
+                           dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
+                           0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, (int64_t)pitch,
+                           (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);
+      };
+    };
+    vs.push_back({"ttmP rank-fastest p12   x3", ttm_rf(3, 12), {}});
+    vs.push_back({"ttmP rank-fastest p12  x40", ttm_rf(40, 12), {}});
+    vs.push_back({"ttmP rank-fastest p16  x40", ttm_rf(40, 16), {}});
     vs.push_back({"ttmP no stores         x40", ttm_x(40, 0, 0), {}});
     vs.push_back({"ttm buf nt-stores      x40", ttm_x(40, R, 1), {}});
     vs.push_back({"ttm buf nt-stores       x3", ttm_x(3, R, 1), {}});
