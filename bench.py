@@ -217,12 +217,14 @@ def main():
         traffic, traffic_src = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = pm.get(f"{args.workload}/{args.dtype}/{world}")
+            key = f"{args.workload}/{args.dtype}/{world}" + ("/dt" if schedule == "dt" else "")
+            ent = pm.get(key)
             if ent:
-                ks = [v for k, v in ent.items() if k.startswith("k_scan")]
-                traffic = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks) / len(ks)
-                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                               "separate passes, FETCH_SIZE x2 (gfx950), mean of the two scan kernels")
+                ks = {k: v for k, v in ent.items() if k.startswith("k_scan")}
+                traffic = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks.values()) / len(ks)
+                traffic_src = (f"profiles/pmc_traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / "
+                               "WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950), per launch of "
+                               + " / ".join(sorted(ks)))
         except Exception:
             pass
         if launches > 0:
@@ -232,7 +234,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "k_scan_suffix/k_scan_prefix (tensor scans K1/K2)",
+                "kernel": "k_scan_suffix_buf (tensor scan: one mode contracted per launch under msdt, "
+                          "a mode half under dt)",
                 "launches": launches, "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": scan_bytes / launches,
                 "scan_ms_per_step": scan_ms / args.steps,

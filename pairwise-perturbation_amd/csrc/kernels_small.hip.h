@@ -524,48 +524,42 @@ __device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int
   wave_sync();
 }
 
-// ONE wave. Fast path for the (overwhelmingly common) positive-definite S: Cholesky S = L L^T,
-// X = L^{-1}, S^{-1} = X^T X. Returns false (wave-uniform) when a pivot is not positive — the
-// caller then falls back to the Jacobi path, which handles any symmetric S like the reference's
-// SVD does. In: A (R x R, ld R+1) lower triangle used, destroyed. X: R*(R+1) scratch.
-__device__ inline bool cholesky_inverse_wave(double *A, double *X, int R, double *Sinv_out) {
+// ONE wave. Fast path for the (overwhelmingly common) positive-definite S: in-place Gauss-Jordan
+// sweeps without pivoting (for an SPD matrix every pivot is a Schur-complement diagonal, > 0, the
+// same quantities a Cholesky factorisation would take the root of). One LDS round trip and one
+// barrier per pivot, ping-ponging between A and X, instead of the factor / triangular-inverse /
+// product chain (three dependent R-step loops). Returns false (wave-uniform) when a pivot is not
+// positive — the caller then falls back to the Jacobi path, which handles any symmetric S like the
+// reference's SVD does. In: A (R x R, ld R+1), destroyed. X: R*(R+1) scratch.
+__device__ inline bool spd_inverse_wave(double *A, double *X, int R, double *Sinv_out) {
   const int lane = threadIdx.x & 63;
   const int ldA = R + 1;  // element (i,j) at A[i*ldA + j]
+  double *src = A, *dst = X;
   for (int k = 0; k < R; k++) {
     wave_sync();
-    const double d = A[k * ldA + k];
-    if (!(d > 0.0)) return false;  // same value in every lane -> uniform
-    const double sq = sqrt(d), inv = 1.0 / sq;
-    for (int i = k + lane; i < R; i += 64) {
-      const double v = A[i * ldA + k];
-      A[i * ldA + k] = (i == k) ? sq : v * inv;
+    const double p = src[k * ldA + k];
+    if (!(p > 0.0)) return false;  // same value in every lane -> uniform
+    const double d = 1.0 / p;
+    for (int e = lane; e < R * R; e += 64) {
+      const int i = e % R, j = e / R;
+      double v;
+      if (i == k)
+        v = (j == k) ? d : src[k * ldA + j] * d;
+      else if (j == k)
+        v = -src[i * ldA + k] * d;
+      else
+        v = src[i * ldA + j] - src[i * ldA + k] * (src[k * ldA + j] * d);
+      dst[i * ldA + j] = v;
     }
-    wave_sync();
-    const int n = R - k - 1;
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = k + 1 + e % n, j = k + 1 + e / n;
-      if (i >= j) A[i * ldA + j] -= A[i * ldA + k] * A[j * ldA + k];
-    }
+    double *t = src;
+    src = dst;
+    dst = t;
   }
   wave_sync();
-  // X = L^{-1} (lower triangular): lane c owns column c, forward substitution down the column
-  for (int c = lane; c < R; c += 64) {
-    for (int i = 0; i < R; i++) {
-      double v = 0.0;
-      if (i >= c) {
-        double acc = (i == c) ? 1.0 : 0.0;
-        for (int j = c; j < i; j++) acc -= A[i * ldA + j] * X[j * ldA + c];
-        v = acc / A[i * ldA + i];
-      }
-      X[i * ldA + c] = v;
-    }
-  }
-  wave_sync();
-  for (int e = lane; e < R * R; e += 64) {  // S^{-1} = X^T X
+  // symmetrise (the two triangles differ by rounding only) and emit column-major
+  for (int e = lane; e < R * R; e += 64) {
     const int a = e % R, b = e / R;
-    double acc = 0;
-    for (int i = max(a, b); i < R; i++) acc += X[i * ldA + a] * X[i * ldA + b];
-    Sinv_out[e] = acc;
+    Sinv_out[e] = 0.5 * (src[a * ldA + b] + src[b * ldA + a]);
   }
   wave_sync();
   return true;
@@ -592,7 +586,7 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
   }
   wave_sync();
   bool ok = false;
-  if (!force_jacobi) ok = cholesky_inverse_wave(A, Q, R, Sinv);
+  if (!force_jacobi) ok = spd_inverse_wave(A, Q, R, Sinv);
   if (!ok) {
     wave_sync();
     for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = S[e];
@@ -647,7 +641,7 @@ __global__ __launch_bounds__(1024) void k_cp_update(
 }
 
 // ------------------------------------------------------------------ fused mode update (single GPU)
-// ONE block of 1024 threads does a whole mode update: S (K4), S^{-1} (wave 0: Cholesky, Jacobi
+// ONE block of 1024 threads does a whole mode update: S (K4), S^{-1} (wave 0: Gauss-Jordan sweeps, Jacobi
 // fallback), gradient with the pre-update W + ||grad||^2 (K5), W = M S^{-1} (K6, optional
 // SVD_solve_mod tail), and the refreshed Gram G_mode = W^T W. Replaces three launches per mode.
 // dynamic LDS: red[32] | sS[R*R] | sI[R*R] | A[R*(R+1)] | Q[R*(R+1)] | cs[64] | pq[64 ints]
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   }
   __syncthreads();
   if (wave == 0) {
-    bool ok = cholesky_inverse_wave(A, Q, R, sI);
+    bool ok = spd_inverse_wave(A, Q, R, sI);
     if (!ok) {
       wave_sync();
       for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = sS[e];

@@ -140,8 +140,8 @@ def test_gram_system(pp, ctx, R):
 
 
 def test_jacobi_fallback_path(pp, tmp_path):
-    """the Jacobi eigen-inverse (fallback when Cholesky meets a non-positive pivot) gives the same
-    sweeps as the Cholesky fast path; forced through PPALS_FORCE_JACOBI on a fresh context"""
+    """the Jacobi eigen-inverse (fallback when the pivoted-free SPD inverse meets a non-positive pivot) gives the same
+    sweeps as the SPD fast path; forced through PPALS_FORCE_JACOBI on a fresh context"""
     import os
     lens, R = [12, 10, 9, 11], 4
     V, W = problem(lens, R, 3, "r")
