@@ -600,6 +600,9 @@ void CpEngine::ms_start_step(int root) {
   ms_X_.contracted = 1u << root;
   ms_reserve(ms_X_, (size_t)L * T * R_ * dtype_size(ms_X_.dt));
   FactorRef f = fref(root, W_.data());
+  if (getenv("PPALS_DEBUG_ADDR"))
+    fprintf(stderr, "[ppals] step root %d: src %p (V %p VT %p) X %p L %lld J %lld T %lld\n", root, src,
+            V_.data, (void *)VT_, ms_X_.buf, (long long)L, (long long)ext(root), (long long)T);
   ops_.scan_contract(src, V_.dtype, L, ext(root), T, &f, 1, R_, ms_X_.buf, ms_X_.dt, L, L * T);
   ms_X_.pending = false;
   ms_X_.valid = true;

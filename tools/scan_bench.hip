@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
   double *slab, *out;
   CK(hipMalloc(&V, sizeof(float) * M * K));
   CK(hipMalloc(&P, sizeof(float) * (size_t)nblk * NT * 256 * VEC));
-  CK(hipMalloc(&slab, std::max<size_t>(sizeof(double) * 64 * 16 * NT * M, sizeof(float) * 16 * (size_t)M * (size_t)s + 4096)));  // also holds the s^3 x 16 fp32 result of the ttm probes
+  CK(hipMalloc(&slab, std::max<size_t>(sizeof(double) * 64 * 16 * NT * M, sizeof(float) * 16 * (size_t)M * (size_t)s + (32u << 20))));  // also holds the s^3 x 16 fp32 result of the ttm probes
   CK(hipMalloc(&out, sizeof(double) * 16 * NT * M));
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, V, M * K, 1u);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, P, (int64_t)nblk * NT * 256 * VEC, 2u);
@@ -201,6 +201,24 @@ int main(int argc, char **argv) {
     vs.push_back({"ttmP rank-fastest p12   x3", ttm_rf(3, 12), {}});
     vs.push_back({"ttmP rank-fastest p12  x40", ttm_rf(40, 12), {}});
     vs.push_back({"ttmP rank-fastest p16  x40", ttm_rf(40, 16), {}});
+    // does the placement of the result relative to the tensor matter (read/write channel overlap)?
+    printf("V %p  slab %p  (slab - V) mod 1 MiB = %zu\n", (void *)V, (void *)slab,
+           (size_t)((char *)slab - (char *)V) & ((1u << 20) - 1));
+    auto ttm_off = [=](int mult, size_t off) {
+      double *o = (double *)((char *)slab + off);
+      return [=]() {
+        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
+                           dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
+                           0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, o, M3, (int64_t)0,
+                           (int64_t)0, R, 1, (int64_t)n_mt);
+      };
+    };
+    vs.push_back({"ttmP out +256 B        x20", ttm_off(20, 256), {}});
+    vs.push_back({"ttmP out +4 KiB        x20", ttm_off(20, 4096), {}});
+    vs.push_back({"ttmP out +36 KiB       x20", ttm_off(20, 36864), {}});
+    vs.push_back({"ttmP out +292 KiB      x20", ttm_off(20, 299008), {}});
+    vs.push_back({"ttmP out +1 MiB+4 KiB  x20", ttm_off(20, (1u << 20) + 4096), {}});
+    vs.push_back({"ttmP out +16 MiB       x20", ttm_off(20, 16u << 20), {}});
     vs.push_back({"ttmP no stores         x40", ttm_x(40, 0, 0), {}});
     vs.push_back({"ttm buf nt-stores      x40", ttm_x(40, R, 1), {}});
     vs.push_back({"ttm buf nt-stores       x3", ttm_x(3, R, 1), {}});
