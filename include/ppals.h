@@ -140,6 +140,19 @@ int ppals_cp_pp(ppals_cp *s, const ppals_cp_opts *o, int *iters);
 /* alsCP_PP_partupdate (als_CP.h:117-122, als_CP.cxx:1146-1207): `-pp 2` */
 int ppals_cp_pp_partupdate(ppals_cp *s, const ppals_cp_opts *o, int *iters);
 
+/* ---- class API (src/CP.h, src/optimizer/) ----
+ * CPD<dtype, Optimizer>::als(tol, timelimit, maxsweep, resprint, Plot_File, bench)
+ * (src/CP.h:42-43, src/CP.cxx:100-186) after CPD::Init (= ppals_cp_set_factors; o->lambda is Init's
+ * lambda). `optimizer` names the reference class whose step() cadence and fractional sweep counter
+ * are reproduced: CPSimpleOptimizer (1 sweep/step, cp_simple_optimizer.cxx:21-56), CPDTOptimizer
+ * (0.5, cp_dt_optimizer.cxx:195-237), CPMSDTOptimizer ((N-1)/N, cp_msdt_optimizer.cxx:172-207).
+ * o->maxiter is maxsweep; no Normalize is applied (src/CP.cxx:171). *sweeps = final counter.
+ * Returns 1 unless sweeps == maxsweep+1 (the reference's bool), <0 on error. */
+#define PPALS_OPT_SIMPLE 0
+#define PPALS_OPT_DT 1
+#define PPALS_OPT_MSDT 2
+int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sweeps, int *iters);
+
 /* ---- Tucker sessions (als_Tucker.h) ---- */
 int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out);
 void ppals_tucker_destroy(ppals_tucker *s);

@@ -1156,6 +1156,121 @@ int ppo_als_cp(int N, const int64_t *lens, int R, const double *V, double *Wflat
   return iter == maxiter + 1 ? 0 : 1;
 }
 
+// ---------------------------------------------------------------- class API (src/CP.cxx, src/optimizer)
+// cholesky_solve (common.cxx:727-737): S = L L^T, W = M S^{-1} by two triangular solves
+void cholesky_solve(i64 rows, int R, const double *M, const double *S, double *W) {
+  vector<double> L((size_t)R * R, 0.0);
+  for (int j = 0; j < R; j++) {
+    double d = S[j + R * j];
+    for (int k = 0; k < j; k++) d -= L[j + R * k] * L[j + R * k];
+    d = std::sqrt(d);
+    L[j + R * j] = d;
+    for (int i = j + 1; i < R; i++) {
+      double v = S[i + R * j];
+      for (int k = 0; k < j; k++) v -= L[i + R * k] * L[j + R * k];
+      L[i + R * j] = v / d;
+    }
+  }
+  vector<double> out((size_t)rows * R);
+#pragma omp parallel for schedule(static)
+  for (i64 i = 0; i < rows; i++) {
+    vector<double> y(R), x(R);
+    for (int j = 0; j < R; j++) {  // y L^T = m  (row vector): forward
+      double v = M[i + rows * j];
+      for (int k = 0; k < j; k++) v -= y[k] * L[j + R * k];
+      y[j] = v / L[j + R * j];
+    }
+    for (int j = R - 1; j >= 0; j--) {  // x L = y: backward
+      double v = y[j];
+      for (int k = j + 1; k < R; k++) v -= x[k] * L[k + R * j];
+      x[j] = v / L[j + R * j];
+    }
+    for (int j = 0; j < R; j++) out[i + rows * j] = x[j];
+  }
+  std::copy(out.begin(), out.end(), W);
+}
+
+// CPOptimizer::update_S (cp_als_optimizer.cxx:19-37): modes ascending, skipping update_index
+void update_S(const Factors &F, int update_index, double lambda, double *S) {
+  int R = F.R;
+  vector<double> G((size_t)R * R);
+  bool first = true;
+  for (int m = 0; m < F.N; m++) {
+    if (m == update_index) continue;
+    const double *W = F.W[m];
+    i64 sl = F.lens[m];
+    for (int i = 0; i < R; i++)
+      for (int j = 0; j < R; j++) {
+        double acc = 0;
+        for (i64 k = 0; k < sl; k++) acc += W[k + sl * i] * W[k + sl * j];
+        G[i + R * j] = acc;
+      }
+    if (first)
+      std::copy(G.begin(), G.end(), S);
+    else
+      for (int e = 0; e < R * R; e++) S[e] = S[e] * G[e];
+    first = false;
+  }
+  for (int i = 0; i < R; i++) S[i + R * i] += lambda;
+}
+
+// The comb-shaped tree of CPDTOptimizer / CPMSDTOptimizer over the POSITIONS 0..N-2 of `indexes`
+// (cp_dt_optimizer.cxx:67-125, cp_msdt_optimizer.cxx:49-110): Construct_Subtree drops the last
+// position, Right_Subtree the second-to-last; keys are strings of 'a'+position.
+struct CombTree {
+  map<string, string> parent, contract_index;
+  static string key(const vector<int> &v) {
+    string s;
+    for (int x : v) s.push_back((char)('a' + x));
+    return s;
+  }
+  void right_subtree(const vector<int> &top) {  // cp_dt_optimizer.cxx:104-125
+    vector<int> child(top.begin(), top.end() - 1);
+    child[child.size() - 1] = top[top.size() - 1];
+    parent[key(child)] = key(top);
+    contract_index[key(child)] = key({top[top.size() - 2]});
+    if (child.size() > 1) right_subtree(child);
+  }
+  void construct_subtree(const vector<int> &top) {  // cp_dt_optimizer.cxx:79-102
+    right_subtree(top);
+    vector<int> child(top.begin(), top.end() - 1);
+    parent[key(child)] = key(top);
+    contract_index[key(child)] = key({top[top.size() - 1]});
+    if (child.size() > 1) construct_subtree(child);
+  }
+};
+
+struct ClassStep {
+  int N, R;
+  const Ten *V;
+  Factors *F;
+  CombTree tree;
+  vector<int> indexes;     // position -> mode
+  map<string, Ten> cache;  // mttkrp_map
+  // mttkrp_map_init (cp_dt_optimizer.cxx:127-161): top = V x_left W_left, modes in cyclic order
+  void init(int left_index) {
+    cache.clear();
+    Ten top = ttm_r(*V, pos_of(*V, left_index), F->W[left_index], R);
+    // remaining dimensions are ascending modes; reorder bookkeeping only (positions follow
+    // `indexes`), the data layout keeps the ascending order and pos_of() finds each mode
+    string topkey;
+    for (int i = 0; i < N - 1; i++) topkey.push_back((char)('a' + i));
+    cache[topkey] = std::move(top);
+    cache[topkey].d = cache[topkey].own.data();
+  }
+  const Ten &node(const string &index) {  // mttkrp_map_DT (cp_dt_optimizer.cxx:163-193)
+    auto it = cache.find(index);
+    if (it != cache.end()) return it->second;
+    const Ten &P = node(tree.parent[index]);
+    int mode = indexes[tree.contract_index[index][0] - 'a'];
+    Ten out = ttm_r(P, pos_of(P, mode), F->W[mode], R);
+    cache[index] = std::move(out);
+    Ten &ref = cache[index];
+    ref.d = ref.own.data();
+    return ref;
+  }
+};
+
 // alsCP_DT (als_CP.cxx:127-320), bench == false
 int ppo_als_cp_dt(int N, const int64_t *lens, int R, const double *V, double *Wflat,
                   double *gradWflat, double tol, double timelimit, int maxiter, double lambda,
@@ -1425,6 +1540,108 @@ int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double
   if (c.log.has_csv) c.log.csv.close();
   if (iters) *iters = iter;
   return iter == maxiter + 1 ? 0 : 1;
+}
+
+// CPD<dtype, Optimizer>::als (src/CP.cxx:100-186) driving one of the class-API optimizers:
+// kind 0 CPSimpleOptimizer::step (cp_simple_optimizer.cxx:21-56, 1 sweep per step),
+// kind 1 CPDTOptimizer::step (cp_dt_optimizer.cxx:195-237, 0.5 sweep per step),
+// kind 2 CPMSDTOptimizer::step (cp_msdt_optimizer.cxx:172-207, (N-1)/N sweep per step).
+// No Normalize (commented out at src/CP.cxx:171); solves by cholesky_solve.
+int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                double *gradWflat, int kind, double lambda, double tol, double timelimit,
+                int maxsweep, int resprint, const char *csv_path, int verbose, double *sweeps_out,
+                int *iters_out) {
+  Factors F = factors(N, lens, R, Wflat), G = factors(N, lens, R, gradWflat);
+  Ten Vt = view_of(N, lens, V);
+  Log log;
+  log.verbose = verbose != 0;
+  log.open(csv_path);
+  log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
+  ClassStep st;
+  st.N = N;
+  st.R = R;
+  st.V = &Vt;
+  st.F = &F;
+  if (kind != 0) {
+    vector<int> top;
+    for (int i = 0; i < N - 1; i++) top.push_back(i);
+    st.tree.construct_subtree(top);
+  }
+  bool first_subtree = true;  // CPDTOptimizer state (cp_dt_optimizer.cxx:30-38)
+  int msdt_left = N;          // CPMSDTOptimizer::left_index (cp_msdt_optimizer.cxx:28)
+  vector<double> S((size_t)R * R);
+  auto update_mode = [&](int mode, const double *Msrc) {
+    vector<double> M(Msrc, Msrc + lens[mode] * R);
+    update_S(F, mode, lambda, S.data());
+    gradient(lens[mode], R, M.data(), F.W[mode], S.data(), G.W[mode]);
+    cholesky_solve(lens[mode], R, M.data(), S.data(), F.W[mode]);
+  };
+  auto cyclic_after = [&](int left) {
+    vector<int> idx;
+    for (int i = left + 1; i < N; i++) idx.push_back(i);
+    for (int i = 0; i < left; i++) idx.push_back(i);
+    return idx;
+  };
+  auto step = [&]() -> double {
+    if (kind == 0) {
+      for (int i = 0; i < N; i++) {
+        vector<double> M((size_t)lens[i] * R);
+        mttkrp_naive(Vt, F, i, M.data());
+        update_mode(i, M.data());
+      }
+      return 1.0;
+    }
+    int left, lo = 0, hi = N - 2;
+    if (kind == 1) {
+      left = first_subtree ? N - 1 : N - 2;
+      if (!first_subtree) hi = 0;  // special_index = 0 (cp_dt_optimizer.cxx:36,211-214)
+      first_subtree = !first_subtree;
+    } else {
+      msdt_left = (msdt_left + N - 1) % N;
+      left = msdt_left;
+    }
+    st.indexes = cyclic_after(left);
+    st.init(left);
+    for (int i = lo; i <= hi; i++) {
+      const Ten &Mt = st.node(string(1, (char)('a' + i)));
+      update_mode(st.indexes[i], Mt.d);
+    }
+    return kind == 1 ? 0.5 : 1.0 * (N - 1) / N;
+  };
+  double st_time = now(), sweeps = 0, gradnorm = 0, diffnorm_V = 1000.;
+  int iters = 0;
+  while ((int)sweeps <= maxsweep) {
+    if (iters % resprint == 0 || sweeps >= maxsweep || sweeps == 0) {
+      double st_time1 = now();
+      gradnorm = gradnorm_of(G);
+      diffnorm_V = residual(Vt, F);
+      st_time += now() - st_time1;
+      double dtime = now() - st_time;
+      if (log.verbose) {
+        std::cout.precision(13);
+        std::cout << "  [dim]=  " << lens[0] << "  [sweeps]=  " << sweeps << "  [gradnorm]  "
+                  << gradnorm << "  [tol]  " << tol << "  [pp_update]  " << 0 << "  [residual]  "
+                  << diffnorm_V << "  [dtime]  " << dtime << "\n";
+      }
+      if (log.has_csv) {
+        log.csv << lens[0] << "," << sweeps << "," << gradnorm << "," << tol << "," << 0 << ","
+                << diffnorm_V << "," << dtime << "\n";
+        if (iters % 100 == 0 && iters != 0) log.csv << std::endl;
+      }
+      if (gradnorm < tol || now() - st_time > timelimit) break;
+    }
+    sweeps += step();
+    iters += 1;
+    if (iters % 10 == 0 && verbose) printf(".");
+  }
+  if (verbose) {
+    printf("\nIters = %d Final proj-grad norm %E \n", iters, gradnorm);
+    printf("tf took %lf seconds\n", now() - st_time);
+  }
+  if (log.has_csv) log.csv.close();
+  if (sweeps_out) *sweeps_out = sweeps;
+  if (iters_out) *iters_out = iters;
+  return sweeps == maxsweep + 1 ? 0 : 1;
 }
 
 int ppo_num_threads(void) {

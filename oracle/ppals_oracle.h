@@ -68,6 +68,13 @@ int ppo_als_cp_pp_partupdate(int N, const int64_t *lens, int R, const double *V,
                              double update_percentage, const char *csv_path, int resprint,
                              int verbose, int *iters); /* als_CP.cxx:1146 */
 
+/* Class API: CPD<dtype,Optimizer>::als (src/CP.cxx:100-186). kind 0 CPSimpleOptimizer, 1 CPDTOptimizer,
+ * 2 CPMSDTOptimizer (src/optimizer/). No Normalize; *sweeps = the fractional sweep counter. */
+int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                double *gradWflat, int kind, double lambda, double tol, double timelimit,
+                int maxsweep, int resprint, const char *csv_path, int verbose, double *sweeps_out,
+                int *iters_out);
+
 /* Tucker. ranks[N]; Wflat holds lens[i] x ranks[i] matrices; core is prod(ranks) */
 void ppo_ttmc(int N, const int64_t *lens, const int *ranks, const double *V, const double *Wflat,
               int skip, double *Y);                                            /* als_Tucker.cxx:76 */

@@ -411,17 +411,22 @@ void CpEngine::refresh_grams() {
 
 void CpEngine::set_factors(const double *Wflat, const double *gradWflat) {
   const double *w = Wflat, *g = gradWflat;
-  double gs = 0;
+  double gs = 0, gsi[MAX_ORDER] = {0};
   for (int i = 0; i < N_; i++) {
     size_t n = (size_t)V_.glens[i] * R_;
     ops_.h2d(W_[i], w, n * sizeof(double));
     w += n;
     if (g) {
       ops_.h2d(gradW_[i], g, n * sizeof(double));
-      for (size_t e = 0; e < n; e++) gs += g[e] * g[e];
+      for (size_t e = 0; e < n; e++) gsi[i] += g[e] * g[e];
+      gs += gsi[i];
       g += n;
     }
   }
+  // per-mode ||grad_W[i]||^2 of the caller's gradients: a partial sweep (class API steps) mixes
+  // them with the modes updated so far, exactly like CPD::update_gradnorm (src/CP.cxx:89-96)
+  ops_.h2d(gradsq_, gsi, sizeof(double) * MAX_ORDER);
+  for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = true;
   // iter-0 [gradnorm] is the norm of the caller's initial grad_W (test_ALS.cxx:338,
   // als_CP.cxx:174-181)
   init_gradnorm_ = std::sqrt(gs);
@@ -690,6 +695,108 @@ void CpEngine::sweep_dt(double lambda) {
   }
   normalize();
   grad_from_sweep_ = true;
+}
+
+// `count` consecutive mode updates starting at mode `first` (cyclic), NO Normalize — the step of
+// the class-API optimizers (src/optimizer/*::step). The multi-sweep state carries over between
+// calls, so a step that starts where the previous one ended reuses the cached contraction.
+void CpEngine::update_modes(int first, int count, double lambda) {
+  for (int k = 0; k < count; k++) {
+    const int i = (first + k) % N_;
+    if (schedule_ == 1) {
+      if (ms_root_ < 0 || ms_root_ == i) ms_start_step((i - 1 + N_) % N_);
+      int pos = -1;
+      for (int q = 0; q < N_ - 1; q++)
+        if (ms_order_[q] == i) pos = q;
+      const int leaf = ms_leaf_[pos];
+      ms_compute(leaf);
+      mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
+      ms_nodes_[leaf].t.valid = false;
+    } else {
+      if (i == 0 || k == 0)
+        for (auto &n : nodes_) n.valid = false;
+      compute_node(leaf_[i]);
+      mode_update(i, nodes_[leaf_[i]].buf, ext(i), lambda, false, 1.0);
+    }
+  }
+  grad_from_sweep_ = true;
+}
+
+// CPD<dtype, Optimizer>::als (src/CP.cxx:100-186). The optimizer kind fixes the step granularity
+// and the fractional sweep counter (Simple 1, DT 0.5 [modes 0..N-2 | mode N-1], MSDT (N-1)/N);
+// the ALS iterates are the same cyclic mode updates for all three, computed with this engine's
+// own contraction schedule. No Normalize (src/CP.cxx:171).
+int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iters_out) {
+  if (kind < 0 || kind > 2) throw std::runtime_error("ppals: unknown class-API optimizer");
+  std::ofstream csv;
+  std::ofstream *pcsv = nullptr;
+  if (rank_ == 0 && !o.csv_path.empty()) {
+    csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
+    pcsv = &csv;
+    if (!o.bench) csv << "[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]\n";
+  }
+  st_time_ = now();
+  int iters = 0, next_mode = 0;
+  bool first_subtree = true;
+  double sweeps = 0, projnorm = 0, diffV = 1000.;
+  const int maxsweep = o.maxiter;
+  while ((int)sweeps <= maxsweep) {
+    if (iters % o.resprint == 0 || sweeps >= maxsweep || sweeps == 0) {
+      ops_.sync();
+      const double st_time1 = now();
+      projnorm = gradnorm();
+      diffV = residual();
+      st_time_ += now() - st_time1;
+      const double dtime = now() - st_time_;
+      if (rank_ == 0) {
+        if (!o.bench) {
+          if (o.verbose) {
+            std::cout.precision(13);
+            std::cout << "  [dim]=  " << V_.glens[0] << "  [sweeps]=  " << sweeps
+                      << "  [gradnorm]  " << projnorm << "  [tol]  " << o.tol
+                      << "  [pp_update]  " << 0 << "  [residual]  " << diffV << "  [dtime]  "
+                      << dtime << "\n";
+          }
+          if (pcsv) {
+            (*pcsv) << V_.glens[0] << "," << sweeps << "," << projnorm << "," << o.tol << "," << 0
+                    << "," << diffV << "," << dtime << "\n";
+            if (iters % 100 == 0 && iters != 0) (*pcsv) << std::endl;
+          }
+        } else if (iters != 0) {
+          if (o.verbose) std::cout << "  [dimension tree step time]  " << dtime << "\n";
+          if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
+        }
+      }
+      if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+    }
+    int count;
+    double frac;
+    if (kind == 0) {
+      count = N_;
+      frac = 1.0;
+    } else if (kind == 1) {
+      count = first_subtree ? N_ - 1 : 1;
+      first_subtree = !first_subtree;
+      frac = 0.5;
+    } else {
+      count = N_ - 1;
+      frac = 1.0 * (N_ - 1) / N_;
+    }
+    update_modes(next_mode, count, o.lambda);
+    next_mode = (next_mode + count) % N_;
+    sweeps += frac;
+    iters += 1;
+    if (iters % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+  }
+  ops_.sync();
+  if (rank_ == 0 && o.verbose) {
+    printf("\nIters = %d Final proj-grad norm %E \n", iters, projnorm);
+    printf("tf took %lf seconds\n", now() - st_time_);
+  }
+  if (pcsv) csv.close();
+  if (sweeps_out) *sweeps_out = sweeps;
+  if (iters_out) *iters_out = iters;
+  return sweeps == maxsweep + 1 ? 0 : 1;
 }
 
 double CpEngine::allreduce_scalar(double x) {

@@ -82,6 +82,9 @@ class CpEngine {
   int run_dt(const CpOpts &o, int *iters);  // alsCP_DT, als_CP.cxx:127-320
   int run_pp(const CpOpts &o, int *iters);  // alsCP_PP, als_CP.cxx:1082-1137
   int run_pp_partupdate(const CpOpts &o, int *iters);  // alsCP_PP_partupdate, als_CP.cxx:1146-1207
+  // CPD<dtype,Optimizer>::als, src/CP.cxx:100-186; kind 0 Simple, 1 DT, 2 MSDT optimizer
+  int run_class(int kind, const CpOpts &o, double *sweeps, int *iters);
+  void update_modes(int first, int count, double lambda);
 
   int order() const { return N_; }
   int rank_r() const { return R_; }

@@ -348,6 +348,14 @@ int ppals_cp_pp_partupdate(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
   return s->eng->run_pp_partupdate(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
+int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sweeps, int *iters) {
+  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (optimizer < PPALS_OPT_SIMPLE || optimizer > PPALS_OPT_MSDT)
+    return fail(PPALS_ERR_ARG, "optimizer must be PPALS_OPT_SIMPLE, PPALS_OPT_DT or PPALS_OPT_MSDT");
+  API_BEGIN
+  return s->eng->run_class(optimizer, to_opts(o), sweeps, iters);
+  API_END(PPALS_ERR_HIP)
+}
 
 // ------------------------------------------------------------------ Tucker
 int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out) {

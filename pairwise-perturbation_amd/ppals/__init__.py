@@ -47,6 +47,7 @@ EXPORTS = [
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
     "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_cp_pp_partupdate",
+    "ppals_cpd_als",
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_hosvd", "ppals_tucker_ttmc", "ppals_tucker_sweeps_dt", "ppals_tucker_dt",
@@ -306,6 +307,16 @@ class CP:
         it = C.c_int(0)
         rc = _check(lib().ppals_cp_pp(self._h, C.byref(o), C.byref(it)))
         return rc, it.value
+
+    def cpd_als(self, optimizer, **kw):
+        """CPD<dtype, Optimizer>::als (src/CP.cxx:100-186); maxiter= is maxsweep.
+        Returns (rc, sweeps, iters)."""
+        o = _opts(**kw)
+        it = C.c_int(0)
+        sw = C.c_double(0)
+        rc = _check(lib().ppals_cpd_als(self._h, int(optimizer), C.byref(o), C.byref(sw),
+                                        C.byref(it)))
+        return rc, sw.value, it.value
 
     def run_pp_partupdate(self, **kw):
         o = _opts(**kw)

@@ -3,6 +3,7 @@ INFRASTRUCTURE: the product's engine + C-ABI sources over a host stand-in for th
 import importlib.util
 import os
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _mod = None
@@ -15,6 +16,7 @@ def load():
         path = os.path.join(ROOT, "pairwise-perturbation_amd", "ppals", "__init__.py")
         spec = importlib.util.spec_from_file_location("ppals_hostsim", path)
         mod = importlib.util.module_from_spec(spec)
+        sys.modules["ppals_hostsim"] = mod  # so objects can find the binding they came from
         spec.loader.exec_module(mod)
         mod._LIBPATH = os.path.join(ROOT, "tests", "hostsim", "build", "libppals_hostsim.so")
         assert b"hostsim" in mod.lib().ppals_version()

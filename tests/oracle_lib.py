@@ -235,6 +235,25 @@ def als_cp_pp_partupdate(V, Ws, gradWs, tol, tol_init, maxiter, update_percentag
     return rc, iters.value, unflat(wf, lens, [R] * len(lens)), unflat(gf, lens, [R] * len(lens))
 
 
+def cpd_als(V, Ws, gradWs, kind, tol, maxsweep, lam=0.0, csv=None, resprint=10, timelimit=5e3,
+            verbose=0):
+    """class API CPD<double, Optimizer>::als (src/CP.cxx:100-186); kind 0 simple, 1 DT, 2 MSDT.
+    Returns (rc, sweeps, iters, W, gradW)."""
+    lens = V.shape
+    R = Ws[0].shape[1]
+    wf, gf = flat(Ws), flat(gradWs)
+    Vf = np.asfortranarray(V)
+    sweeps = C.c_double(0)
+    iters = C.c_int(0)
+    f = lib().ppo_cpd_als
+    f.restype = C.c_int
+    rc = f(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf), kind, C.c_double(lam),
+           C.c_double(tol), C.c_double(timelimit), maxsweep, resprint,
+           (csv.encode() if csv else None), verbose, C.byref(sweeps), C.byref(iters))
+    return (rc, sweeps.value, iters.value, unflat(wf, lens, [R] * len(lens)),
+            unflat(gf, lens, [R] * len(lens)))
+
+
 def ttmc(V, Ws, skip):
     lens = V.shape
     ranks = [W.shape[1] for W in Ws]

@@ -336,3 +336,64 @@ def test_tensor_c_collinear(pp, ctx, dtype):
     c.set_factors(Wt)
     for mode in range(4):
         assert relerr(c.mttkrp(mode), O.mttkrp(want, Wt, mode, 0)) < KTOL[dtype] * 2
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("lens,R,dtype", [([8, 7, 6, 5], 3, 1), ([10, 8, 9], 4, 1),
+                                          ([5, 4, 3, 4, 3], 2, 1), ([12, 10, 8, 6], 5, 0)])
+def test_class_api_als_matches_oracle(pp, ctx, lens, R, dtype, kind, tmp_path):
+    """CPD<double, Optimizer>::als (src/CP.cxx:100-186) for the three optimizer cadences: final
+    factors / gradients, the fractional sweep counter, iteration count, return value and the CSV
+    rows ([sweeps] column, print cadence) against the oracle's restatement."""
+    V, W = problem(lens, R, 5, kind="r")
+    G0 = O.init_factors(lens, R, 3000)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    rc_ref, sw_ref, it_ref, W_ref, G_ref = O.cpd_als(V, W, G0, kind, tol=1e-9, maxsweep=4,
+                                                      csv=c_ref, resprint=2)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G0)
+    rc, sw, it = s.cpd_als(kind, tol=1e-9, maxiter=4, csv=c_got, resprint=2)
+    assert (rc, sw, it) == (rc_ref, sw_ref, it_ref)
+    W_got, G_got = s.get_factors(with_grad=True)
+    tol = 1e-8 if dtype == 1 else 2e-5
+    for a, b in zip(W_got, W_ref):
+        assert relerr(a, b) < tol, relerr(a, b)
+    for a, b in zip(G_got, G_ref):
+        assert np.linalg.norm(a - b) < 100 * tol * (1 + np.linalg.norm(b))
+    h1, r1 = O.read_csv(c_ref)
+    h2, r2 = O.read_csv(c_got)
+    assert h1 == h2 and len(r1) == len(r2)
+    for a, b in zip(r1, r2):
+        assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4] == 0   # dim, sweeps, pp_update
+        assert abs(a[2] - b[2]) <= 1e-3 * abs(a[2]) + 1e-6            # gradnorm (6 digits in CSV)
+        assert abs(a[5] - b[5]) <= 1e-3 * abs(a[5]) + 1e-5 * np.linalg.norm(V)
+    s.close()
+    t.close()
+
+
+def test_class_api_reference_test_case(pp, ctx, tmp_path):
+    """the reference's own unit test, tests/test_decomposition.cxx:38-66 (TEST_CPD): order 6,
+    s = 13, R = 5, CPD<double, CPDTOptimizer<double>>, Init, als(1e-5, 1000, 30, 100, csv). It
+    asserts order and rank only; here the run is also compared with the oracle."""
+    from ppals import decomposition as D
+    order, size, r = 6, 13, 5
+    lens = [size] * order
+    V = O.fill_uniform(size ** order, 7).reshape(lens, order="F")       # V->fill_random(0,1)
+    W = O.init_factors(lens, r, 11)                                      # W[i].fill_random(0,1)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    decom = D.CPD(order, size, r, ctx, optimizer=D.CPDTOptimizer)
+    assert decom.order == 6
+    assert decom.rank[0] == 5
+    decom.Init(t, W)
+    csv = str(tmp_path / "test.csv")
+    ok = decom.als(1e-5, 1000, 30, 100, csv)
+    G0 = pp.init_factors(lens, r, 3000)
+    rc_ref, sw_ref, it_ref, W_ref, G_ref = O.cpd_als(V, W, G0, 1, tol=1e-5, maxsweep=30,
+                                                      resprint=100)
+    assert ok == bool(rc_ref) and decom.sweeps == sw_ref and decom.iters == it_ref
+    for a, b in zip(decom.W, W_ref):
+        assert relerr(a, b) < 1e-6, relerr(a, b)
+    _, rows = O.read_csv(csv)
+    assert rows[0][1] == 0 and rows[-1][1] in (sw_ref, sw_ref - 0.5)
+    t.close()

@@ -106,3 +106,43 @@ def test_every_tensor_source_and_pp_mode_runs(tmp_path, args):
     _, rows = O.read_csv(csv)
     assert len(rows) >= 5
     assert rows[-1][5] <= rows[0][5] * (1 + 1e-9)
+
+
+@pytest.mark.parametrize("pp,kind", [(0, 1), (1, 2), (4, 0)])
+def test_run_driver_class_api(tmp_path, pp, kind):
+    """bin/run: the class-API front end (run.cxx:47-472). Echo block of run.cxx:222-240 (with the
+    updaterank / randomsvd fields), dispatch of run.cxx:387-414, console rows with [sweeps] and
+    [residual], CSV rows against the oracle's CPD::als restatement."""
+    s, R, N = 10, 3, 4
+    csv = str(tmp_path / "out.csv")
+    out = run([os.path.join(BIN, "run"), "-model", "CP", "-tensor", "r", "-dim", str(N), "-size",
+               str(s), "-rank", str(R), "-pp", str(pp), "-maxiter", "6", "-resprint", "1", "-tol",
+               "1e-9", "-filename", csv, "-prec", "64"])
+    lines = out.splitlines()
+    assert lines[0] == f"  model=  CP  tensor=  r  pp=  {pp}"
+    assert lines[1] == f"  dim=  {N}  size=  {s}  rank=  {R}  updaterank=  {s // 2}"
+    assert lines[6] == "  tensorfile=  test  update_percentage_pp=  1"
+    assert lines[7] == "  randomsvd=  0"
+    assert lines[8].startswith("Vnorm= ")
+    assert any("  [sweeps]=  " in ln and "  [residual]  " in ln for ln in lines)
+    assert any(ln.startswith("Iters = ") for ln in lines)
+    lens = [s] * N
+    V = O.build_V(O.init_factors(lens, R, 1000))
+    W, G = O.init_factors(lens, R, 2000), O.init_factors(lens, R, 3000)
+    Vn = np.linalg.norm(V)
+    ref = str(tmp_path / "ref.csv")
+    O.cpd_als(V, W, G, kind, tol=1e-9 * Vn, maxsweep=6, csv=ref, resprint=1)
+    h1, r1 = O.read_csv(ref)
+    h2, r2 = O.read_csv(csv)
+    assert h1 == h2 and len(r1) == len(r2) >= 7
+    for a, b in zip(r1, r2):
+        assert a[:2] == b[:2] and a[4] == b[4] == 0
+        assert abs(a[2] - b[2]) <= 1e-4 * abs(a[2]) + 1e-7
+        assert abs(a[5] - b[5]) <= 1e-4 * abs(a[5]) + 1e-7 * Vn
+
+
+def test_run_driver_rejects_low_rank_optimizers(tmp_path):
+    p = subprocess.run([os.path.join(BIN, "run"), "-tensor", "r", "-dim", "4", "-size", "8", "-pp",
+                        "2", "-filename", str(tmp_path / "o.csv")], capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 2 and "low-rank" in p.stderr
