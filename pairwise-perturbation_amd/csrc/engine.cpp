@@ -259,6 +259,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (const char *e = std::getenv("PPALS_COMM_SMALL_BYTES")) small_msg_bytes_ = std::atoll(e);
   if (const char *e = std::getenv("PPALS_DT_SCHEDULE")) schedule_ = (std::string(e) == "dt") ? 0 : 1;
   if (N_ < 3) schedule_ = 0;
+  if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
   if (schedule_ == 1) {
     ms_build_tree(0, N_ - 2, -1);
     ms_leaf_.assign(N_ - 1, -1);
@@ -891,30 +892,63 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
   const int mode = seq.back() - 'a';
   PPOp op;
   FactorRef f = fref(mode, W_.data());
+  int64_t L = 1, T = 1;
   if (seq.size() == 1) {
-    int64_t L = 1, T = 1;
-    for (int m = 0; m < N_; m++) {
-      if (m < mode) L *= ext(m);
-      if (m > mode) T *= ext(m);
-      if (m != mode) op.modes.push_back(m);
+    // level 1 = one tensor scan. Modes of the left half are contracted on the second resident
+    // layout, where they sit behind the right half, so that EVERY level-1 scan is a
+    // row-contiguous suffix-type scan; the s^(N-1) R result is kept in the tensor's precision.
+    const int mid = (N_ - 1) / 2;
+    bool use_vt = false;
+    if (pp_fast_ && N_ >= 3 && mode <= mid) {
+      ensure_transposed();
+      use_vt = vt_state_ == 1;
+    }
+    std::vector<int> layout;
+    if (use_vt) {
+      for (int m = mid + 1; m < N_; m++) layout.push_back(m);
+      for (int m = 0; m <= mid; m++) layout.push_back(m);
+    } else {
+      for (int m = 0; m < N_; m++) layout.push_back(m);
+    }
+    bool before = true;
+    for (int m : layout) {
+      if (m == mode) {
+        before = false;
+        continue;
+      }
+      (before ? L : T) *= ext(m);
+      op.modes.push_back(m);
     }
     op.elems = L * T;
-    op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.scan_contract(V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, F64, L, op.elems);
+    op.dt = pp_fast_ ? V_.dtype : F64;
+    op.buf = ops_.alloc(dtype_size(op.dt) * (size_t)op.elems * R_);
+    ops_.scan_contract(use_vt ? VT_ : V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, op.dt,
+                       L, op.elems);
   } else {
     const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
-    int64_t L = 1, T = 1;
+    bool before = true;
     for (int m : par.modes) {
-      if (m < mode) L *= ext(m);
-      if (m > mode) T *= ext(m);
-      if (m != mode) op.modes.push_back(m);
+      if (m == mode) {
+        before = false;
+        continue;
+      }
+      (before ? L : T) *= ext(m);
+      op.modes.push_back(m);
     }
     op.elems = L * T;
-    op.buf = (double *)ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.mttv(par.buf, F64, L, ext(mode), T, &f, 1, R_, op.buf, op.elems, 0, nullptr);
+    op.buf = ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
+    ops_.mttv(par.buf, par.dt, L, ext(mode), T, &f, 1, R_, (double *)op.buf, op.elems, 0, nullptr);
   }
   pp_[seq] = op;
   return pp_[seq];
+}
+void CpEngine::pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, double *out,
+                                int64_t out_rows) {
+  if (T.modes.size() != 2 || T.dt != F64) throw std::runtime_error("ppals: not a pair operator");
+  if (T.modes[0] == cmode)  // T[cmode, keep, r]
+    ops_.mttv(T.buf, F64, 1, ext(cmode), ext(T.modes[1]), &f, 1, R_, out, out_rows, 1, nullptr);
+  else  // T[keep, cmode, r]
+    ops_.mttv(T.buf, F64, ext(T.modes[0]), ext(cmode), 1, &f, 1, R_, out, out_rows, 1, nullptr);
 }
 void CpEngine::pp_clear() {
   for (auto &kv : pp_) ops_.free(kv.second.buf);
@@ -940,10 +974,18 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   }
   if (contracted.empty() || (int)contracted.size() >= N_) return -1;
   pp_clear();
-  const PPOp &op = pp_get(contracted);
-  if (out_host) ops_.d2h(out_host, op.buf, sizeof(double) * (size_t)op.elems * R_);
-  int64_t n = op.elems * R_;
+  const PPOp *op = &pp_get(contracted);
+  const bool saved = pp_fast_;
+  if (op->dt != F64 || !std::is_sorted(op->modes.begin(), op->modes.end())) {
+    // the entry point returns fp64 with the remaining modes ascending: rebuild on the plain route
+    pp_clear();
+    pp_fast_ = false;
+    op = &pp_get(contracted);
+  }
+  if (out_host) ops_.d2h(out_host, op->buf, sizeof(double) * (size_t)op->elems * R_);
+  int64_t n = op->elems * R_;
   pp_clear();
+  pp_fast_ = saved;
   return n;
 }
 
@@ -959,10 +1001,7 @@ void CpEngine::sweep_pp(double lambda, double ratio) {
       if (ii == i) continue;
       const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
       FactorRef f = fref(ii, dW_.data());
-      if (ii < i)  // T[ii, i, r]   (als_CP.cxx:785)
-        ops_.mttv(T.buf, F64, 1, ext(ii), si, &f, 1, R_, Mbuf_, si, 1, nullptr);
-      else  // T[i, ii, r]   (als_CP.cxx:793)
-        ops_.mttv(T.buf, F64, si, ext(ii), 1, &f, 1, R_, Mbuf_, si, 1, nullptr);
+      pp_contract_pair(T, ii, f, Mbuf_, si);  // als_CP.cxx:785 / :793
     }
     mode_update(i, Mbuf_, si, lambda, true, ratio);
   }
@@ -1191,10 +1230,7 @@ double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
         if (ii == i) continue;
         const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
         FactorRef f = fref(i, dW_.data());
-        if (ii < i)  // T[ii, i, r], contract i
-          ops_.mttv(T.buf, F64, ext(ii), si, 1, &f, 1, R_, dM_[ii], ext(ii), 1, nullptr);
-        else  // T[i, ii, r], contract i
-          ops_.mttv(T.buf, F64, 1, si, ext(ii), &f, 1, R_, dM_[ii], ext(ii), 1, nullptr);
+        pp_contract_pair(T, i, f, dM_[ii], ext(ii));
       }
     }
     for (int i = 0; i < N_; i++) {

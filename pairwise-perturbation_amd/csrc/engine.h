@@ -99,9 +99,10 @@ class CpEngine {
     bool valid = false;
   };
   struct PPOp {
-    double *buf = nullptr;
+    void *buf = nullptr;
+    int dt = F64;            // level-1 operators are kept in the tensor's own precision
     int64_t elems = 0;
-    std::vector<int> modes;  // remaining modes (ascending)
+    std::vector<int> modes;  // remaining modes in STORAGE order (first fastest)
   };
 
   // a cached intermediate of the multi-sweep schedule: modes in storage order (first fastest),
@@ -147,6 +148,9 @@ class CpEngine {
   void mode_update(int i, const double *M, int64_t ldm, double lambda, bool pp, double ratio);
   void normalize();
   const PPOp &pp_get(const std::string &seq);
+  // out (+)= T contracted over `cmode` with f; T is a pair operator (two modes, any storage order)
+  void pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, double *out, int64_t out_rows);
+  bool pp_fast_ = true;  // both resident layouts + typed level-1 operators (PPALS_PP_FAST=0: off)
   void pp_clear();
   void pp_build_all();
   void sweep_pp(double lambda, double ratio);
