@@ -397,7 +397,7 @@ class HipOps : public Ops {
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
-        // persistent launch: each workgroup walks over ~4+ tiles when there are many
+        // persistent launch: ncu*40 workgroups (measured best of 3..40 per CU), each walks over its tiles
         dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
 #define LAUNCH_SUFFIX_BUF(NTv)                                                                     \
   hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
@@ -761,7 +761,7 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 20, stage_update_ = 1;
+  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr;

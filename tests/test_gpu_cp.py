@@ -397,3 +397,34 @@ def test_class_api_reference_test_case(pp, ctx, tmp_path):
     _, rows = O.read_csv(csv)
     assert rows[0][1] == 0 and rows[-1][1] in (sw_ref, sw_ref - 0.5)
     t.close()
+
+
+EDGE_SHAPES = [([6, 5, 4], 1), ([1, 5, 4, 3], 2), ([5, 1, 4, 3], 2), ([5, 4, 3, 1], 2), ([7, 6], 3),
+               ([3, 2, 3, 2, 2, 3, 2, 2], 2), ([4, 4, 4, 4], 4), ([9, 3, 3, 3], 3),
+               ([64, 2, 3, 2], 2), ([2, 3, 2, 130], 3)]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", EDGE_SHAPES)
+def test_edge_shapes(pp, ctx, lens, R, dtype):
+    """rank 1, unit extents in every position, order 2 (a matrix) and order 8 (PPALS_MAX_ORDER),
+    R = s, one long mode: MTTKRP of every mode and three exact sweeps against the oracle"""
+    V = O.build_V(O.init_factors(lens, R, 1))
+    W, G = O.init_factors(lens, R, 2), O.init_factors(lens, R, 3)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    for m in range(len(lens)):
+        assert relerr(s.mttkrp(m), O.mttkrp(V, W, m, 0)) < KTOL[dtype], (lens, m)
+    s.sweeps_dt(3)
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=2, resprint=1000)
+    W_got, G_got = s.get_factors(with_grad=True)
+    # order 2 is a rank-R matrix factorisation: W_0 W_1^T is unique, the factors are not well
+    # conditioned individually, so compare the model there
+    if len(lens) == 2:
+        assert relerr(W_got[0] @ W_got[1].T, W_ref[0] @ W_ref[1].T) < 100 * FTOL[dtype]
+    else:
+        for a, b in zip(W_got, W_ref):
+            assert relerr(a, b) < 10 * FTOL[dtype], (lens, relerr(a, b))
+    s.close()
+    t.close()
