@@ -465,145 +465,6 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
 // Preconditions (checked by the launcher): 16*M*sizeof(TV) < 2^31 and the packed operand < 2^31 B.
 typedef unsigned int scan_u32x4 __attribute__((vector_size(16)));
 
-template <typename TV, int NT, int OPT = 1>
-__global__ __launch_bounds__(256) void k_scan_suffix_buf_v1(
-    const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
-    const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
-    double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols, int out32) {
-  typedef ScanTraits<TV> TR;
-  typedef typename TR::vec vec;
-  typedef typename TR::acc acc_t;
-  constexpr int VEC = TR::VEC;
-  constexpr int KB = 4 * VEC;
-  constexpr int FLUSH = 4;
-  constexpr int AUXV = (OPT & 1) ? 2 : 0;  // nt: streamed once, keep the packed operand in L2
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, j16 = lane & 15;
-  int64_t bid = blockIdx.x;
-  const int mtile = (int)(bid % n_mtiles);
-  bid /= n_mtiles;
-  const int split = (int)(bid % nsplit);
-  const int64_t batch = bid / nsplit;
-
-  const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
-  if (m0 >= M) return;  // wave-uniform
-  const int64_t m = m0 + (int64_t)VEC * j16;
-  const int64_t m_ld = min(m, M - VEC);  // clamped: lanes past the edge re-read the last rows
-  const int kb0 = split * kb_per_split;
-  const int kb1 = min(nkb, kb0 + kb_per_split);
-
-  // loop-invariant per-lane byte offsets
-  const int voff = (int)(((int64_t)g * M + m_ld) * (int64_t)sizeof(TV));
-  const int voffP = (int)((g * 16 + j16) * VEC * (int)sizeof(TV));
-  // wave-uniform pieces
-  const TV *__restrict__ vbase = V + batch * batch_stride;
-  const int64_t block_bytes = (int64_t)KB * M * (int64_t)sizeof(TV);
-  const int64_t total_bytes = K * M * (int64_t)sizeof(TV);
-  const int ustep = (int)((int64_t)4 * M * (int64_t)sizeof(TV));
-  const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)P, 0, (int)((int64_t)nkb * NT * (4 * 16 * VEC) * (int64_t)sizeof(TV)), 0x00020000);
-
-  acc_t acc[VEC][NT];
-  double acc64[TR::NEEDS_FLUSH ? VEC : 1][TR::NEEDS_FLUSH ? NT : 1][4];
-#pragma unroll
-  for (int a = 0; a < VEC; a++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
-      if constexpr (TR::NEEDS_FLUSH) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
-      }
-    }
-
-#define PPALS_BUF_LOAD(kb_, vv_, bb_)                                                          \
-  {                                                                                            \
-    const int64_t boff_ = (int64_t)(kb_)*block_bytes;                                          \
-    const int64_t rem_ = total_bytes - boff_;                                                  \
-    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                      \
-        (void *)((const char *)vbase + boff_), 0, (int)min(rem_, block_bytes), 0x00020000);    \
-    _Pragma("unroll") for (int u = 0; u < VEC; u++) vv_[u] = __builtin_bit_cast(               \
-        vec, __builtin_amdgcn_raw_buffer_load_b128(rs_, voff, u * ustep, AUXV));               \
-    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bb_[nt] = __builtin_bit_cast(            \
-        vec, __builtin_amdgcn_raw_buffer_load_b128(                                            \
-                 rsrcP, voffP, (int)(((kb_)*NT + nt) * (4 * 16 * VEC) * (int)sizeof(TV)), 0)); \
-  }
-  vec cv[VEC], cb[NT];
-  if (kb0 < kb1) PPALS_BUF_LOAD(kb0, cv, cb);
-  for (int kc = kb0; kc < kb1; kc += FLUSH) {
-    const int ke = min(kb1, kc + FLUSH);
-    for (int kb = kc; kb < ke; kb++) {
-      vec nv[VEC], nb[NT];
-      const int kn = min(kb + 1, kb1 - 1);  // the last block is simply loaded twice
-      PPALS_BUF_LOAD(kn, nv, nb);
-#pragma unroll
-      for (int u = 0; u < VEC; u++)
-#pragma unroll
-        for (int jj = 0; jj < VEC; jj++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-            acc[jj][nt] = TR::mfma(cb[nt][u], cv[u][jj], acc[jj][nt]);
-#pragma unroll
-      for (int u = 0; u < VEC; u++) cv[u] = nv[u];
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) cb[nt] = nb[nt];
-    }
-    if constexpr (TR::NEEDS_FLUSH) {
-#pragma unroll
-      for (int a = 0; a < VEC; a++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            acc64[a][nt][r] += (double)acc[a][nt][r];
-            acc[a][nt][r] = 0;
-          }
-    }
-  }
-#undef PPALS_BUF_LOAD
-
-  // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per column
-  // (16 lanes x VEC rows = 16*VEC contiguous elements); scalar stores only for unaligned strides
-  const int64_t obase = split * out_split_stride + batch * out_batch_stride;
-  const bool vec_ok = (((obase | out_nstride) & (VEC - 1)) == 0);
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int n = 16 * nt + TR::row(lane, r);
-      if (n < ncols && m < M) {
-        double val[VEC];
-#pragma unroll
-        for (int jj = 0; jj < VEC; jj++) {
-          if constexpr (TR::NEEDS_FLUSH)
-            val[jj] = acc64[jj][nt][r];
-          else
-            val[jj] = (double)acc[jj][nt][r];
-        }
-        const int64_t idx = obase + (int64_t)n * out_nstride + m;
-        if (vec_ok && out32) {
-          typedef float ovec_t __attribute__((ext_vector_type(VEC)));
-          ovec_t ov;
-#pragma unroll
-          for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
-          *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
-        } else if (vec_ok) {
-#pragma unroll
-          for (int jj = 0; jj < VEC; jj += 2) {
-            f64x2 ov = {val[jj], val[jj + 1]};
-            *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
-          }
-        } else {
-#pragma unroll
-          for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
-        }
-      }
-    }
-}
-
 // Persistent form: a workgroup walks over tiles id = blockIdx.x, blockIdx.x + gridDim.x, ... and the
 // first block of the NEXT tile is requested while the last block of the current one is multiplied
 // and its results are stored, so the load pipeline never drains at a tile boundary. This matters
@@ -739,25 +600,6 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per
     // column (16 lanes x VEC rows contiguous); scalar stores only for unaligned strides
     const bool vec_ok = (((cur.obase | out_nstride) & (VEC - 1)) == 0);
-    if constexpr ((OPT & 16) != 0 && TR::NEEDS_FLUSH) {
-      // rank-fastest fp32 result X[m * pitch + n] (pitch = out_nstride, a multiple of 4 floats):
-      // a lane holds 4 consecutive n of each of its rows -> one 16-byte store per row, and the
-      // wave's 64 rows form ONE contiguous span instead of `ncols` spans 4*M bytes apart
-      float *o32 = reinterpret_cast<float *>(out) + cur.obase;
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int n0 = 16 * nt + 4 * g;
-        if (n0 < ncols) {
-#pragma unroll
-          for (int jj = 0; jj < VEC; jj++)
-            if (cur.m + jj < M) {
-              f32x4 ov = {(float)acc64[jj][nt][0], (float)acc64[jj][nt][1],
-                          (float)acc64[jj][nt][2], (float)acc64[jj][nt][3]};
-              *reinterpret_cast<f32x4 *>(o32 + (cur.m + jj) * out_nstride + n0) = ov;
-            }
-        }
-      }
-    } else
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -778,10 +620,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             ovec_t ov;
 #pragma unroll
             for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
-            if constexpr (OPT & 8)  // result is consumed much later and exceeds the L2: stream it
-              __builtin_nontemporal_store(ov, reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx));
-            else
-              *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+            *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
           } else if (vec_ok) {
 #pragma unroll
             for (int jj = 0; jj < VEC; jj += 2) {

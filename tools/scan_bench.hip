@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
   double *slab, *out;
   CK(hipMalloc(&V, sizeof(float) * M * K));
   CK(hipMalloc(&P, sizeof(float) * (size_t)nblk * NT * 256 * VEC));
-  CK(hipMalloc(&slab, std::max<size_t>(sizeof(double) * 64 * 16 * NT * M, sizeof(float) * 16 * (size_t)M * (size_t)s + (32u << 20))));  // also holds the s^3 x 16 fp32 result of the ttm probes
+  CK(hipMalloc(&slab, std::max<size_t>(sizeof(double) * 64 * 16 * NT * M, sizeof(float) * 16 * NT * (size_t)M * (size_t)s + 4096)));  // also holds the s^3 x 16 fp32 result of the ttm probes
   CK(hipMalloc(&out, sizeof(double) * 16 * NT * M));
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, V, M * K, 1u);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, P, (int64_t)nblk * NT * 256 * VEC, 2u);
@@ -88,6 +88,12 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(KERN, dim3((unsigned)(n_mtiles * ns)), dim3(256), 0, 0, V, M, K, M * K, P, \
                        n_mtiles, ns, per, nblk, slab, M, (int64_t)16 * NT * M, (int64_t)0, R, 0); \
   }
+#define SUFFIXP(KERN, ns, per) /* persistent buffer-load kernel: takes the tile count */           \
+  [=]() {                                                                                         \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)std::min<int64_t>((int64_t)n_mtiles * ns, ncu * 40)), \
+                       dim3(256), 0, 0, V, M, K, M * K, P, n_mtiles, ns, per, nblk, slab, M,      \
+                       (int64_t)16 * NT * M, (int64_t)0, R, 0, (int64_t)n_mtiles * ns);           \
+  }
 #define PREFIXI(KERN, nsp)                                                                        \
   [=]() {                                                                                         \
     int per_ = (nblk + (nsp)-1) / (nsp);                                                          \
@@ -104,8 +110,8 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 1, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 1, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf v1 nt        x8", SUFFIX((k_scan_suffix_buf_v1<float, 1, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf v1 nt       x12", SUFFIX((k_scan_suffix_buf_v1<float, 1, 1>), ns12, per12), {}});
+    vs.push_back({"suffix buf nt           x8", SUFFIXP((k_scan_suffix_buf<float, 1, 1>), ns8, per8), {}});
+    vs.push_back({"suffix buf nt          x12", SUFFIXP((k_scan_suffix_buf<float, 1, 1>), ns12, per12), {}});
     vs.push_back({"suffix fast nt+xcd      x8", SUFFIX((k_scan_suffix_fast<float, 1, 3>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x4", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns4, per4), {}});
     vs.push_back({"suffix fast nt         x16", SUFFIX((k_scan_suffix_fast<float, 1, 1>), ns16, per16), {}});
@@ -124,7 +130,7 @@ int main(int argc, char **argv) {
     vs.push_back({"suffix generic          x8", SUFFIX((k_scan_suffix<float, 2, true>), ns8, per8), {}});
     vs.push_back({"suffix fast             x8", SUFFIX((k_scan_suffix_fast<float, 2, 0>), ns8, per8), {}});
     vs.push_back({"suffix fast nt          x8", SUFFIX((k_scan_suffix_fast<float, 2, 1>), ns8, per8), {}});
-    vs.push_back({"suffix buf v1 nt        x8", SUFFIX((k_scan_suffix_buf_v1<float, 2, 1>), ns8, per8), {}});
+    vs.push_back({"suffix buf nt           x8", SUFFIXP((k_scan_suffix_buf<float, 2, 1>), ns8, per8), {}});
     vs.push_back({"prefix generic      split1", PREFIX((k_scan_prefix<float, 2, true, 4>), 1), {}});
     vs.push_back({"prefix fast         split1", PREFIX((k_scan_prefix_fast<float, 2, 0>), 1), {}});
     vs.push_back({"prefix fast perm    split1", PREFIX((k_scan_prefix_fast<float, 2, 4>), 1), {}});
@@ -132,102 +138,56 @@ int main(int argc, char **argv) {
     vs.push_back({"prefix fast il+perm split1", PREFIXI((k_scan_prefix_fast<float, 2, 12>), 1), {}});
     vs.push_back({"prefix fast il+p+nt split1", PREFIXI((k_scan_prefix_fast<float, 2, 13>), 1), {}});
   }
-  // single-mode TTM regime of the multi-sweep schedule: M = s^3 rows, K = s, fp32 result
-  if (argc > 4 && NT == 1) {
+  // single-mode TTM regime of the multi-sweep schedule: M = s^3 rows, K = s, fp32 result.
+  // (Earlier probes of this regime — nontemporal stores, a rank-fastest result layout, padded row
+  // counts, result placement offsets — changed nothing or lost; their numbers are kept in
+  // profiles/r01h_scan_bench_ttm_regime_s200_r10.txt.)
+  if (argc > 4) {
     vs.clear();
     const int64_t M3 = (int64_t)s * s * s, K1 = s;
     const int nblk1 = (int)((K1 + 15) / 16);
     const int n_mt = (int)((M3 + 255) / 256);
-    auto ttm = [=](int which, int mult) {
+#define TTM_DISPATCH(BODY)  \
+  if (NT == 1) {           \
+    constexpr int NTC = 1; \
+    BODY                   \
+  } else {                 \
+    constexpr int NTC = 2; \
+    BODY                   \
+  }
+    auto ttm_fast = [=]() {
       return [=]() {
-        if (which == 0)
-          hipLaunchKernelGGL((k_scan_suffix_buf_v1<float, 1, 1>), dim3((unsigned)n_mt), dim3(256), 0,
-                             0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3, (int64_t)0,
-                             (int64_t)0, R, 1);
-        else
-          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
-                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
-                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
-                             (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);
+        TTM_DISPATCH(hipLaunchKernelGGL((k_scan_suffix_fast<float, NTC, 1>), dim3((unsigned)n_mt),
+                                        dim3(256), 0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1,
+                                        slab, M3, (int64_t)0, (int64_t)0, R, 1);)
       };
     };
-    // same bytes as T = s batches of [s^2 x s] (the root = N-2 / root = 0 case), and with a row
-    // count that breaks the 2^11-byte alignment of the k stride (memory-channel aliasing probe)
-    auto ttm_b = [=](int mult) {
+    auto ttm = [=](int mult, int ncols_) {  // ncols_ = 0: no stores at all
+      return [=]() {
+        TTM_DISPATCH(hipLaunchKernelGGL(
+            (k_scan_suffix_buf<float, NTC, 1>),
+            dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256), 0, 0, V, M3, K1,
+            M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3, (int64_t)0, (int64_t)0, ncols_, 1,
+            (int64_t)n_mt);)
+      };
+    };
+    auto ttm_b = [=](int mult) {  // the same bytes as s batches of [s^2 x s] (root N-2 / root 0)
       const int64_t M2 = (int64_t)s * s;
       const int n_mt2 = (int)((M2 + 255) / 256);
       const int64_t nt2 = (int64_t)n_mt2 * s;
       return [=]() {
-        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
-                           dim3((unsigned)std::min<int64_t>(nt2, (int64_t)ncu * mult)), dim3(256), 0,
-                           0, V, M2, K1, M2 * K1, P, n_mt2, 1, nblk1, nblk1, slab, M2 * s,
-                           (int64_t)0, M2, R, 1, nt2);
+        TTM_DISPATCH(hipLaunchKernelGGL(
+            (k_scan_suffix_buf<float, NTC, 1>),
+            dim3((unsigned)std::min<int64_t>(nt2, (int64_t)ncu * mult)), dim3(256), 0, 0, V, M2, K1,
+            M2 * K1, P, n_mt2, 1, nblk1, nblk1, slab, M2 * s, (int64_t)0, M2, R, 1, nt2);)
       };
     };
-    auto ttm_pad = [=](int mult, int64_t pad) {
-      const int64_t Mp = M3 + pad, Kp = K1 - 1;
-      const int n_mtp = (int)((Mp + 255) / 256);
-      return [=]() {
-        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
-                           dim3((unsigned)std::min<int64_t>(n_mtp, (int64_t)ncu * mult)), dim3(256),
-                           0, 0, V, Mp, Kp, Mp * Kp, P, n_mtp, 1, nblk1, nblk1, slab, Mp, (int64_t)0,
-                           (int64_t)0, R, 1, (int64_t)n_mtp);
-      };
-    };
-    vs.push_back({"ttm buf v1 (1 tile/WG)  x1", ttm(0, 0), {}});
+    vs.push_back({"ttm fast (1 tile/WG)    x1", ttm_fast(), {}});
+    vs.push_back({"ttm buf persistent      x3", ttm(3, R), {}});
+    vs.push_back({"ttm buf persistent     x20", ttm(20, R), {}});
+    vs.push_back({"ttm buf persistent     x40", ttm(40, R), {}});
     vs.push_back({"ttmB batched s x [s2 x s] x40", ttm_b(40), {}});
-    auto ttm_x = [=](int mult, int ncols_, int ntst) {  // no stores at all / nontemporal stores
-      return [=]() {
-        if (ntst)
-          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 9>),
-                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
-                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
-                             (int64_t)0, (int64_t)0, ncols_, 1, (int64_t)n_mt);
-        else
-          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
-                             dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
-                             0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, M3,
-                             (int64_t)0, (int64_t)0, ncols_, 1, (int64_t)n_mt);
-      };
-    };
-    auto ttm_rf = [=](int mult, int pitch) {  // rank-fastest result layout
-      return [=]() {
-        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 17>),
-                           dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
-                           0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, slab, (int64_t)pitch,
-                           (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);
-      };
-    };
-    vs.push_back({"ttmP rank-fastest p12   x3", ttm_rf(3, 12), {}});
-    vs.push_back({"ttmP rank-fastest p12  x40", ttm_rf(40, 12), {}});
-    vs.push_back({"ttmP rank-fastest p16  x40", ttm_rf(40, 16), {}});
-    // does the placement of the result relative to the tensor matter (read/write channel overlap)?
-    printf("V %p  slab %p  (slab - V) mod 1 MiB = %zu\n", (void *)V, (void *)slab,
-           (size_t)((char *)slab - (char *)V) & ((1u << 20) - 1));
-    auto ttm_off = [=](int mult, size_t off) {
-      double *o = (double *)((char *)slab + off);
-      return [=]() {
-        hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 1>),
-                           dim3((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * mult)), dim3(256),
-                           0, 0, V, M3, K1, M3 * K1, P, n_mt, 1, nblk1, nblk1, o, M3, (int64_t)0,
-                           (int64_t)0, R, 1, (int64_t)n_mt);
-      };
-    };
-    vs.push_back({"ttmP out +256 B        x20", ttm_off(20, 256), {}});
-    vs.push_back({"ttmP out +4 KiB        x20", ttm_off(20, 4096), {}});
-    vs.push_back({"ttmP out +36 KiB       x20", ttm_off(20, 36864), {}});
-    vs.push_back({"ttmP out +292 KiB      x20", ttm_off(20, 299008), {}});
-    vs.push_back({"ttmP out +1 MiB+4 KiB  x20", ttm_off(20, (1u << 20) + 4096), {}});
-    vs.push_back({"ttmP out +16 MiB       x20", ttm_off(20, 16u << 20), {}});
-    vs.push_back({"ttmP no stores         x40", ttm_x(40, 0, 0), {}});
-    vs.push_back({"ttm buf nt-stores      x40", ttm_x(40, R, 1), {}});
-    vs.push_back({"ttm buf nt-stores       x3", ttm_x(3, R, 1), {}});
-    vs.push_back({"ttm buf persistent      x3", ttm(1, 3), {}});
-    vs.push_back({"ttm buf persistent      x6", ttm(1, 6), {}});
-    vs.push_back({"ttm buf persistent      x5", ttm(1, 5), {}});
-    vs.push_back({"ttm buf persistent     x10", ttm(1, 10), {}});
-    vs.push_back({"ttm buf persistent     x20", ttm(1, 20), {}});
-    vs.push_back({"ttm buf persistent     x40", ttm(1, 40), {}});
+    vs.push_back({"ttmP no stores         x40", ttm(40, 0), {}});
   }
   // a plain streaming read of V as the practical ceiling on this device
   hipEvent_t e0, e1;
