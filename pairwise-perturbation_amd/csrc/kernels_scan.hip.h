@@ -470,6 +470,10 @@ typedef unsigned int scan_u32x4 __attribute__((vector_size(16)));
 // and its results are stored, so the load pipeline never drains at a tile boundary. This matters
 // for the single-mode contractions of the multi-sweep schedule, where a tile has only K/16 = 13
 // blocks (cfg2) and pipeline fill + drain + workgroup launch were ~10 % of its lifetime.
+// Measured and rejected (profiles/r01j_scan_bench_*, same-box A/B of bench.py): a two-cursor form
+// with the load cursor 2 blocks ahead: -9 % at one n-tile (registers), and at two n-tiles (2
+// waves/SIMD) 4.6 TB/s, still behind the global-load kernel k_scan_suffix_fast (5.6 TB/s) that the
+// launcher keeps for that case; the same form with 1 block ahead: -2.5 % against this one.
 template <typename TV, int NT, int OPT = 1>
 __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,

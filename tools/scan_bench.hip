@@ -45,6 +45,15 @@ struct Variant {
   int kind = 0, nsplit = 1;  // filled from the name below
 };
 
+// packed[((((blk*NT+nt)*4+g)*16+n)*4+u] holds k = 16*blk + 4*u + g (suffix packing, VEC = 4)
+__global__ void k_zero_tail(float *P, int nblk, int NT, int K) {
+  const int total = nblk * NT * 256 * 4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int u = e & 3, g = (e >> 6) & 3, blk = e / (NT * 256);
+    if (16 * blk + 4 * u + g >= K) P[e] = 0.f;
+  }
+}
+
 int main(int argc, char **argv) {
   const int s = argc > 1 ? atoi(argv[1]) : 200;
   const int R = argc > 2 ? atoi(argv[2]) : 10;
@@ -182,6 +191,10 @@ int main(int argc, char **argv) {
             M2 * K1, P, n_mt2, 1, nblk1, nblk1, slab, M2 * s, (int64_t)0, M2, R, 1, nt2);)
       };
     };
+    // the product's k_krp_pack zero-fills the packed operand beyond K; do the same here so that the
+    // clamping (fast) and the descriptor-bounded (buf) kernels agree on the partial last block
+    hipLaunchKernelGGL(k_zero_tail, dim3(64), dim3(256), 0, 0, P, (int)nblk1, NT, (int)K1);
+    CK(hipDeviceSynchronize());
     vs.push_back({"ttm fast (1 tile/WG)    x1", ttm_fast(), {}});
     vs.push_back({"ttm buf persistent      x3", ttm(3, R), {}});
     vs.push_back({"ttm buf persistent     x20", ttm(20, R), {}});
