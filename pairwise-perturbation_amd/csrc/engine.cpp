@@ -7,13 +7,17 @@
 //   Build_mttkrp_map          als_CP.cxx:352-409     -> pp_get
 //   alsCP_DT_sub / PP_sub     als_CP.cxx:418-833     -> dt_sub / pp_sub
 //   alsCP_PP                  als_CP.cxx:1082-1137   -> run_pp
+//   alsCP_PP_partupdate       als_CP.cxx:852-1207    -> run_pp_partupdate
+//   CPD<dtype,Optimizer>::als src/CP.cxx:100-186     -> run_class / update_modes
 // Default sweep schedule: the multi-sweep dimension tree (MSDT) of the reference's class API
 // (src/optimizer/cp_msdt_optimizer.cxx:172-207): ONE first-level contraction V x_r W_r is reused
 // for the next N-1 mode updates, so an exact sweep costs N/(N-1) tensor scans instead of 2 — the
 // very same ALS iterates (same update order, same normal equations), 1.5x fewer tensor bytes at
 // N = 4. PPALS_DT_SCHEDULE=dt selects the two-first-level-node tree of alsCP_DT instead.
 // Multi-GPU: V is block-partitioned along mode 0; factors are replicated; each
-// mode update reduce-scatters the s x R partial MTTKRP rows, solves its row block, all-gathers.
+// mode update combines the s x R partial MTTKRP rows over the communicator — one all-reduce plus
+// the redundant fused update for small messages, reduce-scatter / row-block solve / all-gather
+// otherwise (mode_update).
 #include "engine.h"
 
 #include <algorithm>
