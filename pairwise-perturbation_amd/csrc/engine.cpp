@@ -483,6 +483,20 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
                         pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
     grad_replicated_[i] = true;
     return;
+  } else if (i == 0 && (int64_t)sizeof(double) * s * R_ <= small_msg_bytes_) {
+    // same regime, sharded mode: the local rows are complete, so the owners' row blocks are
+    // all-gathered (the cheapest collective: blk x R doubles per rank) and every rank runs the
+    // fused update on the assembled s x R matrix.
+    const int64_t blk = block_rows(s, P_);
+    const int64_t nr = std::max<int64_t>(0, std::min(blk, s - blk * rank_));
+    double *mine = gatherbuf_ + (size_t)rank_ * blk * R_;
+    ops_.pack_blocks(M, nr, ldm, R_, blk, 1, mine);
+    comm_.allgather(mine, gatherbuf_, blk * R_);
+    ops_.unpack_blocks(gatherbuf_, s, s, R_, blk, P_, sendbuf_);
+    ops_.cp_mode_update(G_, N_, i, R_, lambda, sendbuf_, s, W_[i], s, gradW_[i], s, s, gradsq_ + i,
+                        pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
+    grad_replicated_[i] = true;
+    return;
   } else {
     grad_replicated_[i] = false;
     ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
