@@ -441,3 +441,39 @@ def test_edge_shapes(pp, ctx, lens, R, dtype):
             assert relerr(a, b) < 10 * FTOL[dtype], (lens, relerr(a, b))
     s.close()
     t.close()
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        N = int(rng.integers(2, 7))
+        lens = [int(rng.integers(1, 10)) for _ in range(N)]
+        lens[int(rng.integers(0, N))] = int(rng.integers(8, 40))   # one longer mode
+        # rank above a mode extent makes S singular and the reference's untruncated inverse
+        # undefined; its CLI resets such ranks (test_ALS.cxx:121-127)
+        R = min(int(rng.integers(1, 7)), min(lens))
+        cases.append((lens, R, int(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("lens,R,dtype", _fuzz_cases(40, 20260101))
+def test_random_shapes_against_oracle(pp, ctx, lens, R, dtype):
+    """seeded random orders (2-6), extents (1-39), ranks (1-6) and storage types: every MTTKRP, the
+    streaming residual and two exact sweeps against the oracle"""
+    V = O.fill_uniform(int(np.prod(lens)), 9, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W, G = O.init_factors(lens, R, 21), O.init_factors(lens, R, 22)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    for m in range(len(lens)):
+        assert relerr(s.mttkrp(m), O.mttkrp(V, W, m, 0)) < KTOL[dtype], (lens, R, m)
+    assert abs(s.residual() - O.residual(V, W)) < 1e-5 * O.residual(V, W)
+    s.sweeps_dt(2)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=1, resprint=1000)
+    W_got = s.get_factors()
+    # generic (not low-rank) tensors can make S ill-conditioned: compare the fit of the models
+    r_got, r_ref = O.residual(V, W_got), O.residual(V, W_ref)
+    assert abs(r_got - r_ref) < (1e-6 if dtype == 1 else 1e-3) * max(r_ref, 1e-3 * np.linalg.norm(V))
+    s.close()
+    t.close()
