@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--workload", default="cp4_s200_r10", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="storage type of the tensor in HBM (all factor math is fp64)")
+    ap.add_argument("--schedule", default=None, choices=["dt", "msdt"],
+                    help="sweep schedule (default: the engine's, msdt); same ALS iterates either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,6 +145,9 @@ def main():
     V = ppals.Tensor(ctx, lens, dtype).fill_cp(Wtrue)
     cp = ppals.CP(ctx, V, R)
     cp.set_factors(W0, G0)
+    if args.schedule:
+        cp.set_schedule(args.schedule)
+    schedule = cp.schedule
 
     def barrier():
         ctx.sync()
@@ -184,7 +189,6 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         sweeps_s = args.steps / elapsed
-        schedule = "dt" if os.environ.get("PPALS_DT_SCHEDULE", "msdt") == "dt" else "msdt"
         flops = sweep_flops(lens, R, schedule)
         esz = 4 if args.dtype == "f32" else 8
         out = {

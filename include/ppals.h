@@ -111,6 +111,15 @@ int ppals_cp_create(ppals_ctx *ctx, ppals_tensor *V, int R, ppals_cp **out);
 void ppals_cp_destroy(ppals_cp *s);
 int ppals_cp_set_factors(ppals_cp *s, const double *Wflat, const double *gradWflat /*may be NULL*/);
 int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat /*may be NULL*/);
+/* How an exact sweep walks the tensor — the ALS iterates are identical either way.
+ * PPALS_SCHEDULE_DT: the two first-level nodes of alsCP_DT (mttkrp_map_DT, common.cxx:20-133), two
+ * tensor scans per sweep. PPALS_SCHEDULE_MSDT (default): the multi-sweep tree of the class API
+ * (cp_msdt_optimizer.cxx:172-207), N/(N-1) scans per sweep. The environment variable
+ * PPALS_DT_SCHEDULE=dt|msdt sets the default of new sessions. */
+#define PPALS_SCHEDULE_DT 0
+#define PPALS_SCHEDULE_MSDT 1
+int ppals_cp_set_schedule(ppals_cp *s, int schedule);
+int ppals_cp_get_schedule(const ppals_cp *s);
 /* n exact dimension-tree sweeps (body of alsCP_DT's loop incl. Normalize, als_CP.cxx:215-303),
  * enqueued asynchronously on the engine stream; no print block, no host sync */
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda);

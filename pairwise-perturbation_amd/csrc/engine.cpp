@@ -264,7 +264,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (const char *e = std::getenv("PPALS_DT_SCHEDULE")) schedule_ = (std::string(e) == "dt") ? 0 : 1;
   if (N_ < 3) schedule_ = 0;
   if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
-  if (schedule_ == 1) {
+  if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
     ms_build_tree(0, N_ - 2, -1);
     ms_leaf_.assign(N_ - 1, -1);
     for (size_t k = 0; k < ms_nodes_.size(); k++)
@@ -279,6 +279,14 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   leaf_.assign(N_, -1);
   for (size_t k = 0; k < nodes_.size(); k++)
     if (nodes_[k].lo == nodes_[k].hi) leaf_[nodes_[k].lo] = (int)k;
+}
+
+// 0 = the reference's two-first-level-node tree (alsCP_DT), 1 = multi-sweep tree (default)
+void CpEngine::set_schedule(int schedule) {
+  if (schedule != 0 && schedule != 1) throw std::runtime_error("ppals: unknown sweep schedule");
+  schedule_ = (N_ < 3) ? 0 : schedule;
+  for (auto &n : nodes_) n.valid = false;
+  ms_invalidate();
 }
 
 CpEngine::~CpEngine() {

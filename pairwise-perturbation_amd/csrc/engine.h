@@ -64,6 +64,8 @@ class CpEngine {
   ~CpEngine();
 
   void set_factors(const double *Wflat, const double *gradWflat);
+  void set_schedule(int schedule);
+  int schedule() const { return schedule_; }
   void get_factors(double *Wflat, double *gradWflat);
 
   // body of the reference's sweep loop: als_CP.cxx:215-303 (clear cache, N mode updates,

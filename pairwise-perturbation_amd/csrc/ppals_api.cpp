@@ -257,6 +257,16 @@ int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat) {
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
+int ppals_cp_set_schedule(ppals_cp *s, int schedule) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL session");
+  if (schedule != PPALS_SCHEDULE_DT && schedule != PPALS_SCHEDULE_MSDT)
+    return fail(PPALS_ERR_ARG, "schedule must be PPALS_SCHEDULE_DT or PPALS_SCHEDULE_MSDT");
+  API_BEGIN
+  s->eng->set_schedule(schedule);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_get_schedule(const ppals_cp *s) { return s ? s->eng->schedule() : PPALS_ERR_ARG; }
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda) {
   if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN

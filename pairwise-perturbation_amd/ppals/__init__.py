@@ -47,7 +47,7 @@ EXPORTS = [
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
     "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_cp_pp_partupdate",
-    "ppals_cpd_als",
+    "ppals_cpd_als", "ppals_cp_set_schedule", "ppals_cp_get_schedule",
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_hosvd", "ppals_tucker_ttmc", "ppals_tucker_sweeps_dt", "ppals_tucker_dt",
@@ -257,6 +257,15 @@ class CP:
         if with_grad:
             return W, unflat(gf, self.lens, [self.R] * len(self.lens))
         return W
+
+    def set_schedule(self, schedule):
+        """"dt" (two first-level nodes, alsCP_DT) or "msdt" (multi-sweep tree, the default)"""
+        code = {"dt": 0, "msdt": 1}[schedule] if isinstance(schedule, str) else int(schedule)
+        _check(lib().ppals_cp_set_schedule(self._h, code))
+
+    @property
+    def schedule(self):
+        return {0: "dt", 1: "msdt"}[_check(lib().ppals_cp_get_schedule(self._h))]
 
     def sweeps_dt(self, n, lam=0.0):
         _check(lib().ppals_cp_sweeps_dt(self._h, n, C.c_double(lam)))

@@ -168,17 +168,18 @@ def test_jacobi_fallback_path(pp, tmp_path):
 @pytest.mark.parametrize("lens,R,kind", [([12, 10, 9, 11], 4, "r"), ([12, 10, 9, 11], 4, "r2"),
                                          ([16, 16, 16, 16], 10, "r"), ([14, 9, 11], 3, "r"),
                                          ([6, 5, 4, 5, 4, 3], 2, "r"), ([9, 7, 8, 6, 5], 2, "r")])
-def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule, monkeypatch):
+def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule):
     """K sweeps of the HIP engine == K sweeps of alsCP_DT in the oracle (factor matrices within
     1e-5 relative Frobenius for fp32 storage), for both sweep schedules: the multi-sweep tree
     (default: one tensor scan per N-1 mode updates) and the reference's two-node tree"""
-    monkeypatch.setenv("PPALS_DT_SCHEDULE", schedule)
     V, W = problem(lens, R, 3, kind)
     G = O.init_factors(lens, R, 99)
     K = 5
     _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
     t = pp.Tensor(ctx, lens, dtype).upload(V)
     s = pp.CP(ctx, t, R)
+    s.set_schedule(schedule)
+    assert s.schedule == (schedule if len(lens) >= 3 else "dt")
     s.set_factors(W, G)
     s.sweeps_dt(K)
     W_got, G_got = s.get_factors(with_grad=True)
@@ -477,3 +478,22 @@ def test_random_shapes_against_oracle(pp, ctx, lens, R, dtype):
     assert abs(r_got - r_ref) < (1e-6 if dtype == 1 else 1e-3) * max(r_ref, 1e-3 * np.linalg.norm(V))
     s.close()
     t.close()
+
+
+def test_schedule_switch_mid_run(pp, ctx):
+    """ppals_cp_set_schedule between sweeps: the cached contractions of the other schedule are
+    dropped and the iterates continue unchanged (both schedules compute the same ALS updates)"""
+    lens, R = [12, 10, 8, 6], 3
+    V, W = problem(lens, R, 4, "r")
+    G = O.init_factors(lens, R, 99)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=5, resprint=1000)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    for k, sched in enumerate(["msdt", "dt", "dt", "msdt", "msdt", "dt"]):
+        s.set_schedule(sched)
+        s.sweeps_dt(1)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < 1e-8, relerr(a, b)
+    with pytest.raises(pp.PpalsError):
+        s.set_schedule(7)
