@@ -44,6 +44,13 @@ typedef struct ppals_tucker ppals_tucker; /* a Tucker-HOOI session */
 const char *ppals_last_error(void);
 const char *ppals_version(void);
 
+/* Tucker sessions with a mode extent above 64 use the vendor symmetric eigensolver (rocSOLVER
+ * dsyevd). Its libraries register their code objects in milliseconds when they enter the process
+ * BEFORE the HIP runtime is initialised, and in minutes afterwards (0.013 s vs 253 s measured).
+ * Call this first thing — before ppals_ctx_create and before anything else touches the GPU (e.g.
+ * torch.cuda) — in a process that will run such a session. Without it they are loaded on demand. */
+int ppals_preload_eigensolver(void);
+
 /* ---- context (replaces CTF::World dw, test_ALS.cxx:200) ---- */
 int ppals_ctx_create(ppals_ctx **out, int device);
 void ppals_ctx_destroy(ppals_ctx *ctx);

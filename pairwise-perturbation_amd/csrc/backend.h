@@ -10,4 +10,6 @@ const char *backend_name();
 Ops *backend_make_ops(int device);
 void backend_unique_id(void *out128);
 Comm *backend_make_comm(Ops *ops, int rank, int nranks, const void *uid128);
+// load the vendor eigensolver libraries now (see ppals_preload_eigensolver); throws on failure
+void backend_preload_eigensolver();
 }  // namespace ppals

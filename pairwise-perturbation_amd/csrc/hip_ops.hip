@@ -31,6 +31,22 @@ static inline int grid_for(int64_t n, int block, int cap = 4096) {
   return (int)g;
 }
 
+// The vendor eigensolver libraries, process-wide. See hip_preload_eigensolver (hip_ops.h).
+struct EigLibs {
+  void *blas = nullptr, *solver = nullptr;
+};
+static EigLibs &eig_libs() {
+  static EigLibs l;
+  if (l.blas && l.solver) return l;
+  l.blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+  if (!l.blas) l.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  l.solver = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+  if (!l.solver) l.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!l.blas || !l.solver)
+    throw std::runtime_error(std::string("ppals: cannot load rocSOLVER: ") + dlerror());
+  return l;
+}
+
 class HipOps : public Ops {
  public:
   explicit HipOps(int device) {
@@ -708,14 +724,10 @@ class HipOps : public Ops {
   };
   RocSolver &rocsolver() {
     if (rs_.handle) return rs_;
-    void *lb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!lb) lb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    void *ls = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!ls) ls = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lb || !ls) throw std::runtime_error(std::string("ppals: cannot load rocSOLVER: ") + dlerror());
-    auto create = (int (*)(void **))dlsym(lb, "rocblas_create_handle");
-    auto set_stream = (int (*)(void *, hipStream_t))dlsym(lb, "rocblas_set_stream");
-    *(void **)(&rs_.dsyevd) = dlsym(ls, "rocsolver_dsyevd");
+    EigLibs &l = eig_libs();  // loads on first use unless hip_preload_eigensolver() ran earlier
+    auto create = (int (*)(void **))dlsym(l.blas, "rocblas_create_handle");
+    auto set_stream = (int (*)(void *, hipStream_t))dlsym(l.blas, "rocblas_set_stream");
+    *(void **)(&rs_.dsyevd) = dlsym(l.solver, "rocsolver_dsyevd");
     if (!create || !set_stream || !rs_.dsyevd)
       throw std::runtime_error("ppals: rocSOLVER symbols missing");
     if (create(&rs_.handle) != 0 || set_stream(rs_.handle, st_) != 0)
@@ -773,5 +785,6 @@ class HipOps : public Ops {
 };
 
 Ops *make_hip_ops(int device) { return new HipOps(device); }
+void hip_preload_eigensolver() { (void)eig_libs(); }
 
 }  // namespace ppals

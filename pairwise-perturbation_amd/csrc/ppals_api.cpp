@@ -57,6 +57,12 @@ extern "C" {
 const char *ppals_last_error(void) { return g_err.c_str(); }
 const char *ppals_version(void) { return backend_name(); }
 
+int ppals_preload_eigensolver(void) {
+  API_BEGIN
+  backend_preload_eigensolver();
+  return PPALS_OK;
+  API_END(PPALS_ERR_UNSUPPORTED)
+}
 int ppals_ctx_create(ppals_ctx **out, int device) {
   if (!out) return fail(PPALS_ERR_ARG, "ppals_ctx_create: out is NULL");
   *out = nullptr;

@@ -37,7 +37,8 @@ class _Opts(C.Structure):
 
 
 EXPORTS = [
-    "ppals_last_error", "ppals_version", "ppals_ctx_create", "ppals_ctx_destroy",
+    "ppals_last_error", "ppals_version", "ppals_preload_eigensolver", "ppals_ctx_create",
+    "ppals_ctx_destroy",
     "ppals_get_unique_id", "ppals_ctx_init_comm", "ppals_ctx_rank", "ppals_ctx_nranks",
     "ppals_ctx_sync", "ppals_profile_enable", "ppals_profile_read", "ppals_profile_reset",
     "ppals_tensor_create", "ppals_tensor_destroy", "ppals_tensor_local_rows",
@@ -111,6 +112,12 @@ def collinear_factors(lens, R, col_min=0.5, col_max=0.9, seed=0):
     _check(lib().ppals_collinear_factors(len(lens), arr, R, C.c_double(col_min),
                                          C.c_double(col_max), C.c_uint64(seed), _dp(wf)))
     return unflat(wf, lens, [R] * len(lens))
+
+
+def preload_eigensolver():
+    """load rocBLAS / rocSOLVER now — call before anything initialises the HIP runtime in this
+    process when a Tucker session with a mode extent > 64 will follow (include/ppals.h)"""
+    _check(lib().ppals_preload_eigensolver())
 
 
 class Context:

@@ -429,6 +429,7 @@ class CallbackComm : public Comm {
 const char *backend_name() { return "ppals hostsim (TEST INFRASTRUCTURE: host stand-in ops)"; }
 Ops *backend_make_ops(int) { return new HostOps(); }
 void backend_unique_id(void *out128) { std::memset(out128, 0, 128); }
+void backend_preload_eigensolver() {}
 // in the hostsim library the "unique id" argument carries the three callback pointers
 Comm *backend_make_comm(Ops *, int rank, int nranks, const void *uid128) {
   CommCallbacks cb;
