@@ -19,12 +19,13 @@ def golden_dir():
 
 
 def pytest_sessionstart(session):
-    """PPALS_TEST_ROCSOLVER=1 runs the Tucker cases whose modes exceed the in-LDS eigensolver: the
-    vendor libraries must enter the process before the HIP runtime is initialised (milliseconds
-    then, minutes later — include/ppals.h, ppals_preload_eigensolver)"""
-    if os.environ.get("PPALS_TEST_ROCSOLVER", "0") == "1":
-        try:
-            import ppals
-            ppals.preload_eigensolver()
-        except Exception as e:  # a CPU-only box: the gpu tests are deselected anyway
-            print(f"[conftest] eigensolver preload skipped: {e}")
+    """Tucker cases whose modes exceed the in-LDS eigensolver use rocSOLVER: its libraries must
+    enter the process before the HIP runtime is initialised (milliseconds then, minutes later —
+    include/ppals.h, ppals_preload_eigensolver), i.e. before the first test creates a context."""
+    if "not gpu" in (session.config.getoption("-m") or ""):
+        return
+    try:
+        import ppals
+        ppals.preload_eigensolver()
+    except Exception as e:  # no product library / no ROCm: the gpu tests will say so themselves
+        print(f"[conftest] eigensolver preload skipped: {e}")

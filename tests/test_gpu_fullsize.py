@@ -115,9 +115,6 @@ def test_cfg4_full_size(pp, ctx):
     V.close()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("PPALS_TEST_ROCSOLVER", "0") != "1",
-                    reason="s = 400 modes use rocSOLVER dsyevd, whose first call costs from tens of "
-                           "seconds to minutes of one-time initialisation; set PPALS_TEST_ROCSOLVER=1")
 def test_cfg5_tucker_full_size(pp, ctx):
     """configs[4]: Tucker order-3 s = 400, core 20^3. Input = a CP rank-10 tensor, whose
     multilinear rank (<= 10) is below the requested core size, so HOSVD and HOOI must reproduce it

@@ -82,9 +82,6 @@ def test_hosvd_and_dt_sweeps(pp, ctx, lens, ranks, dtype, tmp_path):
         assert abs(a[5] - b[5]) < (1e-4 if dtype == 0 else 1e-8) * np.linalg.norm(V)
 
 
-@pytest.mark.skipif(os.environ.get("PPALS_TEST_ROCSOLVER", "0") != "1",
-                    reason="mode extents > 64 use rocSOLVER dsyevd, whose first call costs minutes "
-                           "of one-time initialisation on a fresh box; set PPALS_TEST_ROCSOLVER=1")
 def test_large_mode_uses_vendor_eig(pp, ctx):
     lens, ranks = [72, 10, 9], [4, 3, 3]
     V = O.fill_uniform(int(np.prod(lens)), 8, lo=0.5, hi=1.0).reshape(lens, order="F")
