@@ -60,8 +60,10 @@ int tensor_create(Ops &ops, Comm &comm, int order, const int64_t *glens, int dty
   const int64_t blk = block_rows(glens[0], P);
   t.row0 = blk * comm.rank();
   t.llens[0] = std::max<int64_t>(0, std::min(blk, glens[0] - t.row0));
-  if (t.llens[0] <= 0) {
-    *err = "leading mode too short for this many ranks (a rank would own no rows)";
+  if (blk * (P - 1) >= glens[0]) {
+    // decided from global quantities only, so EVERY rank returns the error (no rank is left
+    // waiting in a collective): with row blocks of ceil(s0/P) the last rank would own no rows
+    *err = "leading mode too short for this many ranks (the last rank would own no rows)";
     return -1;
   }
   t.nloc = t.llens[0] * rest;

@@ -57,7 +57,20 @@ def main():
 
     cases = [([10, 7, 6, 5], 3, 1), ([9, 8, 7, 6], 4, 0), ([11, 6, 5], 2, 1),
              ([8, 4, 5, 4, 3, 3], 2, 1)]
+    # the degenerate partition (row blocks of ceil(s0/P) leave the last rank empty) is refused on
+    # every rank alike
+    if world >= 3:
+        bad = [world + 1 if world > 3 else 4, 4, 3]    # e.g. s0=5, P=4: blocks of 2 -> 2,2,1,0
+        if -(-bad[0] // world) * (world - 1) >= bad[0]:
+            try:
+                pp.Tensor(ctx, bad, 1)
+                raise AssertionError("degenerate partition accepted")
+            except pp.PpalsError as e:
+                assert "no rows" in str(e)
     for case_no, (lens, R, dtype) in enumerate(cases):
+        lens = list(lens)
+        while -(-lens[0] // world) * (world - 1) >= lens[0]:
+            lens[0] += 1  # keep every rank non-empty
         # alternate the two shard plans of a mode update: one all-reduce + redundant update
         # (small s x R) vs reduce-scatter + row-block update + all-gather
         os.environ["PPALS_COMM_SMALL_BYTES"] = "0" if case_no % 2 else str(1 << 20)
@@ -110,6 +123,9 @@ def main():
 
     for lens, ranks, dtype in [([9, 8, 7], [3, 2, 3], 1), ([7, 6, 5, 6], [2, 3, 2, 2], 1),
                                ([10, 6, 8], [3, 3, 2], 0)]:
+        lens = list(lens)
+        while -(-lens[0] // world) * (world - 1) >= lens[0]:
+            lens[0] += 1  # keep every rank non-empty
         V = O.fill_uniform(int(np.prod(lens)), 21, lo=0.5, hi=1.0).reshape(lens, order="F")
         t = pp.Tensor(ctx, lens, dtype).upload(V)
         tk = pp.Tucker(ctx, t, ranks)

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) rehearsal of the sharded ALS engine on CPU: torch.distributed/gloo behind
+"""world_size-2 (and 3, 4: a last rank with fewer rows) rehearsal of the sharded ALS engine on CPU: torch.distributed/gloo behind
 the communicator callbacks of the host-stand-in build (tests/hostsim). Covers the N>1 shard plan:
 leading-mode block partition, reduce-scatter of partial MTTKRP rows, all-gather of updated rows."""
 import os
@@ -19,7 +19,7 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_engine_matches_oracle(world):
     import hostsim_util
     hostsim_util.load()  # build once, before the ranks race for it
