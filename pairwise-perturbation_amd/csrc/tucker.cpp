@@ -70,6 +70,8 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(gather_);
   ops_.free(Ytmp_);
   ops_.free(Yacc_);
+  ops_.free(chain_[0]);
+  ops_.free(chain_[1]);
   for (auto p : Wprev_) ops_.free(p);
   for (auto p : Winit_) ops_.free(p);
   for (auto p : dW_) ops_.free(p);
@@ -119,10 +121,14 @@ void TuckerEngine::compute_node(int idx) {
     src = p.buf;
     dt = F64;
   }
-  // contract the sibling's modes one at a time (als_Tucker.cxx:216-227); ping-pong buffers
-  double *tmp = nullptr;
+  // contract the sibling's modes one at a time (als_Tucker.cxx:216-227). The intermediates of the
+  // chain live in two grow-only scratch buffers of the session (a per-call hipMalloc/hipFree of
+  // these multi-GB tensors stalled whole seconds at order 6) and keep the tensor's own precision
+  // (like the CP intermediate: fp32 tensor -> fp32 intermediates, fp64 accumulation inside the
+  // scan, fp64 node result).
   const void *cur = src;
   int cur_dt = dt;
+  int pp_slot = 0;
   // the sharded leaf of mode 0 is written with leading dimension blk (= rows per rank) so that it
   // is directly one block of the all-gather buffer (rows beyond the local extent stay zero)
   const bool leaf0_blocked = (dist_ && n.lo == 0 && n.hi == 0);
@@ -134,7 +140,8 @@ void TuckerEngine::compute_node(int idx) {
     const bool last = (m == n.shi);
     const int64_t Lout = (last && leaf0_blocked) ? blk : L;
     const int64_t out_elems = Lout * r_[m] * T;
-    double *dst;
+    void *dst;
+    int dst_dt;
     if (last) {
       if (n.cap < out_elems) {
         ops_.free(n.buf);
@@ -142,20 +149,27 @@ void TuckerEngine::compute_node(int idx) {
         n.cap = out_elems;
       }
       dst = n.buf;
+      dst_dt = F64;
       if (leaf0_blocked) ops_.zero(dst, sizeof(double) * out_elems);
     } else {
-      dst = (double *)ops_.alloc(sizeof(double) * out_elems);
+      dst_dt = V_.dtype;
+      const size_t need = dtype_size(dst_dt) * (size_t)out_elems;
+      if (chain_cap_[pp_slot] < need) {
+        ops_.free(chain_[pp_slot]);
+        chain_[pp_slot] = ops_.alloc(need);
+        chain_cap_[pp_slot] = need;
+      }
+      dst = chain_[pp_slot];
+      pp_slot ^= 1;
     }
     FactorRef f;
     f.ptr = wptr(m);
     f.rows = dims[m];
     f.ld = V_.glens[m];
     // out[l + Lout*(k + r*t)]: the mode product that keeps the mode in place (als_Tucker.cxx:224)
-    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, F64, Lout * r_[m], Lout);
-    if (tmp) ops_.free(tmp);  // synchronises before freeing
-    tmp = last ? nullptr : dst;
+    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, dst_dt, Lout * r_[m], Lout);
     cur = dst;
-    cur_dt = F64;
+    cur_dt = dst_dt;
     dims[m] = r_[m];
   }
   n.valid = true;
@@ -195,14 +209,21 @@ double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
   const void *cur = V_.data;
   int cur_dt = V_.dtype;
   double *prev = nullptr;
+  int pp_slot = 0;
   for (int m = 0; m < N_; m++) {
     if (m == skip) continue;
     int64_t L = 1, T = 1;
     for (int q = 0; q < m; q++) L *= dims[q];
     for (int q = m + 1; q < N_; q++) T *= dims[q];
-    double *dst = (double *)ops_.alloc(sizeof(double) * L * r_[m] * T);
+    const size_t need = sizeof(double) * (size_t)(L * r_[m] * T);
+    if (chain_cap_[pp_slot] < need) {
+      ops_.free(chain_[pp_slot]);
+      chain_[pp_slot] = ops_.alloc(need);
+      chain_cap_[pp_slot] = need;
+    }
+    double *dst = (double *)chain_[pp_slot];
+    pp_slot ^= 1;
     ops_.ttm_keep(cur, cur_dt, L, dims[m], T, wptr(m), V_.glens[m], r_[m], dst);
-    if (prev) ops_.free(prev);
     prev = dst;
     cur = dst;
     cur_dt = F64;
@@ -211,7 +232,7 @@ double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
   int64_t e = 1;
   for (int m = 0; m < N_; m++) e *= dims[m];
   *elems = e;
-  return prev;
+  return prev;  // lives in the session's chain scratch until the next chain runs
 }
 
 int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
@@ -220,7 +241,6 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
   // sharded: skip == 0 returns the local rows, every other result is summed over the ranks
   if (dist_ && skip != 0) comm_.allreduce_sum(Y, e);
   if (Yhost) ops_.d2h(Yhost, Y, sizeof(double) * e);
-  ops_.free(Y);
   return e;
 }
 
@@ -229,7 +249,6 @@ void TuckerEngine::compute_core_full() {
   double *Y = ttmc_chain(-1, &e);
   if (dist_) comm_.allreduce_sum(Y, ncore_);
   ops_.d2d(core_, Y, sizeof(double) * ncore_);
-  ops_.free(Y);
 }
 
 void TuckerEngine::set_factors(const double *Wflat) {
