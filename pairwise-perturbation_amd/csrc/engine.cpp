@@ -267,14 +267,8 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (N_ < 3) schedule_ = 0;
   if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
-    ms_build_tree(0, N_ - 2, -1);
-    ms_leaf_.assign(N_ - 1, -1);
-    for (size_t k = 0; k < ms_nodes_.size(); k++)
-      if (ms_nodes_[k].lo == ms_nodes_[k].hi) ms_leaf_[ms_nodes_[k].lo] = (int)k;
-    if (ms_nodes_.size() + 1 > 32) throw std::runtime_error("ppals: tensor order too large");
+    ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
-    ms_X_.slot = 0;
-    for (size_t k = 0; k < ms_nodes_.size(); k++) ms_nodes_[k].t.slot = (int)k + 1;
   }
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
@@ -601,45 +595,144 @@ void CpEngine::ms_reserve(RTensor &t, size_t bytes) {
   }
 }
 
-// new step: X = V x_root W_root (one tensor scan, K1-type on whichever resident layout keeps the
-// contracted mode away from the fastest index), stored in the tensor's own precision
-void CpEngine::ms_start_step(int root) {
-  ms_root_ = root;
+// How many modes one first-level contraction removes (the "root set" of a step). With k roots a
+// sweep needs N/(N-k) tensor scans and each step writes once / reads twice an intermediate of
+// R / prod(root extents) of the tensor's size; a written byte costs ~2.5 read bytes on this part
+// (profiles/README.md). k = 1 wins at order 4 (cfg2: 1.33 x 1.23 vs 2.0), k = 2 at order 6 with
+// s = 50, R = 6 (1.2 x 1.54 vs 1.5 x 1.01). PPALS_MSDT_ROOTS overrides.
+int CpEngine::ms_choose_roots() const {
+  if (const char *e = std::getenv("PPALS_MSDT_ROOTS")) {
+    const int k = std::atoi(e);
+    if (k >= 1 && k <= N_ - 2) return k;
+  }
+  double gm = 1;
+  for (int m = 0; m < N_; m++) gm *= std::pow((double)V_.glens[m], 1.0 / N_);
+  int best = 1;
+  double best_cost = 1e300;
+  for (int k = 1; k <= std::max(1, N_ / 2) && k <= N_ - 2; k++) {
+    const double xfrac = R_ / std::pow(gm, k);
+    const double cost = (double)N_ / (N_ - k) * (1.0 + 4.5 * xfrac);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = k;
+    }
+  }
+  return best;
+}
+
+// (re)build the step tree for k root modes: binary tree over the N - k positions of the step's
+// mode list. Cached tensors of the old tree are released.
+void CpEngine::ms_set_roots(int k) {
+  for (auto &n : ms_nodes_) {
+    ops_.free(n.t.buf);
+    for (auto &t : n.tmp) ops_.free(t.buf);
+  }
+  ms_nodes_.clear();
+  ms_k_ = k;
+  ms_build_tree(0, N_ - k - 1, -1);
+  ms_leaf_.assign(N_ - k, -1);
+  for (size_t q = 0; q < ms_nodes_.size(); q++)
+    if (ms_nodes_[q].lo == ms_nodes_[q].hi) ms_leaf_[ms_nodes_[q].lo] = (int)q;
+  if (ms_nodes_.size() + 1 > 32) throw std::runtime_error("ppals: tensor order too large");
+  ms_X_.slot = 0;
+  for (size_t q = 0; q < ms_nodes_.size(); q++) ms_nodes_[q].t.slot = (int)q + 1;
+  ms_invalidate();
+}
+
+// new step: X = V contracted with the k root modes first, ..., first + k - 1 (cyclic) in ONE
+// tensor scan on whichever resident layout stores them next to each other and behind at least one
+// other mode; X is kept in the tensor's own precision
+void CpEngine::ms_start_step(int first) {
+  const int k = ms_k_;
+  ms_root_ = first;
+  auto in_set = [&](int m) { return ((m - first + N_) % N_) < k; };
   ms_order_.clear();
-  for (int k = 1; k < N_; k++) ms_order_.push_back((root + k) % N_);
+  for (int q = k; q < N_; q++) ms_order_.push_back((first + q) % N_);
   for (auto &n : ms_nodes_) n.t.valid = false;
   const int mid = (N_ - 1) / 2;
-  std::vector<int> layout;  // storage order of the tensor copy that is scanned
-  const void *src = V_.data;
-  if (root <= mid) ensure_transposed();
-  if (root <= mid && vt_state_ == 1) {
-    for (int m = mid + 1; m < N_; m++) layout.push_back(m);
-    for (int m = 0; m <= mid; m++) layout.push_back(m);
-    src = VT_;
-  } else {
-    for (int m = 0; m < N_; m++) layout.push_back(m);
+  // candidate storage orders: the tensor itself, and its second resident layout
+  std::vector<int> lay_v, lay_t;
+  for (int m = 0; m < N_; m++) lay_v.push_back(m);
+  for (int m = mid + 1; m < N_; m++) lay_t.push_back(m);
+  for (int m = 0; m <= mid; m++) lay_t.push_back(m);
+  // (position of the first root mode, number of consecutive root modes from there)
+  auto run_of = [&](const std::vector<int> &lay) {
+    int p0 = -1;
+    for (int p = 0; p < N_; p++)
+      if (in_set(lay[p])) {
+        p0 = p;
+        break;
+      }
+    int len = 0;
+    while (p0 + len < N_ && in_set(lay[p0 + len])) len++;
+    return std::make_pair(p0, len);
+  };
+  auto rows_before = [&](const std::vector<int> &lay, int p0) {
+    int64_t l = 1;
+    for (int p = 0; p < p0; p++) l *= ext(lay[p]);
+    return l;
+  };
+  // among the layouts that store the root modes next to each other, scan the one with the most
+  // rows in front of them (long contiguous runs per reduction index; a leading root set would be
+  // a column-strided scan)
+  const auto rv = run_of(lay_v), rt = run_of(lay_t);
+  const bool v_ok = rv.second == k, t_ok = rt.second == k;
+  const int64_t Lv = v_ok ? rows_before(lay_v, rv.first) : 0;
+  const int64_t Lt = t_ok ? rows_before(lay_t, rt.first) : 0;
+  bool use_t = false;
+  if (t_ok && Lt > Lv) {
+    ensure_transposed();
+    use_t = vt_state_ == 1;
   }
-  int64_t L = 1, T = 1;
+  if (!v_ok && !use_t) {
+    // a root set that wraps around the last mode is adjacent only in the second layout; without
+    // it (allocation failed / PPALS_TRANSPOSED_COPY=0) fall back to single-mode roots for good
+    if (k == 1) throw std::runtime_error("ppals: internal error (single root not adjacent)");
+    ms_set_roots(1);
+    ms_start_step((first + k - 1) % N_);  // the mode just before the one about to be updated
+    return;
+  }
+  const std::vector<int> &layout = use_t ? lay_t : lay_v;
+  const void *src = use_t ? VT_ : V_.data;
+  int64_t L = 1, J = 1, T = 1;
   bool before = true;
   ms_X_.modes.clear();
+  std::vector<FactorRef> f;
+  unsigned mask = 0;
   for (int m : layout) {
-    if (m == root) {
+    if (in_set(m)) {
       before = false;
+      J *= ext(m);
+      f.push_back(fref(m, W_.data()));  // storage order: first listed = fastest
+      mask |= 1u << m;
       continue;
     }
     (before ? L : T) *= ext(m);
     ms_X_.modes.push_back(m);
   }
   ms_X_.dt = V_.dtype;
-  ms_X_.contracted = 1u << root;
+  ms_X_.contracted = mask;
   ms_reserve(ms_X_, (size_t)L * T * R_ * dtype_size(ms_X_.dt));
-  FactorRef f = fref(root, W_.data());
   if (getenv("PPALS_DEBUG_ADDR"))
-    fprintf(stderr, "[ppals] step root %d: src %p (V %p VT %p) X %p L %lld J %lld T %lld\n", root, src,
-            V_.data, (void *)VT_, ms_X_.buf, (long long)L, (long long)ext(root), (long long)T);
-  ops_.scan_contract(src, V_.dtype, L, ext(root), T, &f, 1, R_, ms_X_.buf, ms_X_.dt, L, L * T);
+    fprintf(stderr, "[ppals] step roots %d..+%d: src %p (V %p VT %p) X %p L %lld J %lld T %lld\n",
+            first, k, src, V_.data, (void *)VT_, ms_X_.buf, (long long)L, (long long)J, (long long)T);
+  ops_.scan_contract(src, V_.dtype, L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt, L,
+                     L * T);
   ms_X_.pending = false;
   ms_X_.valid = true;
+}
+
+// one mode update of the multi-sweep schedule: starts a new step when mode i belongs to the root
+// set of the running one (its factor was frozen into X), i.e. after N - k updates
+void CpEngine::ms_mode_update(int i, double lambda) {
+  if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) ms_start_step((i - ms_k_ + N_) % N_);
+  int pos = -1;
+  for (size_t q = 0; q < ms_order_.size(); q++)
+    if (ms_order_[q] == i) pos = (int)q;
+  const int leaf = ms_leaf_[pos];
+  ms_compute(leaf);
+  mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
+  ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update
 }
 
 // dst = src contracted with `mode` (rank index shared), fp64 result; in_scale = pending factor of
@@ -695,16 +788,7 @@ void CpEngine::ms_compute(int idx) {
 }
 
 void CpEngine::sweep_msdt(double lambda) {
-  for (int i = 0; i < N_; i++) {
-    if (ms_root_ < 0 || ms_root_ == i) ms_start_step((i - 1 + N_) % N_);
-    int pos = -1;
-    for (int k = 0; k < N_ - 1; k++)
-      if (ms_order_[k] == i) pos = k;
-    const int leaf = ms_leaf_[pos];
-    ms_compute(leaf);
-    mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
-    ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update
-  }
+  for (int i = 0; i < N_; i++) ms_mode_update(i, lambda);
   normalize();
   grad_from_sweep_ = true;
 }
@@ -733,14 +817,7 @@ void CpEngine::update_modes(int first, int count, double lambda) {
   for (int k = 0; k < count; k++) {
     const int i = (first + k) % N_;
     if (schedule_ == 1) {
-      if (ms_root_ < 0 || ms_root_ == i) ms_start_step((i - 1 + N_) % N_);
-      int pos = -1;
-      for (int q = 0; q < N_ - 1; q++)
-        if (ms_order_[q] == i) pos = q;
-      const int leaf = ms_leaf_[pos];
-      ms_compute(leaf);
-      mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
-      ms_nodes_[leaf].t.valid = false;
+      ms_mode_update(i, lambda);
     } else {
       if (i == 0 || k == 0)
         for (auto &n : nodes_) n.valid = false;

@@ -132,10 +132,14 @@ class CpEngine {
   void sweep_msdt(double lambda);
   void ms_invalidate() { ms_root_ = -1; }
   int schedule_ = 1;  // 1: multi-sweep dimension tree (default), 0: the reference's two-node tree
-  int ms_root_ = -1;
+  int ms_root_ = -1;  // first mode of the running step's root set (-1: no step)
+  int ms_k_ = 1;      // modes contracted by one first-level scan (ms_choose_roots)
+  int ms_choose_roots() const;
+  void ms_set_roots(int k);
+  void ms_mode_update(int i, double lambda);
   RTensor ms_X_;
   std::vector<MsNode> ms_nodes_;
-  std::vector<int> ms_order_;  // the N-1 modes of the step in update order
+  std::vector<int> ms_order_;  // the N-k modes of the step in update order
   std::vector<int> ms_leaf_;   // node index of each list position
   double *ms_scales_ = nullptr;  // one pending-Normalize scalar per cached tensor (<= 32)
   const double *ms_scale_of(const RTensor &t) const { return t.pending ? ms_scales_ + t.slot : nullptr; }

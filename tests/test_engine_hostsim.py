@@ -30,6 +30,7 @@ test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
 test_driver_pp_partupdate_matches_oracle = G.test_driver_pp_partupdate_matches_oracle
 test_schedule_switch_mid_run = G.test_schedule_switch_mid_run
+test_msdt_root_counts = G.test_msdt_root_counts
 test_edge_shapes = G.test_edge_shapes
 test_random_shapes_against_oracle = G.test_random_shapes_against_oracle
 test_class_api_als_matches_oracle = G.test_class_api_als_matches_oracle

@@ -497,3 +497,33 @@ def test_schedule_switch_mid_run(pp, ctx):
         assert relerr(a, b) < 1e-8, relerr(a, b)
     with pytest.raises(pp.PpalsError):
         s.set_schedule(7)
+
+
+@pytest.mark.parametrize("roots", [1, 2, 3])
+@pytest.mark.parametrize("lens,R", [([12, 10, 8, 6], 3), ([7, 6, 5, 4, 5], 2), ([5, 4, 5, 4, 3, 4], 2),
+                                    ([16, 8, 12, 8], 20)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_msdt_root_counts(pp, ctx, lens, R, roots, dtype, monkeypatch):
+    """the multi-sweep schedule with 1, 2 or 3 modes contracted by the first-level scan (a sweep
+    then needs N/(N-k) tensor scans; the engine picks k from a cost model, PPALS_MSDT_ROOTS forces
+    it): root sets that wrap around the last mode, sets that are adjacent only in the second
+    resident layout, both storage types — same ALS iterates as alsCP_DT"""
+    if roots > len(lens) - 2:
+        pytest.skip("needs at least two modes outside the root set")
+    monkeypatch.setenv("PPALS_MSDT_ROOTS", str(roots))
+    V, W = problem(lens, R, 7, "r")
+    G = O.init_factors(lens, R, 99)
+    K = 2 * len(lens) // max(1, len(lens) - roots) + 2   # several full cycles of root sets
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_schedule("msdt")
+    s.set_factors(W, G)
+    s.sweeps_dt(K)
+    W_got, G_got = s.get_factors(with_grad=True)
+    for a, b in zip(W_got, W_ref):
+        assert relerr(a, b) < FTOL[dtype], (roots, relerr(a, b))
+    gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
+    assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
+    s.close()
+    t.close()

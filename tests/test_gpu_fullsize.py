@@ -115,6 +115,29 @@ def test_cfg4_full_size(pp, ctx):
     V.close()
 
 
+@pytest.mark.parametrize("roots", [1, 2])
+def test_script_order6_full_size(pp, ctx, roots, monkeypatch):
+    """the shape of the reference's own job scripts (script/*.py: -dim 6 -size 50 -rank 6; 62.5 GB
+    in fp32) with one and with two modes contracted per tensor scan, against the closed form"""
+    monkeypatch.setenv("PPALS_MSDT_ROOTS", str(roots))
+    lens, A, W, G = _problem(pp, 50, 6, N=6)
+    try:
+        V = pp.Tensor(ctx, lens, 0).fill_cp(A)
+    except pp.PpalsError as e:
+        pytest.skip(f"cannot hold the 62.5 GB tensor: {e}")
+    assert abs(V.norm() - RS.norm(A)) < 2e-6 * RS.norm(A)
+    s = pp.CP(ctx, V, 6)
+    s.set_factors(W, G)
+    K = 4
+    s.sweeps_dt(K)
+    W_ref, _ = RS.als_cp_dt(A, W, G, K)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < 1e-5, (roots, relerr(a, b))
+    assert abs(s.residual() - RS.residual(A, W_ref)) < 1e-4 * RS.norm(A)
+    s.close()
+    V.close()
+
+
 def test_cfg5_tucker_full_size(pp, ctx):
     """configs[4]: Tucker order-3 s = 400, core 20^3. Input = a CP rank-10 tensor, whose
     multilinear rank (<= 10) is below the requested core size, so HOSVD and HOOI must reproduce it
