@@ -328,7 +328,8 @@ CpEngine::~CpEngine() {
 // rows of (c,d) contiguously — the same suffix-scan access pattern as the "ab" node (K1) instead
 // of the column-strided prefix scan (K2). Costs one extra copy of V in HBM (288 GB are there for
 // it; cfg2: +6.4 GB, cfg4: +102 GB) and one transpose per session; the bytes read per sweep do
-// not change. PPALS_TRANSPOSED_COPY=0 or an allocation failure falls back to the prefix scan.
+// not change. Built once, when the session is created. PPALS_TRANSPOSED_COPY=0 or an allocation
+// failure falls back to the prefix scan (and to single-mode root sets).
 void CpEngine::ensure_transposed() {
   if (vt_state_ != 0) return;
   vt_state_ = -1;
