@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -52,6 +53,18 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   leaf_.assign(N_, -1);
   for (size_t k = 0; k < nodes_.size(); k++)
     if (nodes_[k].lo == nodes_[k].hi) leaf_[nodes_[k].lo] = (int)k;
+  // second resident layout V^T[(right modes), (left modes)] (as in the CP engine): the first-level
+  // node that contracts the LEFT half of the modes then runs as row-contiguous scans too, instead
+  // of a column-strided scan of the leading mode followed by scans with a handful of rows
+  const char *env = std::getenv("PPALS_TRANSPOSED_COPY");
+  if (N_ >= 3 && !(env && std::atoi(env) == 0)) {
+    const int mid = (N_ - 1) / 2;
+    int64_t rows = 1, cols = 1;
+    for (int m = 0; m <= mid; m++) rows *= ext(m);
+    for (int m = mid + 1; m < N_; m++) cols *= ext(m);
+    VT_ = ops_.try_alloc((size_t)rows * cols * dtype_size(V_.dtype));
+    if (VT_) ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
+  }
 }
 
 TuckerEngine::~TuckerEngine() {
@@ -72,6 +85,7 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(Yacc_);
   ops_.free(chain_[0]);
   ops_.free(chain_[1]);
+  ops_.free(VT_);
   for (auto p : Wprev_) ops_.free(p);
   for (auto p : Winit_) ops_.free(p);
   for (auto p : dW_) ops_.free(p);
@@ -104,9 +118,62 @@ int64_t TuckerEngine::node_elems(const Node &n) const {
   return e;
 }
 
+// First-level node that contracts the left half [0, shi] of the modes, on the second layout
+// [shi+1..N-1 | 0..shi]: the contracted modes are the trailing ones there, so they are removed
+// last-first by row-contiguous scans; the result [right extents | left ranks] is transposed into
+// the node's own order [left ranks | right extents] (a few hundred MB at most).
+void TuckerEngine::compute_left_half_on_vt(Node &n) {
+  const int nl = n.shi + 1, nr = N_ - nl;  // left (contracted) / right (kept) mode counts
+  std::vector<int64_t> dims;              // extents in VT storage order
+  for (int m = nl; m < N_; m++) dims.push_back(ext(m));
+  for (int m = 0; m < nl; m++) dims.push_back(ext(m));
+  const void *cur = VT_;
+  int cur_dt = V_.dtype;
+  int pp_slot = 0;
+  for (int m = n.shi; m >= 0; m--) {
+    const int p = nr + m;  // storage position of mode m
+    int64_t L = 1, T = 1;
+    for (int q = 0; q < p; q++) L *= dims[q];
+    for (int q = p + 1; q < N_; q++) T *= dims[q];
+    const bool last = (m == 0);
+    const int dst_dt = last ? F64 : V_.dtype;
+    const size_t need = dtype_size(dst_dt) * (size_t)(L * r_[m] * T);
+    if (chain_cap_[pp_slot] < need) {
+      ops_.free(chain_[pp_slot]);
+      chain_[pp_slot] = ops_.alloc(need);
+      chain_cap_[pp_slot] = need;
+    }
+    void *dst = chain_[pp_slot];
+    pp_slot ^= 1;
+    FactorRef f;
+    f.ptr = wptr(m);
+    f.rows = dims[p];
+    f.ld = V_.glens[m];
+    ops_.scan_contract(cur, cur_dt, L, dims[p], T, &f, 1, r_[m], dst, dst_dt, L * r_[m], L);
+    cur = dst;
+    cur_dt = dst_dt;
+    dims[p] = r_[m];
+  }
+  int64_t rows = 1, cols = 1;
+  for (int q = 0; q < nr; q++) rows *= dims[q];
+  for (int q = nr; q < N_; q++) cols *= dims[q];
+  if (n.cap < rows * cols) {
+    ops_.free(n.buf);
+    n.buf = (double *)ops_.alloc(sizeof(double) * rows * cols);
+    n.cap = rows * cols;
+  }
+  ops_.transpose2d(cur, F64, rows, cols, n.buf);
+  n.valid = true;
+}
+
 void TuckerEngine::compute_node(int idx) {
   Node &n = nodes_[idx];
   if (n.valid) return;
+  // (the sharded leaf of mode 0 keeps its own blocked layout: not this route)
+  if (n.parent < 0 && n.slo == 0 && n.shi < N_ - 1 && VT_ && !(dist_ && n.lo == 0 && n.hi == 0)) {
+    compute_left_half_on_vt(n);
+    return;
+  }
   std::vector<int64_t> dims(N_);
   const void *src;
   int dt;

@@ -31,6 +31,7 @@ class TuckerEngine {
   void build_tree(int lo, int hi, int parent);
   // dims of a node's tensor: ranks on the contracted modes, full extent elsewhere
   void compute_node(int idx);
+  void compute_left_half_on_vt(Node &n);
   double *ttmc_chain(int skip, int64_t *elems);  // result lives in the chain scratch
   int64_t ext(int m) const { return m == 0 ? V_.llens[0] : V_.glens[m]; }
   const double *wptr(int m) const { return W_[m] + (m == 0 ? V_.row0 : 0); }
@@ -64,6 +65,7 @@ class TuckerEngine {
   std::map<std::string, PPOp> pp_;
   std::vector<double *> Wprev_, Winit_, dW_;
   double *Ytmp_ = nullptr, *Yacc_ = nullptr;
+  void *VT_ = nullptr;  // second resident layout [(right modes), (left modes)], nullptr: not held
   void *chain_[2] = {nullptr, nullptr};  // ping-pong scratch of the mode-product chains
   size_t chain_cap_[2] = {0, 0};
   int64_t ytmp_cap_ = 0, yacc_cap_ = 0;
