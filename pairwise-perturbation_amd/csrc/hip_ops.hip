@@ -670,9 +670,9 @@ class HipOps : public Ops {
   // als_Tucker.cxx:20,402). SURVEY.md §2.1 K12 allows the vendor symmetric eigensolver here:
   // rocSOLVER dsyevd, resolved with dlopen on first use (only Tucker sessions ever load it).
   void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
-    if (J <= 64) {  // small modes: in-LDS Jacobi, one wave
-      size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64) + sizeof(int) * 64;
-      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(64), lds, st_, G, (int)J, rank, U);
+    if (J <= 64) {  // small modes: in-LDS Jacobi, one block
+      size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64 + 17) + sizeof(int) * 64;
+      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, G, (int)J, rank, U);
       HIP_CHECK(hipGetLastError());
       return;
     }

@@ -426,19 +426,29 @@ __device__ inline double hadamard_entry(const double *__restrict__ Gall, int N, 
 // for a symmetric matrix this equals the reference's V diag(1/sigma) U^T (common.cxx:717-722),
 // including its behaviour of NOT truncating tiny singular values.
 // LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
-__device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq, int R) {
-  const int lane = threadIdx.x & 63;
+// NTHR cooperating threads: 64 = one wave (wave-level barriers; callable from one wave of a larger
+// block), otherwise the whole block of NTHR threads (block barriers; `red` = 17 doubles of LDS for
+// the convergence sums).
+template <int NTHR>
+__device__ inline void jacobi_eig_t(double *A, double *Q, double *cs, int *pq, int R, double *red) {
+  const int lane = NTHR == 64 ? (threadIdx.x & 63) : threadIdx.x;
+  auto sync = [&]() {
+    if constexpr (NTHR == 64)
+      wave_sync();
+    else
+      __syncthreads();
+  };
   const int ldA = R + 1;
-  for (int e = lane; e < R * R; e += 64) {
+  for (int e = lane; e < R * R; e += NTHR) {
     const int i = e % R, j = e / R;
     Q[i * ldA + j] = (i == j) ? 1.0 : 0.0;
   }
-  wave_sync();
+  sync();
   const int n2 = (R + 1) & ~1;  // players (even); index R (if odd) is a bye
   const int npair = n2 / 2;
   for (int sweep = 0; sweep < 40; sweep++) {
     double off = 0, diag = 0;
-    for (int e = lane; e < R * R; e += 64) {
+    for (int e = lane; e < R * R; e += NTHR) {
       const int i = e % R, j = e / R;
       const double a = A[i * ldA + j];
       if (i == j)
@@ -446,10 +456,15 @@ __device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq
       else
         off += a * a;
     }
-    off = wave_sum(off);
-    diag = wave_sum(diag);
-    off = __shfl(off, 0, 64);
-    diag = __shfl(diag, 0, 64);
+    if constexpr (NTHR == 64) {
+      off = wave_sum(off);
+      diag = wave_sum(diag);
+      off = __shfl(off, 0, 64);
+      diag = __shfl(diag, 0, 64);
+    } else {
+      off = block_sum(off, red);
+      diag = block_sum(diag, red);
+    }
     if (off <= 1e-30 * diag || off == 0.0) break;
     for (int rd = 0; rd < n2 - 1; rd++) {
       if (lane < npair) {  // round-robin pairing: player n2-1 fixed, the others rotate
@@ -480,8 +495,8 @@ __device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq
         pq[2 * lane] = p;
         pq[2 * lane + 1] = q;
       }
-      wave_sync();
-      for (int e = lane; e < npair * R; e += 64) {  // A <- A J, Q <- Q J
+      sync();
+      for (int e = lane; e < npair * R; e += NTHR) {  // A <- A J, Q <- Q J
         const int pi = e / R, i = e % R;
         const int p = pq[2 * pi], q = pq[2 * pi + 1];
         if (p >= 0) {
@@ -494,8 +509,8 @@ __device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq
           Q[i * ldA + q] = sn * qip + c * qiq;
         }
       }
-      wave_sync();
-      for (int e = lane; e < npair * R; e += 64) {  // A <- J^T A
+      sync();
+      for (int e = lane; e < npair * R; e += NTHR) {  // A <- J^T A
         const int pi = e / R, j = e % R;
         const int p = pq[2 * pi], q = pq[2 * pi + 1];
         if (p >= 0) {
@@ -505,10 +520,13 @@ __device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq
           A[q * ldA + j] = sn * apj + c * aqj;
         }
       }
-      wave_sync();
+      sync();
     }
   }
-  wave_sync();
+  sync();
+}
+__device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq, int R) {
+  jacobi_eig_t<64>(A, Q, cs, pq, R, nullptr);
 }
 __device__ inline void jacobi_inverse_wave(double *A, double *Q, double *cs, int *pq, int R,
                                            double *Sinv_out) {
@@ -943,22 +961,25 @@ __global__ __launch_bounds__(256) void k_unfold_gram(const TV *__restrict__ X, i
     if (p < J && q < J) g[p + J * q] = acc[i];
   }
 }
-// Leading eigenvectors of a small symmetric matrix (J <= 64) entirely in LDS, ONE wave: the same
-// parallel-ordered Jacobi as the R x R solve, eigenvalues ranked descending. Used for the Tucker
-// eigen-step whenever the mode extent is small (no vendor library involved).
-__global__ __launch_bounds__(64) void k_top_eig_small(const double *__restrict__ G, int J, int rank,
-                                                      double *__restrict__ U) {
+// Leading eigenvectors of a small symmetric matrix (J <= 64) entirely in LDS, one 256-thread
+// block: the same parallel-ordered Jacobi as the R x R solve (a round's J/2 rotations touch J^2
+// elements: 4 waves shorten the 2.8 ms one wave needs at J = 50 to well under a millisecond),
+// eigenvalues ranked descending. Used for the Tucker eigen-step whenever the mode extent is small
+// (no vendor library involved). dynamic LDS: A[J][J+1] | Q[J][J+1] | cs[64] | pq[64 ints] | red[17]
+__global__ __launch_bounds__(256) void k_top_eig_small(const double *__restrict__ G, int J,
+                                                       int rank, double *__restrict__ U) {
   extern __shared__ double lds[];
   const int ldA = J + 1;
   double *A = lds;
   double *Q = A + J * ldA;
   double *cs = Q + J * ldA;
   int *pq = (int *)(cs + 64);
-  const int lane = threadIdx.x;
-  for (int e = lane; e < J * J; e += 64) A[(e % J) * ldA + e / J] = G[e];
-  wave_sync();
-  jacobi_eig_wave(A, Q, cs, pq, J);
-  for (int k = lane; k < J; k += 64) {
+  double *red = (double *)(pq + 64);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < J * J; e += 256) A[(e % J) * ldA + e / J] = G[e];
+  __syncthreads();
+  jacobi_eig_t<256>(A, Q, cs, pq, J, red);
+  for (int k = tid; k < J; k += 256) {
     const double wk = A[k * ldA + k];
     int pos = 0;  // number of eigenvalues that come before k in descending order
     for (int j = 0; j < J; j++) {
