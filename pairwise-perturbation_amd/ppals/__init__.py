@@ -67,6 +67,11 @@ def lib(path=None):
         _lib = C.CDLL(p)
         _lib.ppals_last_error.restype = C.c_char_p
         _lib.ppals_version.restype = C.c_char_p
+        # the product binding only ever drives the HIP build; the host stand-in of tests/hostsim is
+        # reachable solely through tests/hostsim_util.py, which loads this file under another name
+        if __name__ == "ppals" and b"hostsim" in _lib.ppals_version():
+            _lib = None
+            raise PpalsError(f"{p} is the test stand-in, not the HIP engine (no CPU fallback)")
     return _lib
 
 
