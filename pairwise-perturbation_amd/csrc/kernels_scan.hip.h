@@ -473,7 +473,10 @@ typedef unsigned int scan_u32x4 __attribute__((vector_size(16)));
 // Measured and rejected (profiles/r01j_scan_bench_*, same-box A/B of bench.py): a two-cursor form
 // with the load cursor 2 blocks ahead: -9 % at one n-tile (registers), and at two n-tiles (2
 // waves/SIMD) 4.6 TB/s, still behind the global-load kernel k_scan_suffix_fast (5.6 TB/s) that the
-// launcher keeps for that case; the same form with 1 block ahead: -2.5 % against this one.
+// launcher keeps for that case; the same form with 1 block ahead: -2.5 % against this one; one
+// column tile per WAVE (4/ct row groups x ct column tiles per workgroup, one-tile register budget,
+// the tensor bytes shared through the L2): 3.8 TB/s at two tiles — the doubled L2 -> CU traffic
+// costs more than the lost occupancy.
 template <typename TV, int NT, int OPT = 1>
 __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
