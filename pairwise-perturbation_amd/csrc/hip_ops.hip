@@ -93,6 +93,8 @@ class HipOps : public Ops {
     if (ws_krp_) hipFree(ws_krp_);
     if (ws_part_) hipFree(ws_part_);
     if (ws_small_) hipFree(ws_small_);
+    if (ws_big_) hipFree(ws_big_);
+    if (ws_big2_) hipFree(ws_big2_);
     hipStreamDestroy(st_);
   }
 
@@ -173,8 +175,6 @@ class HipOps : public Ops {
   template <typename TV, int MODE>
   void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                    double *out) {
-    if (R > 64)
-      throw std::runtime_error("ppals: fill_rank/residual support R <= 64 in this version");
     int kch = 32;
     while ((K + kch - 1) / kch > 65535) kch *= 2;
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((K + kch - 1) / kch));
@@ -182,7 +182,10 @@ class HipOps : public Ops {
     int64_t npart = (int64_t)grid.x * grid.y;
     if (MODE != 0) part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
     TV *v = (TV *)V;
-    if (R <= 16)
+    if (R > 64)
+      hipLaunchKernelGGL((k_rank_stream_any<TV, MODE>), grid, dim3(256), 0, st_, v, M, K, Q, P, R,
+                         kch, part);
+    else if (R <= 16)
       hipLaunchKernelGGL((k_rank_stream<TV, 16, MODE>), grid, dim3(256), 0, st_, v, M, K, Q, P, R,
                          kch, part);
     else if (R <= 32)
@@ -539,7 +542,14 @@ class HipOps : public Ops {
   }
   void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
                    double *Sinv) override {
-    if (R > 64) throw std::runtime_error("ppals: gram_system supports R <= 64 in this version");
+    if (R > 64) {  // S, S^-1 out of global memory (kernels_small.hip.h, "rank above 64")
+      double *work = (double *)ensure(ws_big_, ws_big_sz_, sizeof(double) * (size_t)R * R + 64);
+      int *status = (int *)(work + (size_t)R * R);
+      hipLaunchKernelGGL(k_gram_system_big, dim3(1), dim3(1024), 0, st_, Gall, N, mode, R, lambda, S,
+                         Sinv, work, status);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     size_t lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
     hipLaunchKernelGGL(k_gram_system, dim3(1), dim3(64), lds, st_, Gall, N, mode, R, lambda, S,
                        Sinv, force_jacobi_);
@@ -549,7 +559,11 @@ class HipOps : public Ops {
                       int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
                       double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,
                       double ratio, double *S, double *Sinv) override {
-    if (R > 64) throw std::runtime_error("ppals: mode update supports R <= 64 in this version");
+    if (R > 64) {  // unfused route: S / S^-1, row-parallel update, Gram refresh
+      Ops::cp_mode_update(Gall, N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit,
+                          ldi, dW, ldd, ratio, S, Sinv);
+      return;
+    }
     if (force_jacobi_) {  // A/B path: the three separate kernels with the Jacobi inverse
       Ops::cp_mode_update(Gall, N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit,
                           ldi, dW, ldd, ratio, S, Sinv);
@@ -572,6 +586,20 @@ class HipOps : public Ops {
                  int64_t ldn, double *grad, int64_t ldg, int64_t rows, int R, const double *S,
                  const double *Sinv, double *gradsq, const double *Winit, int64_t ldi, double *dW,
                  int64_t ldd, double ratio) override {
+    if (R > 64) {
+      // several blocks update the rows: W_old is read from a scratch copy so that Wnew may alias it
+      const int nb = (int)((rows + 63) / 64);
+      double *wcopy = (double *)ensure(ws_big2_, ws_big2_sz_,
+                                       sizeof(double) * ((size_t)rows * R + (size_t)nb));
+      double *part = wcopy + (size_t)rows * R;
+      HIP_CHECK(hipMemcpy2DAsync(wcopy, sizeof(double) * rows, Wold, sizeof(double) * ldw,
+                                 sizeof(double) * rows, R, hipMemcpyDeviceToDevice, st_));
+      hipLaunchKernelGGL(k_cp_update_big, dim3(nb), dim3(256), 0, st_, M, ldm, wcopy, rows, Wnew, ldn,
+                         grad, ldg, rows, R, S, Sinv, part, Winit, ldi, dW, ldd, ratio);
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, nb, gradsq);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R);
     hipLaunchKernelGGL(k_cp_update, dim3(1), dim3(1024), lds, st_, M, ldm, Wold, ldw, Wnew, ldn,
                        grad, ldg, rows, R, S, Sinv, gradsq, Winit, ldi, dW, ldd, ratio);
@@ -776,8 +804,9 @@ class HipOps : public Ops {
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
-       *ws_small_ = nullptr;
-  size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0;
+       *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;
+  size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0,
+         ws_big_sz_ = 0, ws_big2_sz_ = 0;
   int profiling_ = 0;
   std::vector<Ev> events_;
   size_t nev_ = 0;

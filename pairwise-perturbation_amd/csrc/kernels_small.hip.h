@@ -162,6 +162,39 @@ __global__ __launch_bounds__(256) void k_rank_stream(TV *__restrict__ V, int64_t
   }
 }
 
+// any rank (R > 64): the row's R coefficients do not fit in registers; they are re-read from Q for
+// every column (L1/L2-resident: 256 rows x R doubles per block). Untimed paths only (tensor
+// generation, [diffV]).
+template <typename TV, int MODE>
+__global__ __launch_bounds__(256) void k_rank_stream_any(TV *__restrict__ V, int64_t M, int64_t K,
+                                                         const double *__restrict__ Q,
+                                                         const double *__restrict__ P, int R,
+                                                         int kch, double *__restrict__ partial) {
+  __shared__ double lds[17];
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.y * kch;
+  const int64_t k1 = min(K, k0 + (int64_t)kch);
+  const bool ok = m < M;
+  double acc = 0;
+  for (int64_t k = k0; k < k1; k++) {
+    double v = 0;
+    if (ok)
+      for (int r = 0; r < R; r++) v += Q[m + M * r] * P[k + K * r];
+    if (ok) {
+      if (MODE == 0)
+        V[m + M * k] = (TV)v;
+      else {
+        double d = (double)V[m + M * k] - v;
+        acc += d * d;
+      }
+    }
+  }
+  if (MODE != 0) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  }
+}
+
 // dst[c + cols*r] = src[r + rows*c]: 64x64 tiles through LDS (both sides coalesced)
 template <typename TV>
 __global__ __launch_bounds__(256) void k_transpose(const TV *__restrict__ src, int64_t rows,
@@ -611,6 +644,105 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
     wave_sync();
     jacobi_inverse_wave(A, Q, cs, pq, R, Sinv);
   }
+}
+
+// ------------------------------------------------------------------ rank above 64
+// The fused / one-wave kernels keep S, S^-1 and two work matrices in LDS (R <= 64). For larger R
+// the same arithmetic runs out of global memory (R x R doubles stay L2-resident):
+//  k_gram_system_big: ONE 1024-thread block, S = Hadamard of the Grams, S^-1 by the same
+//    pivot-free Gauss-Jordan sweeps (ping-pong between two global buffers, one barrier per pivot).
+//    *status = 1 when a pivot is not positive (S not SPD: the caller reports it).
+__global__ __launch_bounds__(1024) void k_gram_system_big(const double *__restrict__ Gall, int N,
+                                                          int mode, int R, double lambda,
+                                                          double *__restrict__ S,
+                                                          double *__restrict__ Sinv,
+                                                          double *__restrict__ work,
+                                                          int *__restrict__ status) {
+  const int tid = threadIdx.x;
+  double *src = work, *dst = Sinv;  // R even or odd: the final swap lands the result in `res`
+  for (int e = tid; e < R * R; e += blockDim.x) {
+    const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
+    S[e] = v;
+    src[e] = v;
+  }
+  __syncthreads();
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int k = 0; k < R; k++) {
+    const double p = src[k + (int64_t)R * k];
+    if (!(p > 0.0)) {
+      if (tid == 0) bad = 1;
+    }
+    __syncthreads();
+    if (bad) break;
+    const double d = 1.0 / p;
+    for (int e = tid; e < R * R; e += blockDim.x) {
+      const int i = e % R, j = e / R;
+      double v;
+      if (i == k)
+        v = (j == k) ? d : src[k + (int64_t)R * j] * d;
+      else if (j == k)
+        v = -src[i + (int64_t)R * k] * d;
+      else
+        v = src[e] - src[i + (int64_t)R * k] * (src[k + (int64_t)R * j] * d);
+      dst[e] = v;
+    }
+    __syncthreads();
+    double *t = src;
+    src = dst;
+    dst = t;
+  }
+  if (tid == 0) *status = bad;
+  // symmetrise into Sinv (src holds the result; it may already be Sinv)
+  for (int e = tid; e < R * R; e += blockDim.x) {
+    const int a = e % R, b = e / R;
+    if (a <= b) {
+      const double v = 0.5 * (src[a + (int64_t)R * b] + src[b + (int64_t)R * a]);
+      dst[a + (int64_t)R * b] = v;
+      dst[b + (int64_t)R * a] = v;
+    }
+  }
+  __syncthreads();
+  if (dst != Sinv)
+    for (int e = tid; e < R * R; e += blockDim.x) Sinv[e] = dst[e];
+  if (bad) {  // not SPD: make the failure visible instead of returning a half-swept matrix
+    __syncthreads();
+    for (int e = tid; e < R * R; e += blockDim.x) Sinv[e] = __longlong_as_double(0x7ff8000000000000LL);
+  }
+}
+// row-parallel mode update for any R: grad = -M + W_old S, W = M S^-1 (optional SVD_solve_mod
+// tail), per-block partial ||grad||^2. One block per 64 rows; a thread owns (row, column j).
+// Wnew must not alias Wold here (several blocks): the caller passes a scratch copy of W_old.
+__global__ __launch_bounds__(256) void k_cp_update_big(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ Wold, int64_t ldw,
+    double *__restrict__ Wnew, int64_t ldn, double *__restrict__ grad, int64_t ldg, int64_t rows,
+    int R, const double *__restrict__ S, const double *__restrict__ Sinv,
+    double *__restrict__ gradsq_part, const double *__restrict__ Winit, int64_t ldi,
+    double *__restrict__ dW, int64_t ldd, double ratio) {
+  __shared__ double lds[17];
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  double gs = 0;
+  if (i < rows)
+    for (int j = threadIdx.x >> 6; j < R; j += 4) {
+      double a = 0, b = 0;
+      for (int k = 0; k < R; k++) {
+        a += Wold[i + ldw * k] * S[k + (int64_t)R * j];
+        b += M[i + ldm * k] * Sinv[k + (int64_t)R * j];
+      }
+      const double gv = -M[i + ldm * j] + a;
+      grad[i + ldg * j] = gv;
+      gs += gv * gv;
+      if (Winit) {
+        const double wi = Winit[i + ldi * j];
+        const double d = ratio * (b - wi);
+        dW[i + ldd * j] = d;
+        if (ratio != 1.0) b = wi + d;
+      }
+      Wnew[i + ldn * j] = b;
+    }
+  gs = block_sum(gs, lds);
+  if (threadIdx.x == 0) gradsq_part[blockIdx.x] = gs;
 }
 
 // ------------------------------------------------------------------ mode update (K5 + K6b)

@@ -187,7 +187,7 @@ int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s) {
 }
 int ppals_tensor_fill_collinear(ppals_tensor *t, int R, double col_min, double col_max,
                                 double ratio_noise, uint64_t seed) {
-  if (!t || R <= 0 || R > 64) return fail(PPALS_ERR_ARG, "bad argument (rank must be in 1..64)");
+  if (!t || R <= 0) return fail(PPALS_ERR_ARG, "bad argument (rank must be positive)");
   API_BEGIN
   tensor_fill_collinear(*t->ctx->ops, t->ctx->c(), t->d, R, col_min, col_max, ratio_noise, seed);
   return PPALS_OK;
@@ -235,7 +235,6 @@ void ppals_fill_uniform_host(double *out, int64_t n, uint64_t seed, uint64_t off
 int ppals_cp_create(ppals_ctx *ctx, ppals_tensor *V, int R, ppals_cp **out) {
   if (!ctx || !V || !out) return fail(PPALS_ERR_ARG, "NULL argument");
   if (R <= 0) return fail(PPALS_ERR_ARG, "rank must be positive");
-  if (R > 64) return fail(PPALS_ERR_UNSUPPORTED, "this build supports CP rank <= 64");
   API_BEGIN
   std::unique_ptr<ppals_cp> s(new ppals_cp);
   s->ctx = ctx;

@@ -222,10 +222,6 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
   } else if (tensor[0] == 'r' && strlen(tensor) > 1 && tensor[1] == '2') {
     CHECK(ppals_tensor_fill_uniform(V, 7000 + a.seed, r2_lo, r2_hi));
   } else if (tensor[0] == 'r') {
-    if (a.R > 64) {
-      fprintf(stderr, "this build supports -rank <= 64\n");
-      return 2;
-    }
     std::vector<double> Wtrue;  // test_ALS.cxx:279-284
     init_factors_flat(lens, a.R, 1000 + 16 * a.seed, Wtrue);
     CHECK(ppals_tensor_fill_cp(V, a.R, Wtrue.data()));
@@ -236,10 +232,6 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
     }
     CHECK(ppals_tensor_fill_laplacian(V, ndigits, a.s));  // test_ALS.cxx:222-245
   } else if (tensor[0] == 'c') {
-    if (a.R > 64) {
-      fprintf(stderr, "this build supports -rank <= 64\n");
-      return 2;
-    }
     CHECK(ppals_tensor_fill_collinear(V, a.R, a.col_min, a.col_max, a.ratio_noise,
                                       5000 + a.seed));  // test_ALS.cxx:246-264
   } else {
