@@ -1030,7 +1030,8 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
       op.modes.push_back(m);
     }
     op.elems = L * T;
-    op.dt = pp_fast_ ? V_.dtype : F64;
+    // (at order 3 a level-1 result already IS a pair operator: those stay fp64 like all the others)
+    op.dt = (pp_fast_ && N_ > 3) ? V_.dtype : F64;
     op.buf = ops_.alloc(dtype_size(op.dt) * (size_t)op.elems * R_);
     ops_.scan_contract(use_vt ? VT_ : V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, op.dt,
                        L, op.elems);

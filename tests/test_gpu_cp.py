@@ -220,8 +220,11 @@ def test_driver_dt_csv_matches_oracle(pp, ctx, dtype, tmp_path):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_driver_pp_matches_oracle(pp, ctx, dtype, tmp_path):
-    lens, R = [12, 11, 10, 9], 3
+@pytest.mark.parametrize("lens,R", [([12, 11, 10, 9], 3), ([14, 12, 10], 3), ([7, 6, 6, 5, 5], 2),
+                                    ([5, 4, 5, 4, 4, 3], 2)])
+def test_driver_pp_matches_oracle(pp, ctx, dtype, lens, R, tmp_path):
+    """alsCP_PP for orders 3 (a level-1 operator is itself a pair operator), 4, 5 and 6 (several
+    levels of scaffolding between the tensor and the pair operators)"""
     V, W = problem(lens, R, 5, "r")
     G = O.init_factors(lens, R, 97)
     Vn = np.linalg.norm(V)
