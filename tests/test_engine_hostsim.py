@@ -33,6 +33,7 @@ test_schedule_switch_mid_run = G.test_schedule_switch_mid_run
 test_msdt_root_counts = G.test_msdt_root_counts
 test_edge_shapes = G.test_edge_shapes
 test_random_shapes_against_oracle = G.test_random_shapes_against_oracle
+test_random_larger_shapes_against_oracle = G.test_random_larger_shapes_against_oracle
 test_class_api_als_matches_oracle = G.test_class_api_als_matches_oracle
 test_class_api_reference_test_case = G.test_class_api_reference_test_case
 

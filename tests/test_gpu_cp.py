@@ -532,3 +532,35 @@ def test_msdt_root_counts(pp, ctx, lens, R, roots, dtype, monkeypatch):
     assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
     s.close()
     t.close()
+
+
+def _fuzz_cases_big(n, seed):
+    """orders 3-5 with extents large enough for several workgroup tiles, split-K and batched
+    scans, unaligned and aligned row counts, ranks on both sides of one n-tile"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        N = int(rng.integers(3, 6))
+        lens = [int(rng.integers(3, 70)) for _ in range(N)]
+        if np.prod(lens) > 3e6 or np.prod(lens) < 2e4:
+            continue
+        R = min(int(rng.choice([2, 5, 10, 16, 17, 24, 33])), min(lens))
+        cases.append((lens, R, int(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("lens,R,dtype", _fuzz_cases_big(24, 20260202))
+def test_random_larger_shapes_against_oracle(pp, ctx, lens, R, dtype):
+    V = O.build_V(O.init_factors(lens, R, 31))
+    W, G = O.init_factors(lens, R, 32), O.init_factors(lens, R, 33)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    for m in range(len(lens)):
+        assert relerr(s.mttkrp(m), O.mttkrp(V, W, m, 0)) < KTOL[dtype], (lens, R, m)
+    s.sweeps_dt(2)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=1, resprint=1000)
+    r_got, r_ref = O.residual(V, s.get_factors()), O.residual(V, W_ref)
+    assert abs(r_got - r_ref) < (1e-6 if dtype == 1 else 1e-3) * max(r_ref, 1e-3 * np.linalg.norm(V))
+    s.close()
+    t.close()
