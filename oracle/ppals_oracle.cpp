@@ -1644,6 +1644,14 @@ int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wfla
   return sweeps == maxsweep + 1 ? 0 : 1;
 }
 
+// the mode order alsCP_PP_partupdate uses (sort_indexes, als_CP.cxx:835-843): descending values
+void ppo_sort_indexes(int n, const double *v, int *idx) {
+  vector<int> ord(n);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return v[a] > v[b]; });
+  for (int i = 0; i < n; i++) idx[i] = ord[i];
+}
+
 int ppo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

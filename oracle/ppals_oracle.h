@@ -91,6 +91,9 @@ int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double
                       double *core, double tol, double tol_init, double timelimit, int maxiter,
                       const char *csv_path, int resprint, int verbose, int *iters); /* als_Tucker.cxx:906 */
 
+/* sort_indexes (als_CP.cxx:835-843): the update order of alsCP_PP_partupdate */
+void ppo_sort_indexes(int n, const double *v, int *idx);
+
 int ppo_num_threads(void);
 void ppo_set_num_threads(int n);
 

@@ -254,6 +254,14 @@ def cpd_als(V, Ws, gradWs, kind, tol, maxsweep, lam=0.0, csv=None, resprint=10, 
             unflat(gf, lens, [R] * len(lens)))
 
 
+def sort_indexes(v):
+    """the oracle's restatement of sort_indexes (als_CP.cxx:835-843)"""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    idx = (C.c_int * len(v))()
+    lib().ppo_sort_indexes(len(v), _dp(v), idx)
+    return list(idx)
+
+
 def ttmc(V, Ws, skip):
     lens = V.shape
     ranks = [W.shape[1] for W in Ws]

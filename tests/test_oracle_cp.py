@@ -171,3 +171,14 @@ def test_pp_driver_converges_like_dt(tmp_path):
     _, rows = O.read_csv(csv)
     assert any(r[4] == 1 for r in rows), "PP phase never entered"
     assert O.residual(V, Wn) < 1e-5 * Vnorm
+
+
+def test_sort_indexes_matches_reference(golden_dir):
+    """the update order of alsCP_PP_partupdate: the oracle's rule against the reference's own
+    STL-only sort_indexes (oracle/_ref/sortidx_ref -> tests/golden/sort_indexes.json)"""
+    import json
+    import os
+    cases = json.load(open(os.path.join(golden_dir, "sort_indexes.json")))["cases"]
+    assert len(cases) >= 40
+    for c in cases:
+        assert O.sort_indexes(c["v"]) == c["order"], c
