@@ -1,8 +1,9 @@
 /* ppals_oracle.h — C ABI of the CPU checker (TEST INFRASTRUCTURE, see oracle/README.md).
  *
  * Parity status: UNPINNED for the floating-point path (the reference needs the external CTF
- * library and ships no golden vectors); the dimension tree is pinned against the reference's own
- * STL-only function (oracle/_ref/dimtree_ref, tests/golden/dimension_tree.json).
+ * library and ships no golden vectors); the dimension tree and the `-pp 2` update order are pinned
+ * against the reference's own STL-only functions (oracle/_ref/dimtree_ref, oracle/_ref/sortidx_ref ->
+ * tests/golden/dimension_tree.json, tests/golden/sort_indexes.json).
  *
  * Conventions (identical to the reference's CTF objects):
  *   - dense tensors are fp64, FIRST INDEX FASTEST: V[i0 + lens[0]*(i1 + lens[1]*(i2 + ...))]
