@@ -1304,7 +1304,8 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
 
 // alsCP_PP_partupdate_sub (als_CP.cxx:852-1073): PP phase that updates only the modes with the
 // largest relative MTTKRP perturbation ||dM_i|| / ||M_i|| and propagates every update to the other
-// modes' dM through the cached pair operators. Single GPU (the norms of partial dM are not global).
+// modes' dM through the cached pair operators. Sharded: dM_i (i != 0) is a partial sum, completed
+// on a copy for its norm; M_i is completed in place by its own mode update.
 double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
                                    std::ofstream *csv) {
   const int init_iter = iter;
@@ -1356,9 +1357,19 @@ double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
       }
     }
     for (int i = 0; i < N_; i++) {
-      ops_.sumsq(dM_[i], ext(i) * R_, scal_ + 2 * i);
+      if (dist_ && i != 0) {
+        // dM_i is a partial sum over this rank's rows of the sharded mode: complete a copy of it.
+        // (Mm_i was completed in place by the all-reduce inside its own mode update.)
+        ops_.d2d(sendbuf_, dM_[i], sizeof(double) * ext(i) * R_);
+        comm_.allreduce_sum(sendbuf_, ext(i) * R_);
+        ops_.sumsq(sendbuf_, ext(i) * R_, scal_ + 2 * i);
+      } else {
+        ops_.sumsq(dM_[i], ext(i) * R_, scal_ + 2 * i);
+      }
       ops_.sumsq(Mm_[i], ext(i) * R_, scal_ + 2 * i + 1);
     }
+    // the sharded mode holds complete ROWS: its two sums of squares add up over the ranks
+    if (dist_) comm_.allreduce_sum(scal_, 2);
     double h[2 * MAX_ORDER];
     ops_.d2h(h, scal_, sizeof(double) * 2 * N_);
     for (int i = 0; i < N_; i++) relpert[i] = std::sqrt(h[2 * i]) / std::sqrt(h[2 * i + 1]);
@@ -1371,8 +1382,15 @@ double CpEngine::pp_partupdate_sub(const CpOpts &o, double &projnorm, int &iter,
 
 int CpEngine::run_pp(const CpOpts &o, int *iters) { return run_pp_common(o, iters, false); }
 int CpEngine::run_pp_partupdate(const CpOpts &o, int *iters) {
-  if (P_ > 1)
-    throw std::runtime_error("ppals: -pp 2 (partial update) runs on a single GPU in this version");
+  if (dist_) {
+    // sharded: needs the plan in which every rank sees the complete s x R matrices
+    for (int i = 0; i < N_; i++)
+      if ((int64_t)sizeof(double) * V_.glens[i] * R_ > small_msg_bytes_)
+        throw std::runtime_error(
+            "ppals: -pp 2 on several GPUs needs s x R matrices below PPALS_COMM_SMALL_BYTES");
+    if (o.ratio_step != 1.0)
+      throw std::runtime_error("ppals: -magni != 1 with -pp 2 runs on a single GPU");
+  }
   return run_pp_common(o, iters, true);
 }
 

@@ -115,6 +115,21 @@ def main():
                 _, r2 = O.read_csv(csv)
                 assert [r[:2] + [r[4]] for r in r1] == [r[:2] + [r[4]] for r in r2]
                 assert any(r[4] == 1 for r in r2)
+        # partial-update PP (-pp 2), sharded (the plan with complete s x R matrices on every rank)
+        if case_no % 2 == 0 and dtype == 1:
+            kw2 = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=25, resprint=1)
+            _, it_ref, W_pu_ref, _ = O.als_cp_pp_partupdate(V, W, G, update_percentage=0.5,
+                                                            csv=csv + ".ref2", **kw2)
+            s.set_factors(W, G)
+            _, it_got = s.run_pp_partupdate(csv=csv + "2" if rank == 0 else None,
+                                            update_percentage=0.5, **kw2)
+            assert it_got == it_ref, (it_got, it_ref)
+            for a, b in zip(s.get_factors(), W_pu_ref):
+                assert relerr(a, b) < 1e-6, relerr(a, b)
+            if rank == 0:
+                _, r1 = O.read_csv(csv + ".ref2")
+                _, r2 = O.read_csv(csv + "2")
+                assert [r[:2] + [r[4]] for r in r1] == [r[:2] + [r[4]] for r in r2]
         s.close()
         t.close()
     # ---- Tucker (HOOI), sharded: hosvd + the DT driver against the unsharded oracle

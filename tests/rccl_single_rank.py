@@ -58,6 +58,16 @@ def run(ppals, ctx):
                 assert it == it_ref, (it, it_ref)
                 for i in range(len(lens)):
                     assert relerr(W_dev[i], W_pp[i]) < 1e-6, (lens, plan, i, relerr(W_dev[i], W_pp[i]))
+            if dtype == ppals.F64 and plan != "0":  # -pp 2 needs the complete-matrix plan
+                s.set_factors(W, G)
+                _, it2 = s.run_pp_partupdate(tol=1e-7 * np.linalg.norm(V), maxiter=20, tol_init=0.1,
+                                             update_percentage=0.5)
+                _, it2_ref, W_pu, _ = O.als_cp_pp_partupdate(V, W, G, tol=1e-7 * np.linalg.norm(V),
+                                                             tol_init=0.1, maxiter=20,
+                                                             update_percentage=0.5)
+                assert it2 == it2_ref, (it2, it2_ref)
+                for a, b in zip(s.get_factors(), W_pu):
+                    assert relerr(a, b) < 1e-6
             s.close()
             t.close()
     # Tucker through the all-reduced leaves / Grams and the gathered HOSVD
