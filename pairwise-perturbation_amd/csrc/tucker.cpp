@@ -564,14 +564,33 @@ void TuckerEngine::sweep_pp() {
       int64_t L = 1, T = 1;
       for (int q = 0; q < ii; q++) L *= Tp.dims[q];
       for (int q = ii + 1; q < N_; q++) T *= Tp.dims[q];
-      ops_.ttm_keep(Tp.buf, F64, L, V_.glens[ii], T, dW_[ii], V_.glens[ii], r_[ii], Ytmp_);
+      // sharded mode: the local rows of dW_0 (the operator keeps the local extent of mode 0)
+      const double *dwp = dW_[ii] + (ii == 0 ? V_.row0 : 0);
+      ops_.ttm_keep(Tp.buf, F64, L, ext(ii), T, dwp, V_.glens[ii], r_[ii], Ytmp_);
       ops_.add_inplace(Yacc_, Ytmp_, Y0.elems);
     }
     int64_t L = 1, T = 1;
     for (int q = 0; q < i; q++) L *= r_[q];
     for (int q = i + 1; q < N_; q++) T *= r_[q];
-    if (i == N_ - 1) ops_.d2d(Yend_, Yacc_, sizeof(double) * yend_elems_);
-    ops_.unfold_gram(Yacc_, F64, L, V_.glens[i], T, G_);
+    double *Y = Yacc_;
+    if (dist_) {
+      // same completion as the exact sweep: partial sums are all-reduced, the rows of the sharded
+      // mode gathered (from a copy padded to the uniform block height)
+      if (i == 0) {
+        const int64_t blk = block_rows(V_.glens[0], P_);
+        if (ytmp_cap_ < blk * T) {
+          ops_.free(Ytmp_);
+          Ytmp_ = (double *)ops_.alloc(sizeof(double) * blk * T);
+          ytmp_cap_ = blk * T;
+        }
+        ops_.pack_blocks(Yacc_, ext(0), ext(0), (int)T, blk, 1, Ytmp_);
+        Y = complete_leaf(0, Ytmp_, blk * T);
+      } else {
+        Y = complete_leaf(i, Yacc_, Y0.elems);
+      }
+    }
+    if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
+    ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);
     ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
     ops_.sign_align(W_[i], Winit_[i], V_.glens[i], r_[i]);  // als_Tucker.cxx:874-885
     double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
@@ -681,8 +700,6 @@ void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, in
 }
 
 int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
-  if (P_ > 1)
-    throw std::runtime_error("ppals: Tucker -pp 1 runs on a single GPU in this version");
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
   if (rank_ == 0 && !o.csv_path.empty()) {

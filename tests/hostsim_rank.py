@@ -169,6 +169,23 @@ def main():
                 assert a[1] == b[1] and abs(a[5] - b[5]) < (1e-6 if dtype == 1 else 1e-3) * np.linalg.norm(V)
         for skip in (-1, 1):
             assert np.linalg.norm(tk.ttmc(skip) - O.ttmc(V, W2, skip)) < tol * 10 * np.linalg.norm(V)
+        # alsTucker_PP, sharded, against the unsharded oracle (fp64 storage: same phase pattern)
+        if dtype == 1:
+            kwp = dict(tol=0.0, tol_init=0.1, maxiter=10, resprint=1)
+            _, itp_ref, Wp_ref, corep_ref = O.als_tucker_pp(V, W_ref, core_ref, csv=csv + ".ppref",
+                                                            **kwp)
+            tk.hosvd()
+            tk.set_factors(W_ref)
+            _, itp = tk.run_pp(csv=csv + ".pp" if rank == 0 else None, **kwp)
+            Wp, corep = tk.get_factors()
+            assert itp == itp_ref, (itp, itp_ref)
+            for a, b in zip(Wp, Wp_ref):
+                assert np.linalg.norm(proj(a) - proj(b)) < 1e-5
+            if rank == 0:
+                _, r1 = O.read_csv(csv + ".ppref")
+                _, r2 = O.read_csv(csv + ".pp")
+                assert [r[1:2] + r[4:5] for r in r1] == [r[1:2] + r[4:5] for r in r2]
+                assert any(r[4] == 1 for r in r2)
         tk.close()
         t.close()
     assert calls["rs"] > 0 and calls["ag"] > 0 and calls["ar"] > 0

@@ -87,6 +87,15 @@ def run(ppals, ctx):
     assert abs(np.linalg.norm(cd) - np.linalg.norm(cr)) < 1e-8 * np.linalg.norm(cr)
     for a, b in zip(Wd, Wr):
         assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-6
+    # alsTucker_PP through the same completions
+    tk.hosvd()
+    tk.set_factors(W0)
+    _, itp = tk.run_pp(tol=0.0, tol_init=0.1, maxiter=8, resprint=1000)
+    _, itp_ref, Wp, _ = O.als_tucker_pp(V, W0, core0, tol=0.0, tol_init=0.1, maxiter=8,
+                                        resprint=1000)
+    assert itp == itp_ref
+    for a, b in zip(tk.get_factors()[0], Wp):
+        assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-5
 
 
 def main():
