@@ -524,16 +524,16 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
       ldb = blk;
     }
     double *mine = gatherbuf_ + (size_t)rank_ * blk * R_;
+    // SVD_solve_mod tail (common.cxx:753-756): the row block is written as W_init + ratio *
+    // (M S^-1 - W_init) already, so after the gather dW = W - W_init holds for every row
     ops_.cp_update(Mblk, ldb, W_[i] + r0, s, mine, blk, gradW_[i] + r0, s, nr, R_, S_, Sinv_,
-                   gradsq_ + i, nullptr, 0, nullptr, 0, 1.0);
+                   gradsq_ + i, pp ? Winit_[i] + r0 : nullptr, s, pp ? dW_[i] + r0 : nullptr, s,
+                   ratio);
     comm_.allgather(mine, gatherbuf_, blk * R_);
     ops_.unpack_blocks(gatherbuf_, s, s, R_, blk, P_, W_[i]);
     if (pp) {
-      // SVD_solve_mod tail (common.cxx:753-756) on the gathered factor
       double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
       int64_t n[1] = {s * R_};
-      if (ratio != 1.0)
-        throw std::runtime_error("ppals: -magni != 1 is not supported on more than one GPU yet");
       ops_.diff_norms(A, B, n, 1, 1, D, 0, scal_ + 2 * MAX_ORDER);
     }
   }
@@ -1388,8 +1388,6 @@ int CpEngine::run_pp_partupdate(const CpOpts &o, int *iters) {
       if ((int64_t)sizeof(double) * V_.glens[i] * R_ > small_msg_bytes_)
         throw std::runtime_error(
             "ppals: -pp 2 on several GPUs needs s x R matrices below PPALS_COMM_SMALL_BYTES");
-    if (o.ratio_step != 1.0)
-      throw std::runtime_error("ppals: -magni != 1 with -pp 2 runs on a single GPU");
   }
   return run_pp_common(o, iters, true);
 }

@@ -115,6 +115,15 @@ def main():
                 _, r2 = O.read_csv(csv)
                 assert [r[:2] + [r[4]] for r in r1] == [r[:2] + [r[4]] for r in r2]
                 assert any(r[4] == 1 for r in r2)
+        # -magni != 1 (ratio_step of SVD_solve_mod), sharded, on whichever plan this case runs
+        if dtype == 1:
+            kwm = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=20, resprint=1000)
+            _, itm_ref, W_m_ref, _ = O.als_cp_pp(V, W, G, ratio_step=0.8, **kwm)
+            s.set_factors(W, G)
+            _, itm = s.run_pp(ratio_step=0.8, **kwm)
+            assert itm == itm_ref, (itm, itm_ref)
+            for a, b in zip(s.get_factors(), W_m_ref):
+                assert relerr(a, b) < 1e-6, relerr(a, b)
         # partial-update PP (-pp 2), sharded (the plan with complete s x R matrices on every rank)
         if case_no % 2 == 0 and dtype == 1:
             kw2 = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=25, resprint=1)

@@ -29,6 +29,7 @@ test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
 test_driver_pp_partupdate_matches_oracle = G.test_driver_pp_partupdate_matches_oracle
+test_driver_pp_with_magni = G.test_driver_pp_with_magni
 test_schedule_switch_mid_run = G.test_schedule_switch_mid_run
 test_msdt_root_counts = G.test_msdt_root_counts
 test_edge_shapes = G.test_edge_shapes

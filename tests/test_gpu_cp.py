@@ -564,3 +564,29 @@ def test_random_larger_shapes_against_oracle(pp, ctx, lens, R, dtype):
     assert abs(r_got - r_ref) < (1e-6 if dtype == 1 else 1e-3) * max(r_ref, 1e-3 * np.linalg.norm(V))
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("ratio", [0.8, 1.2])
+def test_driver_pp_with_magni(pp, ctx, ratio, tmp_path):
+    """-magni (ratio_step of SVD_solve_mod, common.cxx:753-756): W = W_init + ratio * (M S^-1 - W_init)
+    in the PP phase"""
+    lens, R = [12, 11, 10, 9], 3
+    V, W = problem(lens, R, 5, "r")
+    G = O.init_factors(lens, R, 97)
+    Vn = np.linalg.norm(V)
+    kw = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=30, resprint=1)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    _, it_ref, W_ref, _ = O.als_cp_pp(V, W, G, ratio_step=ratio, csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    _, it = s.run_pp(ratio_step=ratio, csv=c_got, **kw)
+    assert it == it_ref
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert [r[:2] + [r[4]] for r in r1] == [r[:2] + [r[4]] for r in r2]
+    assert any(r[4] == 1 for r in r2)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < 1e-6
+    s.close()
+    t.close()
