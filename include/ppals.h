@@ -93,6 +93,10 @@ int ppals_collinear_factors(int order, const int64_t *lens, int R, double col_mi
 /* host data: the FULL tensor in fp64, first index fastest (the layout read_dense_from_file
  * implies, test_ALS.cxx:289-325); each rank keeps its own leading-mode rows */
 int ppals_tensor_upload(ppals_tensor *t, const double *host_full);
+/* A tensor may be re-filled / re-uploaded while CP or Tucker sessions created on it are alive:
+ * every fill or upload bumps the tensor's generation, and a session rebuilds what it derived from
+ * the old contents (its second resident layout; cached tree nodes and PP operators are dropped)
+ * the next time it reads the tensor. Not while one of the session's calls is running. */
 int ppals_tensor_norm(ppals_tensor *t, double *out); /* V.norm2(), test_ALS.cxx:328 */
 /* same counter-based generator for host-side factor initialisation (W.fill_random(0,1)) */
 void ppals_fill_uniform_host(double *out, int64_t n, uint64_t seed, uint64_t offset, double lo,

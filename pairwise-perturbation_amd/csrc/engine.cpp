@@ -273,6 +273,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   // The second resident layout is part of the session's set-up, like the tensor itself: built
   // here rather than at the first sweep, whose [dtime] would otherwise carry a one-off multi-GB
   // hipMalloc (≈ 1 s per 44 GB, several seconds on a fresh box) plus the transpose.
+  if (V_.generation) tensor_gen_ = *V_.generation;
   ensure_transposed();
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
@@ -344,6 +345,22 @@ void CpEngine::ensure_transposed() {
   vt_state_ = 1;
 }
 
+// The tensor handle stays writable while sessions exist (ppals_tensor_fill_*/upload). Everything
+// a session derived from the old contents — the second resident layout, tree nodes, the
+// multi-sweep intermediate, PP operators — is rebuilt / dropped when the generation moved.
+// Called wherever a session is about to read the tensor.
+void CpEngine::check_tensor_generation() {
+  if (!V_.generation || *V_.generation == tensor_gen_) return;
+  tensor_gen_ = *V_.generation;
+  if (vt_state_ == 1) {
+    const int mid = (N_ - 1) / 2;
+    ops_.transpose2d(V_.data, V_.dtype, prod_ext(0, mid), prod_ext(mid + 1, N_ - 1), VT_);
+  }
+  for (auto &n : nodes_) n.valid = false;
+  ms_invalidate();
+  pp_clear();
+}
+
 FactorRef CpEngine::fref(int m, double *const *W) const {
   FactorRef f;
   f.ptr = W[m] + (m == 0 ? V_.row0 : 0);
@@ -388,6 +405,7 @@ int CpEngine::find_node(int lo, int hi) const {
 // Khatri-Rao product of ALL sibling modes (K1: sibling is a suffix, K2: a prefix); deeper nodes
 // contract the cached parent tensor, which already carries the rank index.
 void CpEngine::compute_node(int idx) {
+  check_tensor_generation();
   Node &n = nodes_[idx];
   if (n.valid) return;
   n.elems = prod_ext(n.lo, n.hi);
@@ -730,6 +748,7 @@ void CpEngine::ms_start_step(int first) {
 // one mode update of the multi-sweep schedule: starts a new step when mode i belongs to the root
 // set of the running one (its factor was frozen into X), i.e. after N - k updates
 void CpEngine::ms_mode_update(int i, double lambda) {
+  check_tensor_generation();
   if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) ms_start_step((i - ms_k_ + N_) % N_);
   int pos = -1;
   for (size_t q = 0; q < ms_order_.size(); q++)
@@ -878,7 +897,7 @@ int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iter
           if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
         }
       }
-      if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+      if (agree(projnorm < o.tol || now() - st_time_ > o.timelimit)) break;
     }
     int count;
     double frac;
@@ -917,6 +936,14 @@ double CpEngine::allreduce_scalar(double x) {
   double y = 0;
   ops_.d2h(&y, scal_, sizeof(double));
   return y;
+}
+
+// A stop decision that involves this rank's own wall clock (the time limit) must be the same on
+// every rank, or one rank leaves the loop while the others enter the next sweep's collective:
+// any rank over the limit stops all of them (one scalar all-reduce, print blocks only).
+bool CpEngine::agree(bool local) {
+  if (!dist_) return local;
+  return allreduce_scalar(local ? 1.0 : 0.0) > 0.0;
 }
 
 double CpEngine::gradnorm() {
@@ -997,6 +1024,7 @@ void CpEngine::gram_system(int mode, double lambda, double *S_host, double *Sinv
 // Build_mttkrp_map (als_CP.cxx:352-409): key = contracted modes in ascending order; built by
 // dropping the last contracted mode. Level 1 scans V (K8), deeper levels contract the cache.
 const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
+  check_tensor_generation();
   auto it = pp_.find(seq);
   if (it != pp_.end()) return it->second;
   const int mode = seq.back() - 'a';
@@ -1159,7 +1187,7 @@ bool CpEngine::print_block(const CpOpts &o, int iter, int pp_flag, double &projn
     }
     csv_row(csv, V_.glens[0], iter, projnorm, o.tol, pp_flag, diffV, dtime);
   }
-  return (projnorm < o.tol) || (now() - st_time_ > o.timelimit);
+  return agree((projnorm < o.tol) || (now() - st_time_ > o.timelimit));
 }
 
 int CpEngine::run_dt(const CpOpts &o, int *iters) {
@@ -1189,7 +1217,7 @@ int CpEngine::run_dt(const CpOpts &o, int *iters) {
           if (o.verbose) std::cout << "  [dimension tree step time]  " << dtime << "\n";
           if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
         }
-        if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+        if (agree(projnorm < o.tol || now() - st_time_ > o.timelimit)) break;
       }
     }
     sweep_dt(o.lambda);
@@ -1292,7 +1320,7 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
             }
           }
         }
-        if (projnorm < o.tol || now() - st_time_ > o.timelimit) break;
+        if (agree(projnorm < o.tol || now() - st_time_ > o.timelimit)) break;
       }
     }
     sweep_pp(o.lambda, o.ratio_step);
@@ -1425,7 +1453,7 @@ int CpEngine::run_pp_common(const CpOpts &o, int *iters, bool partupdate) {
       pp_sub(o, gradnorm_v, iter, pcsv);
     // deviation from the reference: a timelimit hit terminates instead of looping forever
     // (als_CP.cxx:1105 with breaks at :496 and :750)
-    if (now() - st_time_ > o.timelimit) break;
+    if (agree(now() - st_time_ > o.timelimit)) break;
   }
   ops_.sync();
   pp_clear();

@@ -20,6 +20,10 @@ struct TensorDesc {
   int dtype = F32;
   void *data = nullptr;
   int64_t nloc = 0;
+  // bumped by every fill / upload of the tensor (owned by the ppals_tensor handle; nullptr: the
+  // contents never change). Sessions compare it with the generation their derived data (second
+  // resident layout, cached contractions) was built from and rebuild when it moved.
+  const uint64_t *generation = nullptr;
 };
 
 // leading-mode block partition shared by the tensor shard and the factor-matrix row blocks
@@ -161,6 +165,7 @@ class CpEngine {
   void pp_build_all();
   void sweep_pp(double lambda, double ratio);
   double allreduce_scalar(double x);
+  bool agree(bool local);
   void read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw);
   bool print_block(const CpOpts &o, int iter, int pp_flag, double &projnorm, double &diffV,
                    std::ofstream *csv);
@@ -184,7 +189,9 @@ class CpEngine {
   double *Qbuf_ = nullptr, *Pbuf_ = nullptr;  // residual KRP operands
   void *VT_ = nullptr;        // second resident layout of V: right-half modes fastest
   int vt_state_ = 0;          // 0 not tried, 1 built, -1 unavailable (disabled / no memory)
+  uint64_t tensor_gen_ = 0;   // generation of the tensor contents VT_ and the caches were built from
   void ensure_transposed();
+  void check_tensor_generation();
   // s x R partials up to this size use one all-reduce + redundant update instead of
   // reduce-scatter + row-block update + all-gather (PPALS_COMM_SMALL_BYTES overrides)
   int64_t small_msg_bytes_ = 1 << 20;

@@ -586,6 +586,10 @@ class HipOps : public Ops {
                  int64_t ldn, double *grad, int64_t ldg, int64_t rows, int R, const double *S,
                  const double *Sinv, double *gradsq, const double *Winit, int64_t ldi, double *dW,
                  int64_t ldd, double ratio) override {
+    if (rows <= 0) {  // a rank that owns no rows of this mode (row-block plan): nothing to launch
+      HIP_CHECK(hipMemsetAsync(gradsq, 0, sizeof(double), st_));
+      return;
+    }
     if (R > 64) {
       // several blocks update the rows: W_old is read from a scratch copy so that Wnew may alias it
       const int nb = (int)((rows + 63) / 64);

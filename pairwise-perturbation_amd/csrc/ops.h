@@ -142,7 +142,7 @@ class Ops {
   // decomposition without truncation (the reference's SVD_solve, common.cxx:717-722)
   virtual void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
                            double *Sinv) = 0;
-  // for `rows` rows: grad = -M + Wold*S ; Wnew = M*Sinv ; *gradsq += sum grad^2
+  // for `rows` rows: grad = -M + Wold*S ; Wnew = M*Sinv ; *gradsq = sum grad^2 (overwritten; 0 when rows == 0)
   // if Winit != nullptr (SVD_solve_mod, common.cxx:739-758): dW = ratio*(Wnew-Winit) and, when
   // ratio != 1, Wnew = Winit + dW.
   virtual void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw,

@@ -25,6 +25,7 @@ struct ppals_ctx {
 struct ppals_tensor {
   ppals_ctx *ctx;
   TensorDesc d;
+  uint64_t generation = 1;  // bumped by every fill / upload; sessions rebuild what they derived
 };
 struct ppals_cp {
   ppals_ctx *ctx;
@@ -142,6 +143,7 @@ int ppals_tensor_create(ppals_ctx *ctx, int order, const int64_t *global_lens, i
     g_err = "ppals_tensor_create: " + err;
     return PPALS_ERR_ARG;
   }
+  t->d.generation = &t->generation;
   *out = t.release();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -163,6 +165,7 @@ int ppals_tensor_local_rows(const ppals_tensor *t, int64_t *lo, int64_t *n) {
 int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat) {
   if (!t || !Wtrue_flat || R <= 0) return fail(PPALS_ERR_ARG, "bad argument");
   API_BEGIN
+  t->generation++;
   tensor_fill_cp(*t->ctx->ops, t->d, R, Wtrue_flat);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -170,6 +173,7 @@ int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat) {
 int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double hi) {
   if (!t) return fail(PPALS_ERR_ARG, "NULL tensor");
   API_BEGIN
+  t->generation++;
   tensor_fill_uniform(*t->ctx->ops, t->d, seed, lo, hi);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -181,6 +185,7 @@ int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s) {
   for (int i = 0; i < t->d.order; i++) total *= (double)t->d.glens[i];
   for (int i = 0; i < ndigits; i++) want *= s;
   if (total != want) return fail(PPALS_ERR_ARG, "tensor extents do not hold size^dim elements");
+  t->generation++;
   tensor_fill_laplacian(*t->ctx->ops, t->d, ndigits, s);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -189,6 +194,7 @@ int ppals_tensor_fill_collinear(ppals_tensor *t, int R, double col_min, double c
                                 double ratio_noise, uint64_t seed) {
   if (!t || R <= 0) return fail(PPALS_ERR_ARG, "bad argument (rank must be positive)");
   API_BEGIN
+  t->generation++;
   tensor_fill_collinear(*t->ctx->ops, t->ctx->c(), t->d, R, col_min, col_max, ratio_noise, seed);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -204,6 +210,7 @@ int ppals_collinear_factors(int order, const int64_t *lens, int R, double col_mi
 int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
   if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
+  t->generation++;
   tensor_upload(*t->ctx->ops, t->d, host_full);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)

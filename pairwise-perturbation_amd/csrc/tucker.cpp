@@ -65,6 +65,22 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
     VT_ = ops_.try_alloc((size_t)rows * cols * dtype_size(V_.dtype));
     if (VT_) ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
   }
+  if (V_.generation) tensor_gen_ = *V_.generation;
+}
+
+// see CpEngine::check_tensor_generation: the tensor handle stays writable while sessions exist
+void TuckerEngine::check_tensor_generation() {
+  if (!V_.generation || *V_.generation == tensor_gen_) return;
+  tensor_gen_ = *V_.generation;
+  if (VT_) {
+    const int mid = (N_ - 1) / 2;
+    int64_t rows = 1, cols = 1;
+    for (int m = 0; m <= mid; m++) rows *= ext(m);
+    for (int m = mid + 1; m < N_; m++) cols *= ext(m);
+    ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
+  }
+  for (auto &n : nodes_) n.valid = false;
+  pp_clear();
 }
 
 TuckerEngine::~TuckerEngine() {
@@ -167,6 +183,7 @@ void TuckerEngine::compute_left_half_on_vt(Node &n) {
 }
 
 void TuckerEngine::compute_node(int idx) {
+  check_tensor_generation();
   Node &n = nodes_[idx];
   if (n.valid) return;
   // (the sharded leaf of mode 0 keeps its own blocked layout: not this route)
@@ -397,6 +414,16 @@ void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
                 core_);
 }
 
+// rank-agreed stop decision (see CpEngine::agree): the time limit reads a rank-local clock
+bool TuckerEngine::agree(bool local) {
+  if (!dist_) return local;
+  double x = local ? 1.0 : 0.0, y = 0;
+  ops_.h2d(scal_ + 3, &x, sizeof(double));
+  comm_.allreduce_sum(scal_ + 3, 1);
+  ops_.d2h(&y, scal_ + 3, sizeof(double));
+  return y > 0.0;
+}
+
 double TuckerEngine::core_norm() {
   ops_.sumsq(core_, ncore_, scal_);
   ops_.sumsq(core_prev_, ncore_, scal_ + 1);
@@ -482,7 +509,7 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
         if (talk) std::cout << "  [dimension tree step time]  " << dtime << "\n";
         if (pcsv) (*pcsv) << "[DTtime]" << "," << dtime << "\n";
       }
-      if (diffnorm < o.tol || now() - st_time > o.timelimit) break;
+      if (agree(diffnorm < o.tol || now() - st_time > o.timelimit)) break;
       ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
     }
     sweep_dt();
@@ -510,6 +537,7 @@ static std::string tk_all_but(int N, int i, int j = -1) {
 // last one; every contraction keeps the tensor order. Level 1 scans V (K11), deeper levels
 // contract the cached fp64 intermediate.
 const TuckerEngine::PPOp &TuckerEngine::pp_get(const std::string &args) {
+  check_tensor_generation();
   auto it = pp_.find(args);
   if (it != pp_.end()) return it->second;
   const int mode = args.back() - 'a';
@@ -625,7 +653,8 @@ bool TuckerEngine::print_block(const CpOpts &o, int iter, int pp_flag, double &d
       if (iter % 100 == 0 && iter != 0) (*csv) << std::endl;
     }
   }
-  if (diffnorm < o.tol || now() - st_time > o.timelimit || (stop_at_maxiter && iter == o.maxiter))
+  if (agree(diffnorm < o.tol || now() - st_time > o.timelimit ||
+            (stop_at_maxiter && iter == o.maxiter)))
     return true;
   ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
   return false;
@@ -727,7 +756,7 @@ int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
     if (rank_ == 0 && o.verbose) printf("pairwise perturbation starts from %d\n", iter);
     pp_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
     if (tol_init > 5e-3) tol_init *= 0.9;  // als_Tucker.cxx:947-948
-    if (now() - st_time > o.timelimit) break;
+    if (agree(now() - st_time > o.timelimit)) break;
   }
   ops_.sync();
   pp_clear();

@@ -40,6 +40,7 @@ class TuckerEngine {
   double *complete_leaf(int i, double *Yloc, int64_t elems_local);
   void compute_core_full();
   double core_norm();
+  bool agree(bool local);
   double residual();
   int64_t node_elems(const Node &n) const;
 
@@ -66,6 +67,8 @@ class TuckerEngine {
   std::vector<double *> Wprev_, Winit_, dW_;
   double *Ytmp_ = nullptr, *Yacc_ = nullptr;
   void *VT_ = nullptr;  // second resident layout [(right modes), (left modes)], nullptr: not held
+  uint64_t tensor_gen_ = 0;  // generation of the tensor contents VT_ and the caches were built from
+  void check_tensor_generation();
   void *chain_[2] = {nullptr, nullptr};  // ping-pong scratch of the mode-product chains
   size_t chain_cap_[2] = {0, 0};
   int64_t ytmp_cap_ = 0, yacc_cap_ = 0;

@@ -39,32 +39,92 @@ static int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// RCCL unique-id exchange through the file system (single node): rank 0 writes, the others poll
-static int exchange_uid(int rank, unsigned char *uid) {
+// RCCL unique-id exchange through the file system (single node), as a nonce handshake so that no
+// rank can ever pick up the file of an earlier launch (same parent process, recycled PIDs, a
+// crashed run's leftovers):
+//   rank k > 0 publishes  <path>.r<k>  = its own 16-byte nonce (pid, start time in ns) and keeps it
+//              in place (re-creating it if rank 0's start-up clean-up removed it);
+//   rank 0     removes what earlier launches left under <path>*, waits for the world-1 hello files,
+//              then writes <path> = uid (128 B) + every rank's nonce;
+//   rank k     accepts <path> only when slot k carries ITS nonce, then removes its hello file;
+//   rank 0     removes <path> once the communicator exists (uid_exchange_done: ncclCommInitRank
+//              is collective, so every rank has read the file by then).
+static std::string uid_path() {
+  if (getenv("PPALS_UID_FILE")) return getenv("PPALS_UID_FILE");
   std::string dir = getenv("PPALS_UID_DIR") ? getenv("PPALS_UID_DIR") : "/tmp";
   std::string tag = getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
-  std::string path = dir + "/ppals_uid_" + tag + "_" + std::to_string((long)getppid());
-  if (getenv("PPALS_UID_FILE")) path = getenv("PPALS_UID_FILE");
-  if (rank == 0) {
-    if (ppals_get_unique_id(uid) < 0) return -1;
-    std::string tmp = path + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return -1;
-    fwrite(uid, 1, PPALS_UNIQUE_ID_BYTES, f);
-    fclose(f);
-    rename(tmp.c_str(), path.c_str());
-    return 0;
+  std::string run = getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "none";
+  for (auto &c : run)
+    if (c == '/' || c == ' ') c = '_';
+  return dir + "/ppals_uid_" + tag + "_" + run + "_" + std::to_string((long)getppid());
+}
+static bool write_atomically(const std::string &path, const void *buf, size_t n) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(buf, 1, n, f) == n;
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+    unlink(tmp.c_str());
+    return false;
   }
-  for (int tries = 0; tries < 6000; tries++) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (f) {
-      size_t n = fread(uid, 1, PPALS_UNIQUE_ID_BYTES, f);
-      fclose(f);
-      if (n == PPALS_UNIQUE_ID_BYTES) return 0;
+  return true;
+}
+static bool read_exactly(const std::string &path, void *buf, size_t n) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const size_t got = fread(buf, 1, n, f);
+  const bool more = fgetc(f) != EOF;
+  fclose(f);
+  return got == n && !more;
+}
+static const int UID_NONCE_BYTES = 16;
+static int exchange_uid(int rank, int world, unsigned char *uid) {
+  const std::string path = uid_path();
+  auto hello = [&](int k) { return path + ".r" + std::to_string(k); };
+  const size_t total = PPALS_UNIQUE_ID_BYTES + (size_t)UID_NONCE_BYTES * world;
+  std::vector<unsigned char> file(total, 0);
+  const int max_tries = 100 * env_int("PPALS_UID_TIMEOUT_S", 120);
+  if (rank == 0) {
+    unlink(path.c_str());
+    for (int k = 1; k < world; k++) unlink(hello(k).c_str());
+    if (ppals_get_unique_id(uid) < 0) return -1;
+    memcpy(file.data(), uid, PPALS_UNIQUE_ID_BYTES);
+    for (int k = 1; k < world; k++) {
+      unsigned char *slot = file.data() + PPALS_UNIQUE_ID_BYTES + (size_t)UID_NONCE_BYTES * k;
+      int tries = 0;
+      while (!read_exactly(hello(k), slot, UID_NONCE_BYTES)) {
+        if (++tries > max_tries) return -1;
+        usleep(10000);
+      }
+    }
+    return write_atomically(path, file.data(), total) ? 0 : -1;
+  }
+  unsigned char nonce[UID_NONCE_BYTES];
+  const uint64_t pid = (uint64_t)getpid();
+  const uint64_t t_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                            std::chrono::system_clock::now().time_since_epoch()).count();
+  memcpy(nonce, &pid, 8);
+  memcpy(nonce + 8, &t_ns, 8);
+  unlink(hello(rank).c_str());
+  for (int tries = 0; tries < max_tries; tries++) {
+    unsigned char mine[UID_NONCE_BYTES];
+    if (!read_exactly(hello(rank), mine, UID_NONCE_BYTES) || memcmp(mine, nonce, UID_NONCE_BYTES))
+      write_atomically(hello(rank), nonce, UID_NONCE_BYTES);
+    if (read_exactly(path, file.data(), total) &&
+        !memcmp(file.data() + PPALS_UNIQUE_ID_BYTES + (size_t)UID_NONCE_BYTES * rank, nonce,
+                UID_NONCE_BYTES)) {
+      memcpy(uid, file.data(), PPALS_UNIQUE_ID_BYTES);
+      unlink(hello(rank).c_str());
+      return 0;
     }
     usleep(10000);
   }
+  unlink(hello(rank).c_str());
   return -1;
+}
+static void uid_exchange_done(int rank) {
+  if (rank == 0) unlink(uid_path().c_str());
 }
 
 
@@ -118,7 +178,12 @@ static Args parse_args(int argc, char **argv, int resprint_default) {
   a.ratio_noise = (o = getCmdOption(b, e, "-rationoise")) ? atof(o) : 0.01;
   if (a.ratio_noise < 0) a.ratio_noise = 0.01;
   // extra flags (the reference's parser ignores unknown flags)
-  a.prec = (o = getCmdOption(b, e, "-prec")) ? atoi(o) : 32;
+  // -prec: storage type of the tensor in HBM. Default 64 = the reference's precision, so that a
+  // default command line stops where the fp64 reference stops (-tol 1e-10 * ||V|| is far below
+  // what fp32 storage can resolve: its gradient norm floors near 1e-5 * ||V||). -prec 32 halves
+  // the bytes every sweep streams (the configuration bench.py measures).
+  a.prec = (o = getCmdOption(b, e, "-prec")) ? atoi(o) : 64;
+  if (a.prec != 32 && a.prec != 64) a.prec = 64;
   a.seed = (o = getCmdOption(b, e, "-seed")) ? strtoull(o, 0, 10) : 0;
   a.rank = env_int("RANK", 0);
   a.world = env_int("WORLD_SIZE", 1);
@@ -172,11 +237,12 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
   CHECK(ppals_ctx_create(&ctx, a.device));
   if (a.world > 1) {
     unsigned char uid[PPALS_UNIQUE_ID_BYTES];
-    if (exchange_uid(a.rank, uid) != 0) {
+    if (exchange_uid(a.rank, a.world, uid) != 0) {
       fprintf(stderr, "RCCL unique-id exchange failed\n");
       return 1;
     }
     CHECK(ppals_ctx_init_comm(ctx, a.rank, a.world, uid));
+    uid_exchange_done(a.rank);
   }
   lens.assign(a.dim, (int64_t)a.s);
   const int ndigits = a.dim;  // -tensor p / p2: number of base-`size` digits of an element index
@@ -191,6 +257,11 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
     lens.assign(a.dim, (int64_t)a.s * a.s);
   }
   const int dtype = a.prec == 64 ? PPALS_F64 : PPALS_F32;
+  if (dtype == PPALS_F32 && a.tol < 1e-6 && a.rank == 0)
+    fprintf(stderr,
+            "ppals: -prec 32 stores the tensor in fp32: [gradnorm] floors near 1e-5*||V||, so "
+            "-tol %g cannot be met; the run ends at -maxiter / -timelimit (use -prec 64 for the "
+            "reference's stop criterion)\n", a.tol);
   const char *tensor = a.tensor;
   bool from_file = false;
   if (tensor[0] == 'o') {  // raw fp64, first index fastest (test_ALS.cxx:287-326)

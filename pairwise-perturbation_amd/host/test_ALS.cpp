@@ -6,7 +6,8 @@
 // file under $PPALS_UID_DIR (default /tmp) and shard the tensor along its leading mode.
 //
 // Extra flags (unknown flags are ignored by the reference's parser, so command lines stay
-// compatible): -prec 32|64 (tensor storage in HBM, default 32), -seed N (default 0),
+// compatible): -prec 64|32 (tensor storage in HBM; default 64 = the reference's precision, 32 = the
+// fast mode bench.py measures), -seed N (default 0),
 // -device N (default LOCAL_RANK).
 // Not supported: -issparse 1 (the engine is dense).
 #include "driver_common.h"

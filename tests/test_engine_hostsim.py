@@ -37,6 +37,7 @@ test_random_shapes_against_oracle = G.test_random_shapes_against_oracle
 test_random_larger_shapes_against_oracle = G.test_random_larger_shapes_against_oracle
 test_class_api_als_matches_oracle = G.test_class_api_als_matches_oracle
 test_class_api_reference_test_case = G.test_class_api_reference_test_case
+test_tensor_refill_while_session_alive = G.test_tensor_refill_while_session_alive
 
 import test_gpu_tucker as GT  # noqa: E402
 

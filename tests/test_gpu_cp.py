@@ -590,3 +590,32 @@ def test_driver_pp_with_magni(pp, ctx, ratio, tmp_path):
         assert relerr(a, b) < 1e-6
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_tensor_refill_while_session_alive(pp, ctx, dtype):
+    """ppals_tensor_upload / fill_* on a tensor that live sessions were created on: the session
+    notices the new generation and rebuilds what it derived from the old contents (second resident
+    layout, cached contractions) — first-level nodes of BOTH halves, MTTKRPs and sweeps follow the
+    new data (include/ppals.h, contract of ppals_tensor_upload)"""
+    lens, R = [12, 10, 8, 6], 3
+    V1, W = problem(lens, R, 4, "r")
+    V2, _ = problem(lens, R, 9, "r2")
+    G = O.init_factors(lens, R, 99)
+    t = pp.Tensor(ctx, lens, dtype).upload(V1)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    s.sweeps_dt(2)            # caches of both schedules' first step are live now
+    t.upload(V2)
+    s.set_factors(W, G)
+    for key in ("ab", "cd"):
+        assert relerr(s.tree_node(key), O.tree_node(V2, W, key).ravel(order="F")) < KTOL[dtype], key
+    for m in range(4):
+        assert relerr(s.mttkrp(m), O.mttkrp(V2, W, m, 0)) < KTOL[dtype], m
+    t.upload(V1)              # and back, without touching the factors in between
+    s.sweeps_dt(3)
+    _, _, W_ref, _ = O.als_cp_dt(V1, W, G, tol=0.0, maxiter=2, resprint=1000)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < FTOL[dtype], relerr(a, b)
+    s.close()
+    t.close()
