@@ -97,6 +97,9 @@ int ppals_tensor_upload(ppals_tensor *t, const double *host_full);
  * every fill or upload bumps the tensor's generation, and a session rebuilds what it derived from
  * the old contents (its second resident layout; cached tree nodes and PP operators are dropped)
  * the next time it reads the tensor. Not while one of the session's calls is running. */
+/* the reverse (the commented-out V.write_dense_to_file, test_ALS.cxx:347): this rank's leading-mode
+ * rows, widened to fp64, into their places of the FULL host tensor; other ranks' rows untouched */
+int ppals_tensor_download(ppals_tensor *t, double *host_full);
 int ppals_tensor_norm(ppals_tensor *t, double *out); /* V.norm2(), test_ALS.cxx:328 */
 /* same counter-based generator for host-side factor initialisation (W.fill_random(0,1)) */
 void ppals_fill_uniform_host(double *out, int64_t n, uint64_t seed, uint64_t offset, double lo,
@@ -177,6 +180,10 @@ int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sw
 int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out);
 void ppals_tucker_destroy(ppals_tucker *s);
 int ppals_tucker_set_factors(ppals_tucker *s, const double *Wflat);
+/* the `core` argument of alsTucker_DT / alsTucker_PP (als_Tucker.h:46,89; it seeds core_prev):
+ * prod(ranks) doubles, first index fastest; NULL: core = V x_i W_i^T of the current factors.
+ * A new session's core is zero (pp_bench.cxx:327 hands over a fresh tensor). */
+int ppals_tucker_set_core(ppals_tucker *s, const double *core);
 int ppals_tucker_get_factors(ppals_tucker *s, double *Wflat, double *core);
 /* hosvd (als_Tucker.h:14-15, als_Tucker.cxx:66): overwrites the factors and the core */
 int ppals_tucker_hosvd(ppals_tucker *s);

@@ -453,10 +453,27 @@ double residual(const Ten &V, const Factors &F) {
 struct Log {
   std::ofstream csv;
   bool has_csv = false, verbose = false;
-  void open(const char *path) {
+  // append: pp_bench hands ONE open stream to every call (pp_bench.cxx:296-345)
+  void open(const char *path, bool append = false) {
     if (path && path[0]) {
-      csv.open(path);
+      csv.open(path, append ? std::ios::app : std::ios::out);
       has_csv = true;
+    }
+  }
+  // bench == true emitters: als_CP.cxx:204-208, als_Tucker.cxx:324-329
+  void dt_time(double dtime) {
+    if (verbose) std::cout << "  [dimension tree step time]  " << dtime << "\n";
+    if (has_csv) csv << "[DTtime]" << "," << dtime << "\n";
+  }
+  // als_CP.cxx:739-747, als_Tucker.cxx:805-813
+  void pp_times(double dtime_first, double dtime) {
+    if (verbose) {
+      std::cout << "  [PP first time]  " << dtime_first << "\n";
+      std::cout << "  [PP second time]  " << dtime << "\n";
+    }
+    if (has_csv) {
+      csv << "  [PPfirst]  " << "," << dtime_first << "\n";
+      csv << "  [PPsecond]  " << "," << dtime << "\n";
     }
   }
   void header(const char *h) {
@@ -549,6 +566,7 @@ struct CPRun {
   int maxiter, resprint;
   Log log;
   double st_time;
+  bool bench = false;
 };
 
 // print block: als_CP.cxx:166-213 (and :457-498, :697-752)
@@ -591,12 +609,14 @@ double cp_dt_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double &
   return diffnorm_V;
 }
 
-// alsCP_PP_sub (als_CP.cxx:621-833), bench == false
+// alsCP_PP_sub (als_CP.cxx:621-833); c.bench: the pp_bench control flow (:656-664 restart test
+// skipped, :735-748 [PPfirst]/[PPsecond] bookkeeping, :829-830 iter++ on exit)
 double cp_pp_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double ratio_step,
                  double &projnorm, int &iter) {
   int N = c.N, R = c.R;
   int init_iter = iter;
   double diffnorm_V = 1000;
+  double dtime_first = 0;
   vector<vector<double>> W_init(N);
   PPMap pp;
   pp.N = N;
@@ -606,10 +626,12 @@ double cp_pp_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double r
   vector<double> S((size_t)R * R), Sinv((size_t)R * R);
   for (; iter <= c.maxiter; iter++) {
     int num_dw_break = 0;
-    for (int i = 0; i < N; i++) {
-      i64 n = c.F.lens[i] * R;
-      double norm_dW = fro(dW[i].data(), n), norm_W = fro(c.F.W[i], n);
-      if (std::fabs(norm_dW / norm_W) > tol_init) num_dw_break++;
+    if (!c.bench) {
+      for (int i = 0; i < N; i++) {
+        i64 n = c.F.lens[i] * R;
+        double norm_dW = fro(dW[i].data(), n), norm_W = fro(c.F.W[i], n);
+        if (std::fabs(norm_dW / norm_W) > tol_init) num_dw_break++;
+      }
     }
     if ((iter - init_iter) % 15 == 0 || num_dw_break > 0) {
       if (num_dw_break > 0 || iter != init_iter) return diffnorm_V;
@@ -623,7 +645,23 @@ double cp_pp_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double r
       for (int ii = 0; ii < N; ii++) pp.get(all_but(N, ii));
     }
     if (iter % c.resprint == 0 || iter == c.maxiter || iter == init_iter) {
-      if (print_block(c, iter, 1, projnorm, diffnorm_V)) break;
+      if (!c.bench) {
+        if (print_block(c, iter, 1, projnorm, diffnorm_V)) break;
+      } else {
+        double st_time1 = now();
+        projnorm = gradnorm_of(c.G);
+        diffnorm_V = residual(*c.V, c.F);
+        c.st_time += now() - st_time1;
+        double dtime = now() - c.st_time;
+        if (iter != c.maxiter) {
+          dtime_first = dtime;
+          c.st_time = now();
+        } else {
+          dtime_first = dtime_first + dtime;
+          c.log.pp_times(dtime_first, dtime);
+        }
+        if ((projnorm < c.tol) || now() - c.st_time > c.timelimit) break;
+      }
     }
     for (int i = 0; i < N; i++) {
       i64 si = c.F.lens[i];
@@ -660,6 +698,7 @@ double cp_pp_sub(CPRun &c, vector<vector<double>> &dW, double tol_init, double r
     normalize(c.F);
     if (iter % 10 == 0 && c.log.verbose) printf(".");
   }
+  if (c.bench) iter++;
   return diffnorm_V;
 }
 
@@ -894,11 +933,13 @@ struct TuckerRun {
   int maxiter, resprint;
   Log log;
   double st_time;
+  bool bench = false;
 };
 
 // print block shared by DT_sub / PP_sub (als_Tucker.cxx:521-564, :763-822)
-bool tucker_print(TuckerRun &c, int iter, int pp_flag, double &diffnorm, double &diffnorm_V,
-                  bool also_stop_at_maxiter) {
+// the measurements of a print block (core, |  ||core|| - ||core_prev||  |, residual), untimed:
+// returns [dtime]
+double tucker_measure(TuckerRun &c, double &diffnorm, double &diffnorm_V) {
   double st_time1 = now();
   Ten cc = ttmc(*c.V, c.F, -1);
   std::memcpy(c.core, cc.d, sizeof(double) * c.ncore);
@@ -910,7 +951,11 @@ bool tucker_print(TuckerRun &c, int iter, int pp_flag, double &diffnorm, double 
   cview.d = c.core;
   diffnorm_V = tucker_residual(*c.V, cview, c.F);
   c.st_time += now() - st_time1;
-  double dtime = now() - c.st_time;
+  return now() - c.st_time;
+}
+bool tucker_print(TuckerRun &c, int iter, int pp_flag, double &diffnorm, double &diffnorm_V,
+                  bool also_stop_at_maxiter) {
+  double dtime = tucker_measure(c, diffnorm, diffnorm_V);
   c.log.row(c.F.lens[0], iter, "diffnorm", diffnorm, c.tol, pp_flag, diffnorm_V, dtime);
   if (diffnorm < c.tol || now() - c.st_time > c.timelimit ||
       (also_stop_at_maxiter && iter == c.maxiter))
@@ -964,12 +1009,14 @@ void tucker_dt_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, do
   }
 }
 
-// alsTucker_PP_sub (als_Tucker.cxx:679-896), bench == false
+// alsTucker_PP_sub (als_Tucker.cxx:679-896); c.bench: the pp_bench control flow (:722-730 restart
+// test skipped, :799-814 [PPfirst]/[PPsecond] bookkeeping, :892-893 iter++ on exit)
 void tucker_pp_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, double &diffnorm,
                    int &iter) {
   int N = c.N;
   int init_iter = iter;
   double diffnorm_V = 1000;
+  double dtime_first = 0;
   vector<vector<double>> W_init(N);
   TuckerPPMap pp;
   pp.N = N;
@@ -978,9 +1025,11 @@ void tucker_pp_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, do
   Ten Y_end;
   for (; iter <= c.maxiter; iter++) {
     int num_dw_break = 0;
-    for (int i = 0; i < N; i++) {
-      i64 n = c.F.lens[i] * c.ranks[i];
-      if (std::fabs(fro(dW[i].data(), n) / fro(c.F.W[i], n)) > tol_init) num_dw_break++;
+    if (!c.bench) {
+      for (int i = 0; i < N; i++) {
+        i64 n = c.F.lens[i] * c.ranks[i];
+        if (std::fabs(fro(dW[i].data(), n) / fro(c.F.W[i], n)) > tol_init) num_dw_break++;
+      }
     }
     if (iter == init_iter || num_dw_break > 0) {
       if (num_dw_break > 0) return;
@@ -995,7 +1044,20 @@ void tucker_pp_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, do
     }
     if ((iter % c.resprint == 0 && iter != 0) || iter == 1 || iter == c.maxiter ||
         iter == init_iter) {
-      if (tucker_print(c, iter, 1, diffnorm, diffnorm_V, true)) break;
+      if (!c.bench) {
+        if (tucker_print(c, iter, 1, diffnorm, diffnorm_V, true)) break;
+      } else {
+        double dtime = tucker_measure(c, diffnorm, diffnorm_V);
+        if (iter != c.maxiter) {
+          dtime_first = dtime;
+          c.st_time = now();
+        } else {
+          dtime_first = dtime_first + dtime;
+          c.log.pp_times(dtime_first, dtime);
+        }
+        if (diffnorm < c.tol || now() - c.st_time > c.timelimit || iter == c.maxiter) break;
+        std::copy(c.core, c.core + c.ncore, c.core_prev.begin());
+      }
     }
     for (int i = 0; i < N; i++) {
       Ten Y = pp.get(all_but(N, i));  // copy
@@ -1019,6 +1081,7 @@ void tucker_pp_sub(TuckerRun &c, vector<vector<double>> &dW, double tol_init, do
     Ten cc = ttm_keep(Y_end, N - 1, c.F.W[N - 1], c.F.lens[N - 1], c.ranks[N - 1]);
     std::memcpy(c.core, cc.d, sizeof(double) * c.ncore);
   }
+  if (c.bench) iter++;
 }
 
 }  // namespace
@@ -1271,10 +1334,12 @@ struct ClassStep {
   }
 };
 
-// alsCP_DT (als_CP.cxx:127-320), bench == false
-int ppo_als_cp_dt(int N, const int64_t *lens, int R, const double *V, double *Wflat,
-                  double *gradWflat, double tol, double timelimit, int maxiter, double lambda,
-                  const char *csv_path, int resprint, int verbose, int *iters) {
+// alsCP_DT (als_CP.cxx:127-320). bench != 0: pp_bench's form (:131-135 no heading, :203-209 a
+// [DTtime] line instead of the row, at every print point but iter 0; the stream is the caller's:
+// lines are appended, :311-313)
+int ppo_als_cp_dt_ex(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                     double *gradWflat, double tol, double timelimit, int maxiter, double lambda,
+                     const char *csv_path, int resprint, int verbose, int bench, int *iters) {
   CPRun c;
   Ten Vt = view_of(N, lens, V);
   c.V = &Vt;
@@ -1287,15 +1352,26 @@ int ppo_als_cp_dt(int N, const int64_t *lens, int R, const double *V, double *Wf
   c.lambda = lambda;
   c.maxiter = maxiter;
   c.resprint = resprint;
+  c.bench = bench != 0;
   c.log.verbose = verbose != 0;
-  c.log.open(csv_path);
-  c.log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
+  c.log.open(csv_path, c.bench);
+  if (!c.bench) c.log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
   c.st_time = now();
   double projnorm = 0, diffnorm_V = 1000;
   int iter;
   for (iter = 0; iter <= maxiter; iter++) {
     if (iter % resprint == 0 || iter == maxiter) {
-      if (print_block(c, iter, 0, projnorm, diffnorm_V)) break;
+      if (!c.bench) {
+        if (print_block(c, iter, 0, projnorm, diffnorm_V)) break;
+      } else {
+        double st_time1 = now();
+        projnorm = gradnorm_of(c.G);
+        diffnorm_V = residual(Vt, c.F);
+        c.st_time += now() - st_time1;
+        double dtime = now() - c.st_time;
+        if (iter != 0) c.log.dt_time(dtime);
+        if ((projnorm < tol) || now() - c.st_time > timelimit) break;
+      }
     }
     dt_sweep(Vt, c.F, c.G, lambda, true);
     normalize(c.F);
@@ -1309,12 +1385,19 @@ int ppo_als_cp_dt(int N, const int64_t *lens, int R, const double *V, double *Wf
   if (iters) *iters = iter;
   return iter == maxiter + 1 ? 0 : 1;
 }
+int ppo_als_cp_dt(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                  double *gradWflat, double tol, double timelimit, int maxiter, double lambda,
+                  const char *csv_path, int resprint, int verbose, int *iters) {
+  return ppo_als_cp_dt_ex(N, lens, R, V, Wflat, gradWflat, tol, timelimit, maxiter, lambda, csv_path,
+                          resprint, verbose, 0, iters);
+}
 
-// alsCP_PP (als_CP.cxx:1082-1137), bench == false
-int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wflat,
-                  double *gradWflat, double tol, double tol_init, double timelimit, int maxiter,
-                  double lambda, double ratio_step, const char *csv_path, int resprint, int verbose,
-                  int *iters) {
+// alsCP_PP (als_CP.cxx:1082-1137). bench != 0: no heading, no exact phase (:1107-1117), the PP
+// phase in its bench form (cp_pp_sub)
+int ppo_als_cp_pp_ex(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                     double *gradWflat, double tol, double tol_init, double timelimit, int maxiter,
+                     double lambda, double ratio_step, const char *csv_path, int resprint,
+                     int verbose, int bench, int *iters) {
   CPRun c;
   Ten Vt = view_of(N, lens, V);
   c.V = &Vt;
@@ -1327,17 +1410,20 @@ int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wf
   c.lambda = lambda;
   c.maxiter = maxiter;
   c.resprint = resprint;
+  c.bench = bench != 0;
   c.log.verbose = verbose != 0;
-  c.log.open(csv_path);
-  c.log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
+  c.log.open(csv_path, c.bench);
+  if (!c.bench) c.log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
   c.st_time = now();
   int iter = 0;
   double gradnorm = 10.;
   vector<vector<double>> dW(N);
   for (int j = 0; j < N; j++) dW[j].assign((size_t)lens[j] * R, 0.0);
   while (gradnorm > tol && iter <= maxiter) {
-    if (verbose) printf("DT starts from %d\n", iter);
-    cp_dt_sub(c, dW, tol_init, gradnorm, iter);
+    if (!c.bench) {
+      if (verbose) printf("DT starts from %d\n", iter);
+      cp_dt_sub(c, dW, tol_init, gradnorm, iter);
+    }
     if (verbose) printf("pairwise perturbation starts from %d\n", iter);
     cp_pp_sub(c, dW, tol_init, ratio_step, gradnorm, iter);
     if (now() - c.st_time > timelimit) break;  // deviation: the reference loops forever here
@@ -1349,6 +1435,13 @@ int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wf
   if (c.log.has_csv) c.log.csv.close();
   if (iters) *iters = iter;
   return iter == maxiter + 1 ? 0 : 1;
+}
+int ppo_als_cp_pp(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                  double *gradWflat, double tol, double tol_init, double timelimit, int maxiter,
+                  double lambda, double ratio_step, const char *csv_path, int resprint, int verbose,
+                  int *iters) {
+  return ppo_als_cp_pp_ex(N, lens, R, V, Wflat, gradWflat, tol, tol_init, timelimit, maxiter, lambda,
+                          ratio_step, csv_path, resprint, verbose, 0, iters);
 }
 
 // alsCP_PP_partupdate (als_CP.cxx:1146-1207), bench == false
@@ -1440,16 +1533,17 @@ int ppo_als_tucker(int N, const int64_t *lens, const int *ranks, const double *V
   return iter == maxiter + 1 ? 0 : 1;
 }
 
-// alsTucker_DT (als_Tucker.cxx:240-424), bench == false
-int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
-                      double *core, double tol, double timelimit, int maxiter, const char *csv_path,
-                      int resprint, int verbose, int *iters) {
+// alsTucker_DT (als_Tucker.cxx:240-424). bench != 0: no heading (:243-247), a [DTtime] line
+// instead of the row at every print point (:324-329), lines appended to the caller's stream
+int ppo_als_tucker_dt_ex(int N, const int64_t *lens, const int *ranks, const double *V,
+                         double *Wflat, double *core, double tol, double timelimit, int maxiter,
+                         const char *csv_path, int resprint, int verbose, int bench, int *iters) {
   Factors F = factors(N, lens, 0, Wflat, ranks);
   Ten Vt = view_of(N, lens, V);
   Log log;
   log.verbose = verbose != 0;
-  log.open(csv_path);
-  log.header("[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]");
+  log.open(csv_path, bench != 0);
+  if (!bench) log.header("[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]");
   i64 ncore = 1;
   for (int i = 0; i < N; i++) ncore *= ranks[i];
   vector<double> core_prev(core, core + ncore);
@@ -1475,7 +1569,10 @@ int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double
       diffnorm_V = tucker_residual(Vt, cview, F);
       st_time += now() - st_time1;
       double dtime = now() - st_time;
-      log.row(lens[0], iter, "diffnorm", diffnorm, tol, 0, diffnorm_V, dtime);
+      if (!bench)
+        log.row(lens[0], iter, "diffnorm", diffnorm, tol, 0, diffnorm_V, dtime);
+      else
+        log.dt_time(dtime);
       if (diffnorm < tol || now() - st_time > timelimit) break;
       std::copy(core, core + ncore, core_prev.begin());
     }
@@ -1505,10 +1602,19 @@ int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double
   return iter == maxiter + 1 ? 0 : 1;
 }
 
-// alsTucker_PP (als_Tucker.cxx:906-962), bench == false
-int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
-                      double *core, double tol, double tol_init, double timelimit, int maxiter,
-                      const char *csv_path, int resprint, int verbose, int *iters) {
+int ppo_als_tucker_dt(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
+                      double *core, double tol, double timelimit, int maxiter, const char *csv_path,
+                      int resprint, int verbose, int *iters) {
+  return ppo_als_tucker_dt_ex(N, lens, ranks, V, Wflat, core, tol, timelimit, maxiter, csv_path,
+                              resprint, verbose, 0, iters);
+}
+
+// alsTucker_PP (als_Tucker.cxx:906-962). bench != 0: no heading, no exact phase (:928-937), the
+// PP phase in its bench form (tucker_pp_sub)
+int ppo_als_tucker_pp_ex(int N, const int64_t *lens, const int *ranks, const double *V,
+                         double *Wflat, double *core, double tol, double tol_init, double timelimit,
+                         int maxiter, const char *csv_path, int resprint, int verbose, int bench,
+                         int *iters) {
   TuckerRun c;
   Ten Vt = view_of(N, lens, V);
   c.V = &Vt;
@@ -1524,15 +1630,16 @@ int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double
   c.maxiter = maxiter;
   c.resprint = resprint;
   c.log.verbose = verbose != 0;
-  c.log.open(csv_path);
-  c.log.header("[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]");
+  c.bench = bench != 0;
+  c.log.open(csv_path, c.bench);
+  if (!c.bench) c.log.header("[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]");
   c.st_time = now();
   int iter = 0;
   double diffnorm = 10.;
   vector<vector<double>> dW(N);
   for (int j = 0; j < N; j++) dW[j].assign((size_t)lens[j] * ranks[j], 0.0);
   while (diffnorm > tol && iter <= maxiter) {
-    tucker_dt_sub(c, dW, tol_init, diffnorm, iter);
+    if (!c.bench) tucker_dt_sub(c, dW, tol_init, diffnorm, iter);
     tucker_pp_sub(c, dW, tol_init, diffnorm, iter);
     if (tol_init > 5e-3) tol_init *= 0.9;
     if (now() - c.st_time > timelimit) break;
@@ -1540,6 +1647,13 @@ int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double
   if (c.log.has_csv) c.log.csv.close();
   if (iters) *iters = iter;
   return iter == maxiter + 1 ? 0 : 1;
+}
+
+int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double *V, double *Wflat,
+                      double *core, double tol, double tol_init, double timelimit, int maxiter,
+                      const char *csv_path, int resprint, int verbose, int *iters) {
+  return ppo_als_tucker_pp_ex(N, lens, ranks, V, Wflat, core, tol, tol_init, timelimit, maxiter,
+                              csv_path, resprint, verbose, 0, iters);
 }
 
 // CPD<dtype, Optimizer>::als (src/CP.cxx:100-186) driving one of the class-API optimizers:

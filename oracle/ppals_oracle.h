@@ -92,6 +92,25 @@ int ppo_als_tucker_pp(int N, const int64_t *lens, const int *ranks, const double
                       double *core, double tol, double tol_init, double timelimit, int maxiter,
                       const char *csv_path, int resprint, int verbose, int *iters); /* als_Tucker.cxx:906 */
 
+/* The same four drivers with the reference's `bool bench` argument (pp_bench.cxx:299-345 calls them
+ * with maxiter = 1, bench = true): no CSV heading, [DTtime] / [PPfirst] / [PPsecond] lines instead
+ * of rows (als_CP.cxx:203-209,735-748; als_Tucker.cxx:324-329,799-814) APPENDED to csv_path, the PP
+ * phase without its restart test and with iter++ on exit (als_CP.cxx:656-664,829-830). */
+int ppo_als_cp_dt_ex(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                     double *gradWflat, double tol, double timelimit, int maxiter, double lambda,
+                     const char *csv_path, int resprint, int verbose, int bench, int *iters);
+int ppo_als_cp_pp_ex(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                     double *gradWflat, double tol, double tol_init, double timelimit, int maxiter,
+                     double lambda, double ratio_step, const char *csv_path, int resprint,
+                     int verbose, int bench, int *iters);
+int ppo_als_tucker_dt_ex(int N, const int64_t *lens, const int *ranks, const double *V,
+                         double *Wflat, double *core, double tol, double timelimit, int maxiter,
+                         const char *csv_path, int resprint, int verbose, int bench, int *iters);
+int ppo_als_tucker_pp_ex(int N, const int64_t *lens, const int *ranks, const double *V,
+                         double *Wflat, double *core, double tol, double tol_init, double timelimit,
+                         int maxiter, const char *csv_path, int resprint, int verbose, int bench,
+                         int *iters);
+
 /* sort_indexes (als_CP.cxx:835-843): the update order of alsCP_PP_partupdate */
 void ppo_sort_indexes(int n, const double *v, int *idx);
 

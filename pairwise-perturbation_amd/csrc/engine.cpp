@@ -139,6 +139,9 @@ void tensor_fill_uniform(Ops &ops, const TensorDesc &V, uint64_t seed, double lo
 void tensor_upload(Ops &ops, const TensorDesc &V, const double *host_full) {
   ops.upload_shard(V.data, V.dtype, host_full, V.llens[0], V.glens[0], V.row0, rest_of(V));
 }
+void tensor_download(Ops &ops, const TensorDesc &V, double *host_full) {
+  ops.download_shard(V.data, V.dtype, host_full, V.llens[0], V.glens[0], V.row0, rest_of(V));
+}
 void tensor_fill_laplacian(Ops &ops, const TensorDesc &V, int ndigits, int s) {
   ops.fill_laplacian(V.data, V.dtype, V.llens[0], V.glens[0], V.row0, rest_of(V), ndigits, s);
   ops.sync();

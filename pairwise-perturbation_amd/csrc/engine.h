@@ -40,6 +40,7 @@ int tensor_create(Ops &ops, Comm &comm, int order, const int64_t *glens, int dty
 void tensor_fill_cp(Ops &ops, const TensorDesc &V, int R, const double *Wtrue_flat);
 void tensor_fill_uniform(Ops &ops, const TensorDesc &V, uint64_t seed, double lo, double hi);
 void tensor_upload(Ops &ops, const TensorDesc &V, const double *host_full);
+void tensor_download(Ops &ops, const TensorDesc &V, double *host_full);
 // `-tensor p/p2` (laplacian_tensor + fold_unfold, common.cxx:575-642,870-880): ndigits = -dim, s = -size
 void tensor_fill_laplacian(Ops &ops, const TensorDesc &V, int ndigits, int s);
 // `-tensor c` (Gen_collinearity + noise, common.cxx:361-423, test_ALS.cxx:246-264)

@@ -248,6 +248,28 @@ class HipOps : public Ops {
     free(stage);
   }
 
+  void download_shard(const void *V, int dt, double *host_full, int64_t l0, int64_t g0,
+                      int64_t row0, int64_t rest) override {
+    const int64_t chunk_cols = std::max<int64_t>(1, (int64_t)(64 << 20) / (8 * l0));
+    std::vector<double> host((size_t)(chunk_cols * l0));
+    double *stage = (double *)alloc(sizeof(double) * chunk_cols * l0);
+    for (int64_t c0 = 0; c0 < rest; c0 += chunk_cols) {
+      const int64_t nc = std::min(chunk_cols, rest - c0), n = nc * l0;
+      if (dt == F32)
+        hipLaunchKernelGGL(k_widen_rows<float>, dim3(grid_for(n, 256)), dim3(256), 0, st_, stage,
+                           (const float *)V + c0 * l0, n);
+      else
+        hipLaunchKernelGGL(k_widen_rows<double>, dim3(grid_for(n, 256)), dim3(256), 0, st_, stage,
+                           (const double *)V + c0 * l0, n);
+      HIP_CHECK(hipGetLastError());
+      d2h(host.data(), stage, sizeof(double) * n);
+      for (int64_t c = 0; c < nc; c++)
+        std::copy(host.begin() + c * l0, host.begin() + (c + 1) * l0,
+                  host_full + (c0 + c) * g0 + row0);
+    }
+    free(stage);
+  }
+
   void *try_alloc(size_t bytes) override {
     void *p = nullptr;
     hipSetDevice(dev_);

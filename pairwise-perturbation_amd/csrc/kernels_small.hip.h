@@ -237,6 +237,13 @@ __global__ void k_convert_rows(TV *__restrict__ dst, const double *__restrict__ 
     dst[e] = (TV)src[e];
 }
 
+template <typename TV>
+__global__ void k_widen_rows(double *__restrict__ dst, const TV *__restrict__ src, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] = (double)src[e];
+}
+
 // ------------------------------------------------------------------ plain Khatri-Rao product
 __global__ void k_krp(double *__restrict__ out, KrpArgs a, int64_t J, int col0, int ncols) {
   const int64_t total = J * ncols;

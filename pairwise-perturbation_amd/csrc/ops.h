@@ -71,6 +71,11 @@ class Ops {
   virtual void upload_shard(void *V, int dt, const double *host_full, int64_t l0, int64_t g0,
                             int64_t row0, int64_t rest) = 0;
 
+  // the reverse: the local shard's rows, widened to fp64, into their places of the FULL host tensor
+  // (rows of other ranks are left untouched). Synchronises.
+  virtual void download_shard(const void *V, int dt, double *host_full, int64_t l0, int64_t g0,
+                              int64_t row0, int64_t rest) = 0;
+
   // dst[c + cols*r] = src[r + rows*c] (same element type dt): builds the second resident layout
   // of the tensor (right-half modes fastest) so that BOTH first-level tree nodes are suffix scans
   virtual void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) = 0;

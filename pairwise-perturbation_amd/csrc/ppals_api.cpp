@@ -215,6 +215,13 @@ int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
+int ppals_tensor_download(ppals_tensor *t, double *host_full) {
+  if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  tensor_download(*t->ctx->ops, t->d, host_full);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
 int ppals_tensor_norm(ppals_tensor *t, double *out) {
   if (!t || !out) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
@@ -399,6 +406,13 @@ int ppals_tucker_set_factors(ppals_tucker *s, const double *Wflat) {
   if (!s || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->set_factors(Wflat);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_tucker_set_core(ppals_tucker *s, const double *core) {
+  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->set_core(core);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }

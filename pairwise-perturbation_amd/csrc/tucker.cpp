@@ -343,6 +343,14 @@ void TuckerEngine::set_factors(const double *Wflat) {
     w += n;
   }
 }
+// core == nullptr: core = V x_i W_i^T from the current factors (TTMc(core, V, W, -1)); the value
+// becomes the `core` argument (and the initial core_prev) of the next alsTucker_DT / _PP call
+void TuckerEngine::set_core(const double *core) {
+  if (core)
+    ops_.h2d(core_, core, sizeof(double) * ncore_);
+  else
+    compute_core_full();
+}
 void TuckerEngine::get_factors(double *Wflat, double *core) {
   double *w = Wflat;
   for (int i = 0; i < N_; i++) {
@@ -697,17 +705,20 @@ void TuckerEngine::dt_sub(const CpOpts &o, double tol_init, double &diffnorm, in
   }
 }
 
-// alsTucker_PP_sub (als_Tucker.cxx:679-896), bench == false
+// alsTucker_PP_sub (als_Tucker.cxx:679-896); o.bench: pp_bench's form (:722-730 no restart test,
+// :799-814 [PPfirst]/[PPsecond], :892-893 iter++ on exit)
 void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, int &iter,
                           std::ofstream *csv, double &st_time) {
   const int init_iter = iter;
-  double diffV = 1000;
+  double diffV = 1000, dtime_first = 0;
   std::vector<double> nd, nw;
   for (; iter <= o.maxiter; iter++) {
     int num_dw_break = 0;
-    read_norms(false, nd, nw);
-    for (int i = 0; i < N_; i++)
-      if (std::fabs(nd[i] / nw[i]) > tol_init) num_dw_break++;
+    if (!o.bench) {
+      read_norms(false, nd, nw);
+      for (int i = 0; i < N_; i++)
+        if (std::fabs(nd[i] / nw[i]) > tol_init) num_dw_break++;
+    }
     if (iter == init_iter || num_dw_break > 0) {
       if (num_dw_break > 0) return;
       for (int j = 0; j < N_; j++) {
@@ -722,10 +733,39 @@ void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, in
     }
     if ((iter % o.resprint == 0 && iter != 0) || iter == 1 || iter == o.maxiter ||
         iter == init_iter) {
-      if (print_block(o, iter, 1, diffnorm, diffV, csv, st_time, true)) break;
+      if (!o.bench) {
+        if (print_block(o, iter, 1, diffnorm, diffV, csv, st_time, true)) break;
+      } else {
+        ops_.sync();
+        const double st_time1 = now();
+        compute_core_full();
+        diffnorm = core_norm();
+        diffV = residual();
+        st_time += now() - st_time1;
+        const double dtime = now() - st_time;
+        if (iter != o.maxiter) {
+          dtime_first = dtime;
+          st_time = now();
+        } else {
+          dtime_first = dtime_first + dtime;
+          if (rank_ == 0) {
+            if (o.verbose) {
+              std::cout << "  [PP first time]  " << dtime_first << "\n";
+              std::cout << "  [PP second time]  " << dtime << "\n";
+            }
+            if (csv) {
+              (*csv) << "  [PPfirst]  " << "," << dtime_first << "\n";
+              (*csv) << "  [PPsecond]  " << "," << dtime << "\n";
+            }
+          }
+        }
+        if (agree(diffnorm < o.tol || now() - st_time > o.timelimit || iter == o.maxiter)) break;
+        ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
+      }
     }
     sweep_pp();
   }
+  if (o.bench) iter++;
 }
 
 int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
@@ -734,7 +774,7 @@ int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
   if (rank_ == 0 && !o.csv_path.empty()) {
     csv.open(o.csv_path, o.csv_append ? std::ios::app : std::ios::out);
     pcsv = &csv;
-    csv << "[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]\n";
+    if (!o.bench) csv << "[dim],[iter],[diffnorm],[tol],[pp_update],[diffV],[dtime]\n";
   }
   if (Wprev_.empty()) {
     for (int i = 0; i < N_; i++) {
@@ -751,8 +791,10 @@ int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
   double diffnorm = 10.;
   double tol_init = o.tol_init;
   while (diffnorm > o.tol && iter <= o.maxiter) {
-    if (rank_ == 0 && o.verbose) printf("DT starts from %d\n", iter);
-    dt_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
+    if (!o.bench) {
+      if (rank_ == 0 && o.verbose) printf("DT starts from %d\n", iter);
+      dt_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
+    }
     if (rank_ == 0 && o.verbose) printf("pairwise perturbation starts from %d\n", iter);
     pp_sub(o, tol_init, diffnorm, iter, pcsv, st_time);
     if (tol_init > 5e-3) tol_init *= 0.9;  // als_Tucker.cxx:947-948

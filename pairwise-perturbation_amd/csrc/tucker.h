@@ -15,6 +15,7 @@ class TuckerEngine {
   ~TuckerEngine();
   void set_factors(const double *Wflat);
   void get_factors(double *Wflat, double *core);
+  void set_core(const double *core);  // nullptr: recompute from V and the factors
   void hosvd();                          // als_Tucker.cxx:12-70
   int64_t ttmc(int skip, double *Yhost);  // als_Tucker.cxx:76-110
   void sweep_dt();                       // als_Tucker.cxx:340-408

@@ -134,7 +134,41 @@ struct Args {
   double update_percentage_pp, tol, pp_res_tol, lambda_, magni, col_min, col_max, ratio_noise,
       timelimit;
   uint64_t seed;
+  // file exchange with a run of the reference made elsewhere (raw little-endian fp64, first index
+  // fastest = the layout V.read_dense_from_file / write_dense_to_file use, test_ALS.cxx:302,347)
+  const char *dumpV, *dumpW0, *loadW0, *dumpW;
+  std::vector<int64_t> lens_override;  // -lens a,b,c,..: extents of the `-tensor o*` file
+  std::vector<int> ranks_override;     // -ranks r0,r1,..: Tucker core extents
 };
+
+static std::vector<int64_t> parse_int_list(const char *str) {
+  std::vector<int64_t> v;
+  if (!str) return v;
+  const char *p = str;
+  while (*p) {
+    char *end;
+    const long long x = strtoll(p, &end, 10);
+    if (end == p) break;
+    v.push_back(x);
+    p = (*end == ',') ? end + 1 : end;
+    if (*end != ',') break;
+  }
+  return v;
+}
+// raw fp64 files of the exchange flags
+static bool write_doubles(const char *path, const double *p, size_t n) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return false;
+  const bool ok = fwrite(p, sizeof(double), n, f) == n;
+  return fclose(f) == 0 && ok;
+}
+static bool read_doubles(const char *path, double *p, size_t n) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  const bool ok = fread(p, sizeof(double), n, f) == n && fgetc(f) == EOF;
+  fclose(f);
+  return ok;
+}
 
 // test_ALS.cxx:64-196 — same defaults, same silent resets. resprint_default: 10 in test_ALS
 // (test_ALS.cxx:133-139), 1 in pp_bench (pp_bench.cxx).
@@ -185,6 +219,12 @@ static Args parse_args(int argc, char **argv, int resprint_default) {
   a.prec = (o = getCmdOption(b, e, "-prec")) ? atoi(o) : 64;
   if (a.prec != 32 && a.prec != 64) a.prec = 64;
   a.seed = (o = getCmdOption(b, e, "-seed")) ? strtoull(o, 0, 10) : 0;
+  a.dumpV = getCmdOption(b, e, "-dumpV");
+  a.dumpW0 = getCmdOption(b, e, "-dumpW0");
+  a.loadW0 = getCmdOption(b, e, "-loadW0");
+  a.dumpW = getCmdOption(b, e, "-dumpW");
+  a.lens_override = parse_int_list(getCmdOption(b, e, "-lens"));
+  for (auto r : parse_int_list(getCmdOption(b, e, "-ranks"))) a.ranks_override.push_back((int)r);
   a.rank = env_int("RANK", 0);
   a.world = env_int("WORLD_SIZE", 1);
   a.device = (o = getCmdOption(b, e, "-device")) ? atoi(o) : env_int("LOCAL_RANK", 0);
@@ -265,13 +305,22 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
   const char *tensor = a.tensor;
   bool from_file = false;
   if (tensor[0] == 'o') {  // raw fp64, first index fastest (test_ALS.cxx:287-326)
+    // -lens a,b,c,d (extra flag): the same code path on a file of other extents, named by
+    // -tensorfile — a dump of this driver (-dumpV) or of a CTF run, a down-scaled dataset
+    const bool custom = !a.lens_override.empty();
     if (strlen(tensor) > 1 && tensor[1] == '1') {
-      a.tensorfile = "coil-100.bin";
+      if (!custom) a.tensorfile = "coil-100.bin";
       lens = {3, 128, 128, 7200};
     } else if (strlen(tensor) > 1 && tensor[1] == '2') {
-      a.tensorfile = "time-lapse.bin";
+      if (!custom) a.tensorfile = "time-lapse.bin";
       lens = {33, 1344, 1024, 9};
     }
+    if (custom) lens = a.lens_override;
+    for (auto l : lens)
+      if (l <= 0) {
+        fprintf(stderr, "-lens: extents must be positive\n");
+        return 2;
+      }
     a.dim = (int)lens.size();
     from_file = true;
   }
@@ -282,12 +331,10 @@ static int make_ctx_and_tensor(Args &a, double r2_lo, double r2_hi, ppals_ctx **
     size_t n = 1;
     for (auto l : lens) n *= (size_t)l;
     std::vector<double> host(n);
-    FILE *f = fopen(a.tensorfile, "rb");
-    if (!f || fread(host.data(), sizeof(double), n, f) != n) {
-      fprintf(stderr, "cannot read %zu doubles from %s\n", n, a.tensorfile);
+    if (!read_doubles(a.tensorfile, host.data(), n)) {
+      fprintf(stderr, "%s does not hold exactly %zu doubles\n", a.tensorfile, n);
       return 2;
     }
-    fclose(f);
     CHECK(ppals_tensor_upload(V, host.data()));
     if (a.rank == 0) cout << "Read dataset finished " << endl;
   } else if (tensor[0] == 'r' && strlen(tensor) > 1 && tensor[1] == '2') {

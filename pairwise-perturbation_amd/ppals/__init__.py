@@ -43,6 +43,7 @@ EXPORTS = [
     "ppals_ctx_sync", "ppals_profile_enable", "ppals_profile_read", "ppals_profile_reset",
     "ppals_tensor_create", "ppals_tensor_destroy", "ppals_tensor_local_rows",
     "ppals_tensor_fill_cp", "ppals_tensor_fill_uniform", "ppals_tensor_upload",
+    "ppals_tensor_download",
     "ppals_tensor_fill_laplacian", "ppals_tensor_fill_collinear", "ppals_collinear_factors",
     "ppals_tensor_norm", "ppals_fill_uniform_host", "ppals_tree_node", "ppals_mttkrp",
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
@@ -51,6 +52,7 @@ EXPORTS = [
     "ppals_cpd_als", "ppals_cp_set_schedule", "ppals_cp_get_schedule",
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
+    "ppals_tucker_set_core",
     "ppals_tucker_hosvd", "ppals_tucker_ttmc", "ppals_tucker_sweeps_dt", "ppals_tucker_dt",
     "ppals_tucker_pp",
 ]
@@ -222,6 +224,12 @@ class Tensor:
         _check(lib().ppals_tensor_upload(self._h, _dp(Vf)))
         return self
 
+    def download(self):
+        """the tensor as fp64, first index fastest (this rank's rows; zeros elsewhere)"""
+        out = np.zeros(self.lens, dtype=np.float64, order="F")
+        _check(lib().ppals_tensor_download(self._h, _dp(out)))
+        return out
+
     def norm(self):
         out = C.c_double(0)
         _check(lib().ppals_tensor_norm(self._h, C.byref(out)))
@@ -369,6 +377,14 @@ class Tucker:
     def set_factors(self, Ws):
         wf = flat(Ws)
         _check(lib().ppals_tucker_set_factors(self._h, _dp(wf)))
+
+    def set_core(self, core=None):
+        """the `core` argument of alsTucker_DT/_PP; None: recompute it from V and the factors"""
+        if core is None:
+            _check(lib().ppals_tucker_set_core(self._h, None))
+        else:
+            cf = np.asfortranarray(core, dtype=np.float64).ravel(order="F").copy()
+            _check(lib().ppals_tucker_set_core(self._h, _dp(cf)))
 
     def get_factors(self):
         wf = np.empty(sum(s * r for s, r in zip(self.lens, self.ranks)))

@@ -162,6 +162,12 @@ class HostOps : public Ops {
       for (int64_t a = 0; a < l0; a++) st(V, dt, a + l0 * c, host_full[row0 + a + g0 * c]);
   }
 
+  void download_shard(const void *V, int dt, double *host_full, int64_t l0, int64_t g0,
+                      int64_t row0, int64_t rest) override {
+    for (int64_t c = 0; c < rest; c++)
+      for (int64_t a = 0; a < l0; a++) host_full[row0 + a + g0 * c] = ld(V, dt, a + l0 * c);
+  }
+
   void unpack_shards(const void *stage, int dt, int64_t s0, int64_t rest, int64_t blk, int P,
                      int64_t chunk_bytes, void *full) override {
     for (int64_t c = 0; c < rest; c++)

@@ -194,29 +194,31 @@ def als_cp(V, Ws, gradWs, tol, maxiter, timelimit=5e3):
 
 
 def als_cp_dt(V, Ws, gradWs, tol, maxiter, lam=0.0, csv=None, resprint=10, timelimit=5e3,
-              verbose=0):
+              verbose=0, bench=0):
     lens = V.shape
     R = Ws[0].shape[1]
     wf, gf = flat(Ws), flat(gradWs)
     Vf = np.asfortranarray(V)
     iters = C.c_int(0)
-    rc = lib().ppo_als_cp_dt(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf),
-                             C.c_double(tol), C.c_double(timelimit), maxiter, C.c_double(lam),
-                             (csv.encode() if csv else None), resprint, verbose, C.byref(iters))
+    rc = lib().ppo_als_cp_dt_ex(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf),
+                                C.c_double(tol), C.c_double(timelimit), maxiter, C.c_double(lam),
+                                (csv.encode() if csv else None), resprint, verbose, bench,
+                                C.byref(iters))
     return rc, iters.value, unflat(wf, lens, [R] * len(lens)), unflat(gf, lens, [R] * len(lens))
 
 
 def als_cp_pp(V, Ws, gradWs, tol, tol_init, maxiter, lam=0.0, ratio_step=1.0, csv=None,
-              resprint=10, timelimit=5e3, verbose=0):
+              resprint=10, timelimit=5e3, verbose=0, bench=0):
     lens = V.shape
     R = Ws[0].shape[1]
     wf, gf = flat(Ws), flat(gradWs)
     Vf = np.asfortranarray(V)
     iters = C.c_int(0)
-    rc = lib().ppo_als_cp_pp(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf),
-                             C.c_double(tol), C.c_double(tol_init), C.c_double(timelimit), maxiter,
-                             C.c_double(lam), C.c_double(ratio_step),
-                             (csv.encode() if csv else None), resprint, verbose, C.byref(iters))
+    rc = lib().ppo_als_cp_pp_ex(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf),
+                                C.c_double(tol), C.c_double(tol_init), C.c_double(timelimit),
+                                maxiter, C.c_double(lam), C.c_double(ratio_step),
+                                (csv.encode() if csv else None), resprint, verbose, bench,
+                                C.byref(iters))
     return rc, iters.value, unflat(wf, lens, [R] * len(lens)), unflat(gf, lens, [R] * len(lens))
 
 
@@ -294,32 +296,34 @@ def als_tucker(V, Ws, core, tol, maxiter, timelimit=5e3):
     return rc, iters.value, unflat(wf, lens, ranks), cf.reshape(ranks, order="F")
 
 
-def als_tucker_dt(V, Ws, core, tol, maxiter, csv=None, resprint=10, timelimit=5e3, verbose=0):
+def als_tucker_dt(V, Ws, core, tol, maxiter, csv=None, resprint=10, timelimit=5e3, verbose=0,
+                  bench=0):
     lens = V.shape
     ranks = [W.shape[1] for W in Ws]
     wf = flat(Ws)
     cf = np.asfortranarray(core).ravel(order="F").copy()
     Vf = np.asfortranarray(V)
     iters = C.c_int(0)
-    rc = lib().ppo_als_tucker_dt(len(lens), _lens(lens), _ranks(ranks), _dp(Vf), _dp(wf), _dp(cf),
-                                 C.c_double(tol), C.c_double(timelimit), maxiter,
-                                 (csv.encode() if csv else None), resprint, verbose,
-                                 C.byref(iters))
+    rc = lib().ppo_als_tucker_dt_ex(len(lens), _lens(lens), _ranks(ranks), _dp(Vf), _dp(wf),
+                                    _dp(cf), C.c_double(tol), C.c_double(timelimit), maxiter,
+                                    (csv.encode() if csv else None), resprint, verbose, bench,
+                                    C.byref(iters))
     return rc, iters.value, unflat(wf, lens, ranks), cf.reshape(ranks, order="F")
 
 
 def als_tucker_pp(V, Ws, core, tol, tol_init, maxiter, csv=None, resprint=10, timelimit=5e3,
-                  verbose=0):
+                  verbose=0, bench=0):
     lens = V.shape
     ranks = [W.shape[1] for W in Ws]
     wf = flat(Ws)
     cf = np.asfortranarray(core).ravel(order="F").copy()
     Vf = np.asfortranarray(V)
     iters = C.c_int(0)
-    rc = lib().ppo_als_tucker_pp(len(lens), _lens(lens), _ranks(ranks), _dp(Vf), _dp(wf), _dp(cf),
-                                 C.c_double(tol), C.c_double(tol_init), C.c_double(timelimit),
-                                 maxiter, (csv.encode() if csv else None), resprint, verbose,
-                                 C.byref(iters))
+    rc = lib().ppo_als_tucker_pp_ex(len(lens), _lens(lens), _ranks(ranks), _dp(Vf), _dp(wf),
+                                    _dp(cf), C.c_double(tol), C.c_double(tol_init),
+                                    C.c_double(timelimit), maxiter,
+                                    (csv.encode() if csv else None), resprint, verbose, bench,
+                                    C.byref(iters))
     return rc, iters.value, unflat(wf, lens, ranks), cf.reshape(ranks, order="F")
 
 

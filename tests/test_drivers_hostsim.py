@@ -1,0 +1,34 @@
+"""CPU runs of the DRIVER tests (tests/test_gpu_driver.py): the product's bin/test_ALS, bin/pp_bench
+and bin/run sources linked against the host stand-in (tests/hostsim) — flag parsing, echo block,
+CSV, the V/W file exchange and the `-tensor o*` path, pp_bench's line format, against the oracle.
+They say nothing about the HIP kernels; `-m gpu` runs the same tests on the real binaries."""
+import os
+import subprocess
+
+import pytest
+
+import test_gpu_driver as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def BIN():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+    return os.path.join(ROOT, "tests", "hostsim", "build")
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    return False
+
+
+test_test_ALS_matches_oracle = D.test_test_ALS_matches_oracle
+test_cli_defaults_and_silent_resets = D.test_cli_defaults_and_silent_resets
+test_pp_bench_lines = D.test_pp_bench_lines
+test_every_tensor_source_and_pp_mode_runs = D.test_every_tensor_source_and_pp_mode_runs
+test_run_driver_class_api = D.test_run_driver_class_api
+test_cfg1_cli_matches_oracle = D.test_cfg1_cli_matches_oracle
+test_file_exchange_and_o_path = D.test_file_exchange_and_o_path
+test_o_path_rejects_short_file = D.test_o_path_rejects_short_file
+test_pp_bench_tucker_lines = D.test_pp_bench_tucker_lines

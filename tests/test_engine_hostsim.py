@@ -38,11 +38,13 @@ test_random_larger_shapes_against_oracle = G.test_random_larger_shapes_against_o
 test_class_api_als_matches_oracle = G.test_class_api_als_matches_oracle
 test_class_api_reference_test_case = G.test_class_api_reference_test_case
 test_tensor_refill_while_session_alive = G.test_tensor_refill_while_session_alive
+test_bench_mode_matches_oracle = G.test_bench_mode_matches_oracle
 
 import test_gpu_tucker as GT  # noqa: E402
 
 test_ttmc_matches_oracle = GT.test_ttmc_matches_oracle
 test_hosvd_and_dt_sweeps = GT.test_hosvd_and_dt_sweeps
 test_tucker_pp_driver_matches_oracle = GT.test_tucker_pp_driver_matches_oracle
+test_tucker_bench_mode_matches_oracle = GT.test_tucker_bench_mode_matches_oracle
 test_tensor_p_laplacian = G.test_tensor_p_laplacian
 test_tensor_c_collinear = G.test_tensor_c_collinear

@@ -619,3 +619,53 @@ def test_tensor_refill_while_session_alive(pp, ctx, dtype):
         assert relerr(a, b) < FTOL[dtype], relerr(a, b)
     s.close()
     t.close()
+
+
+def _bench_lines(path):
+    """labels of a pp_bench-format file: text before the comma of every non-empty line"""
+    return [ln.split(",")[0] for ln in open(path).read().splitlines() if ln.strip()]
+
+
+@pytest.mark.parametrize("maxiter,resprint", [(1, 1), (4, 2), (3, 1)])
+@pytest.mark.parametrize("lens,R", [([12, 11, 10, 9], 3), ([10, 9, 8], 3)])
+def test_bench_mode_matches_oracle(pp, ctx, lens, R, maxiter, resprint, tmp_path):
+    """`bool bench = true` of alsCP_DT / alsCP_PP (what pp_bench.cxx:299-314 calls with maxiter 1):
+    no heading, [DTtime] at every print point but iter 0 (als_CP.cxx:203-209); the PP phase without
+    its restart test, with the [PPfirst]/[PPsecond] bookkeeping and iter++ on exit
+    (als_CP.cxx:656-664,735-748,829-830). Factors, gradients, iteration counts, return values and
+    the emitted line labels against the oracle's restatement (fp64 storage)."""
+    V, W = problem(lens, R, 6, "r")
+    G = O.init_factors(lens, R, 96)
+    Vn = np.linalg.norm(V)
+    # start where PP is a valid approximation (pp_bench itself starts from random factors, where
+    # several approximate sweeps in a row are chaotic and no factor comparison means anything)
+    _, _, W, G = O.als_cp_dt(V, W, G, tol=0.0, maxiter=7, resprint=1000)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.CP(ctx, t, R)
+    for phase in ("dt", "pp"):
+        c_ref, c_got = str(tmp_path / f"ref_{phase}.csv"), str(tmp_path / f"got_{phase}.csv")
+        for c in (c_ref, c_got):
+            open(c, "w").write("[timetype],[dtime]\n")   # the driver's heading; callees append
+        kw = dict(tol=1e-9 * Vn, maxiter=maxiter, resprint=resprint)
+        s.set_factors(W, G)
+        if phase == "dt":
+            rc_ref, it_ref, W_ref, G_ref = O.als_cp_dt(V, W, G, csv=c_ref, bench=1, **kw)
+            rc, it = s.run_dt(csv=c_got, csv_append=1, bench=1, **kw)
+        else:
+            rc_ref, it_ref, W_ref, G_ref = O.als_cp_pp(V, W, G, tol_init=0.05, csv=c_ref, bench=1, **kw)
+            rc, it = s.run_pp(tol_init=0.05, csv=c_got, csv_append=1, bench=1, **kw)
+        assert (rc, it) == (rc_ref, it_ref), phase
+        assert _bench_lines(c_got) == _bench_lines(c_ref), phase
+        labels = _bench_lines(c_got)[1:]
+        if phase == "dt":
+            assert labels and set(labels) == {"[DTtime]"}
+        else:
+            assert labels == ["  [PPfirst]  ", "  [PPsecond]  "]
+            assert it == maxiter + 2          # the loop's maxiter+1, then iter++ on exit
+        W_got, G_got = s.get_factors(with_grad=True)
+        for a, b in zip(W_got, W_ref):
+            assert relerr(a, b) < 1e-8, (phase, relerr(a, b))
+        for a, b in zip(G_got, G_ref):
+            assert np.linalg.norm(a - b) < 1e-7 * (1 + np.linalg.norm(b)), phase
+    s.close()
+    t.close()

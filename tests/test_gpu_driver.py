@@ -11,7 +11,18 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "pairwise-perturbation_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def BIN():
+    """directory of the driver binaries under test (tests/test_drivers_hostsim.py re-runs these
+    tests with the same drivers linked against the host stand-in)"""
+    return os.path.join(ROOT, "pairwise-perturbation_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    return True
 
 
 def run(cmd):
@@ -21,7 +32,7 @@ def run(cmd):
 
 
 @pytest.mark.parametrize("pp,prec", [(0, 64), (1, 64), (0, 32)])
-def test_test_ALS_matches_oracle(tmp_path, pp, prec):
+def test_test_ALS_matches_oracle(BIN, tmp_path, pp, prec):
     s, R, N = 12, 3, 4
     csv = str(tmp_path / "out.csv")
     out = run([os.path.join(BIN, "test_ALS"), "-model", "CP", "-tensor", "r", "-dim", str(N),
@@ -61,7 +72,7 @@ def test_test_ALS_matches_oracle(tmp_path, pp, prec):
         assert abs(a[2] - b[2]) <= tol * abs(a[2]) and abs(a[5] - b[5]) <= tol * abs(a[5])
 
 
-def test_cli_defaults_and_silent_resets(tmp_path):
+def test_cli_defaults_and_silent_resets(BIN, tmp_path):
     """out-of-range values are silently reset to the defaults (test_ALS.cxx:76-146)"""
     csv = str(tmp_path / "o.csv")
     out = run([os.path.join(BIN, "test_ALS"), "-model", "X", "-tensor", "r", "-dim", "3", "-size",
@@ -74,7 +85,7 @@ def test_cli_defaults_and_silent_resets(tmp_path):
     assert "resprint=  10" in lines[5]
 
 
-def test_pp_bench_lines(tmp_path):
+def test_pp_bench_lines(BIN, tmp_path):
     csv = str(tmp_path / "b.csv")
     run([os.path.join(BIN, "pp_bench"), "-model", "CP", "-tensor", "r", "-dim", "4", "-size", "16",
          "-rank", "3", "-maxiter", "3", "-filename", csv])
@@ -97,7 +108,7 @@ def test_pp_bench_lines(tmp_path):
     ["-model", "Tucker", "-tensor", "r2", "-dim", "3", "-size", "12", "-rank", "3", "-pp", "1",
      "-pp_res_tol", "0.1"],
 ])
-def test_every_tensor_source_and_pp_mode_runs(tmp_path, args):
+def test_every_tensor_source_and_pp_mode_runs(BIN, tmp_path, args):
     """the whole -tensor / -pp flag space of test_ALS.cxx:222-326,352-396 is accepted and decreases
     the residual"""
     csv = str(tmp_path / "o.csv")
@@ -109,7 +120,7 @@ def test_every_tensor_source_and_pp_mode_runs(tmp_path, args):
 
 
 @pytest.mark.parametrize("pp,kind", [(0, 1), (1, 2), (4, 0)])
-def test_run_driver_class_api(tmp_path, pp, kind):
+def test_run_driver_class_api(BIN, tmp_path, pp, kind):
     """bin/run: the class-API front end (run.cxx:47-472). Echo block of run.cxx:222-240 (with the
     updaterank / randomsvd fields), dispatch of run.cxx:387-414, console rows with [sweeps] and
     [residual], CSV rows against the oracle's CPD::als restatement."""
@@ -141,8 +152,153 @@ def test_run_driver_class_api(tmp_path, pp, kind):
         assert abs(a[5] - b[5]) <= 1e-4 * abs(a[5]) + 1e-7 * Vn
 
 
-def test_run_driver_rejects_low_rank_optimizers(tmp_path):
+def test_run_driver_rejects_low_rank_optimizers(BIN, tmp_path):
     p = subprocess.run([os.path.join(BIN, "run"), "-tensor", "r", "-dim", "4", "-size", "8", "-pp",
                         "2", "-filename", str(tmp_path / "o.csv")], capture_output=True, text=True,
                        timeout=120)
     assert p.returncode == 2 and "low-rank" in p.stderr
+
+
+def _read_doubles(path):
+    return np.fromfile(path, dtype="<f8")
+
+
+def _split_flat(flat, lens, ranks):
+    out, o = [], 0
+    for s, r in zip(lens, ranks):
+        out.append(flat[o:o + s * r].reshape((s, r), order="F"))
+        o += s * r
+    return out, o
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_cfg1_cli_matches_oracle(BIN, full_size, tmp_path, prec):
+    """BASELINE.json configs[0], verbatim: `test_ALS -model CP -tensor r -dim 3 -size 64 -rank 5
+    -pp 0` (order 3 = the generalised tree, SURVEY §8a note). Default flags otherwise: -tol 1e-10,
+    -maxiter 5000, -resprint 10; the run ends by the reference's stop criterion in fp64 storage
+    (the default). CSV rows and the FINAL FACTORS (-dumpW) against the oracle driven from the
+    same counter-based initialisation; fp32 storage (-prec 32, 200 sweeps): factors within 1e-5."""
+    s, R, N = (64 if full_size else 20), 5, 3
+    csv, dump = str(tmp_path / "out.csv"), str(tmp_path / "w.bin")
+    cmd = [os.path.join(BIN, "test_ALS"), "-model", "CP", "-tensor", "r", "-dim", str(N), "-size",
+           str(s), "-rank", str(R), "-pp", "0", "-filename", csv, "-dumpW", dump]
+    maxiter = 5000
+    if prec == 32:
+        maxiter = 200
+        cmd += ["-prec", "32", "-maxiter", str(maxiter)]
+    out = run(cmd)
+    assert out.splitlines()[0] == "  model=  CP  tensor=  r  pp=  0"
+    assert out.splitlines()[1] == f"  dim=  {N}  size=  {s}  rank=  {R}"
+    lens = [s] * N
+    V = O.build_V(O.init_factors(lens, R, 1000))
+    W, G = O.init_factors(lens, R, 2000), O.init_factors(lens, R, 3000)
+    Vn = np.linalg.norm(V)
+    ref = str(tmp_path / "ref.csv")
+    rc_ref, it_ref, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=1e-10 * Vn, maxiter=maxiter, csv=ref,
+                                               resprint=10)
+    h1, r1 = O.read_csv(ref)
+    h2, r2 = O.read_csv(csv)
+    assert h1 == h2
+    floor = (1e-7 if prec == 64 else 1e-4) * Vn     # compare rows above the rounding floor
+    n = 0
+    for a, b in zip(r1, r2):
+        if a[2] < floor or a[5] < floor:
+            break
+        assert a[:2] == b[:2] and a[4] == b[4] == 0
+        assert abs(a[2] - b[2]) <= (1e-4 if prec == 64 else 1e-2) * a[2], (a, b)
+        assert abs(a[5] - b[5]) <= (1e-4 if prec == 64 else 1e-2) * a[5], (a, b)
+        n += 1
+    assert n >= 5
+    if prec == 64:
+        # both runs end by `gradnorm < tol` (an exact-rank problem), within a print period
+        assert rc_ref == 1 and r2[-1][2] < 1e-10 * Vn * 1.0001
+        assert abs(r2[-1][1] - r1[-1][1]) <= 10
+    flat = _read_doubles(dump)
+    Wd, o = _split_flat(flat, lens, [R] * N)
+    assert flat.size == 2 * o
+    for a, b in zip(Wd, W_ref):
+        assert relerr(a, b) < (1e-7 if prec == 64 else 1e-5), (prec, relerr(a, b))
+
+
+@pytest.mark.parametrize("model", ["CP", "Tucker"])
+def test_file_exchange_and_o_path(BIN, tmp_path, model):
+    """-dumpV / -dumpW0 / -loadW0 / -dumpW (raw fp64, first index fastest: the layout
+    V.read_dense_from_file reads, test_ALS.cxx:289-325) and the `-tensor o1` file path
+    (test_ALS.cxx:287-305) on a small file through the -lens hook: the dumps hold what the oracle
+    builds, a run fed back from the files reproduces the first run bit for bit, and the oracle
+    driven from the SAME FILES agrees — the route by which a CTF run made elsewhere can be compared."""
+    lens, R = [6, 8, 7, 9], 3
+    ranks = [2, 3, 3, 2]
+    vbin, w0, w1, w2 = (str(tmp_path / n) for n in ("v.bin", "w0.bin", "w1.bin", "w2.bin"))
+    c1, c2 = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    # the source tensor: an `r`-type tensor of non-cubic shape, written the way imageloader.py does
+    V = O.build_V(O.init_factors(lens, R, 1000))
+    np.asfortranarray(V).ravel(order="F").astype("<f8").tofile(vbin)
+    common = ["-model", model, "-tensor", "o1", "-tensorfile", vbin, "-lens",
+              ",".join(map(str, lens)), "-rank", str(R), "-maxiter", "12", "-resprint", "1", "-tol",
+              "1e-12", "-dim", "4"]
+    if model == "Tucker":
+        common += ["-ranks", ",".join(map(str, ranks))]
+    vdump = str(tmp_path / "vdump.bin")
+    out = run([os.path.join(BIN, "test_ALS")] + common +
+              ["-filename", c1, "-dumpV", vdump, "-dumpW0", w0, "-dumpW", w1])
+    assert "Read the tensor from file" in out and "Read dataset finished" in out
+    assert np.array_equal(_read_doubles(vdump), _read_doubles(vbin))   # fp64 storage: exact
+    run([os.path.join(BIN, "test_ALS")] + common + ["-filename", c2, "-loadW0", w0, "-dumpW", w2])
+    assert np.array_equal(_read_doubles(w1), _read_doubles(w2))
+    rows1, rows2 = O.read_csv(c1)[1], O.read_csv(c2)[1]
+    assert [r[:6] for r in rows1] == [r[:6] for r in rows2]
+    Vf = _read_doubles(vbin).reshape(lens, order="F")
+    Vn = np.linalg.norm(Vf)
+    if model == "CP":
+        W0, o = _split_flat(_read_doubles(w0), lens, [R] * 4)
+        G0, _ = _split_flat(_read_doubles(w0)[o:], lens, [R] * 4)
+        for a, b in zip(W0, O.init_factors(lens, R, 2000)):
+            assert np.array_equal(a, b)
+        _, _, W_ref, G_ref = O.als_cp_dt(Vf, W0, G0, tol=1e-12 * Vn, maxiter=12, resprint=1)
+        W1, o = _split_flat(_read_doubles(w1), lens, [R] * 4)
+        G1, _ = _split_flat(_read_doubles(w1)[o:], lens, [R] * 4)
+        for a, b in zip(W1, W_ref):
+            assert relerr(a, b) < 1e-8
+        for a, b in zip(G1, G_ref):
+            assert np.linalg.norm(a - b) < 1e-7 * (1 + np.linalg.norm(b))
+    else:
+        W0, o = _split_flat(_read_doubles(w0), lens, ranks)
+        Wh, core_h = O.hosvd(Vf, ranks)
+        for a, b in zip(W0, Wh):
+            assert relerr(a @ a.T, b @ b.T) < 1e-8
+        _, _, W_ref, core_ref = O.als_tucker_dt(Vf, W0, O.ttmc(Vf, W0, -1), tol=1e-12 * Vn,
+                                                maxiter=12, resprint=1)
+        flat = _read_doubles(w1)
+        W1, o = _split_flat(flat, lens, ranks)
+        assert flat.size == o + int(np.prod(ranks))
+        for a, b in zip(W1, W_ref):
+            assert relerr(a @ a.T, b @ b.T) < 1e-7
+        assert abs(np.linalg.norm(flat[o:]) - np.linalg.norm(core_ref)) < 1e-8 * np.linalg.norm(core_ref)
+
+
+def test_o_path_rejects_short_file(BIN, tmp_path):
+    vbin = str(tmp_path / "v.bin")
+    np.zeros(100).tofile(vbin)
+    p = subprocess.run([os.path.join(BIN, "test_ALS"), "-tensor", "o1", "-tensorfile", vbin, "-lens",
+                        "4,5,6,7", "-dim", "4", "-rank", "2", "-filename", str(tmp_path / "o.csv")],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "does not hold exactly 840 doubles" in p.stderr
+
+
+def test_pp_bench_tucker_lines(BIN, tmp_path):
+    """pp_bench -model Tucker (pp_bench.cxx:321-345; script_weakscaling.py:41-46 runs it)"""
+    csv = str(tmp_path / "b.csv")
+    out = run([os.path.join(BIN, "pp_bench"), "-model", "Tucker", "-tensor", "r2", "-dim", "3",
+               "-size", "14", "-rank", "3", "-maxiter", "3", "-filename", csv])
+    text = open(csv).read().splitlines()
+    assert text[0] == "[timetype],[dtime]"
+    assert sum(ln.startswith("[DTtime],") for ln in text) == 3
+    assert sum(ln.startswith("  [PPfirst]  ,") for ln in text) == 3
+    assert sum(ln.startswith("  [PPsecond]  ,") for ln in text) == 3
+    assert out.count("pairwise perturbation starts from 0") == 3
+    assert out.count("Iter = 2 Final Diff norm") == 6   # DT: loop end at maxiter+1; PP: iter++ on exit

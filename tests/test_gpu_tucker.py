@@ -120,3 +120,43 @@ def test_tucker_pp_driver_matches_oracle(pp, ctx, dtype, tmp_path):
     W, core = s.get_factors()
     for a, b in zip(W, W_ref):
         assert np.linalg.norm(proj(a) - proj(b)) < (5e-2 if dtype == 0 else 1e-5)
+
+
+@pytest.mark.parametrize("maxiter,resprint", [(1, 1), (3, 2)])
+def test_tucker_bench_mode_matches_oracle(pp, ctx, maxiter, resprint, tmp_path):
+    """`bool bench = true` of alsTucker_DT / alsTucker_PP as pp_bench.cxx:321-345 drives them: random
+    (non-orthonormal) factors — hosvd is commented out there — a zero core on the first call, the
+    SAME core object carried from call to call, factors restored before each. [DTtime] /
+    [PPfirst] / [PPsecond] labels, iteration counts, return values, projectors and ||core||."""
+    lens, ranks = [12, 10, 9], [3, 3, 3]
+    V = O.fill_uniform(int(np.prod(lens)), 4, lo=-1.0, hi=1.0).reshape(lens, order="F")
+    W0 = [O.fill_uniform(s * r, 50 + i).reshape((s, r), order="F")
+          for i, (s, r) in enumerate(zip(lens, ranks))]
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    core_ref = np.zeros(ranks)
+    kw = dict(tol=1e-12, maxiter=maxiter, resprint=resprint)
+    for rep, phase in enumerate(["dt", "dt", "pp", "pp"]):
+        c_ref, c_got = str(tmp_path / f"ref{rep}.csv"), str(tmp_path / f"got{rep}.csv")
+        for c in (c_ref, c_got):
+            open(c, "w").write("[timetype],[dtime]\n")
+        s.set_factors(W0)
+        if phase == "dt":
+            rc_ref, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, core_ref, csv=c_ref, bench=1, **kw)
+            rc, it = s.run_dt(csv=c_got, csv_append=1, bench=1, **kw)
+        else:
+            rc_ref, it_ref, W_ref, core_ref = O.als_tucker_pp(V, W0, core_ref, tol_init=0.05,
+                                                              csv=c_ref, bench=1, **kw)
+            rc, it = s.run_pp(tol_init=0.05, csv=c_got, csv_append=1, bench=1, **kw)
+        assert (rc, it) == (rc_ref, it_ref), (rep, phase)
+        got = [ln.split(",")[0] for ln in open(c_got).read().splitlines() if ln.strip()]
+        ref = [ln.split(",")[0] for ln in open(c_ref).read().splitlines() if ln.strip()]
+        assert got == ref and len(got) > 1, (rep, got, ref)
+        if phase == "pp":
+            assert got[1:] == ["  [PPfirst]  ", "  [PPsecond]  "] and it == maxiter + 1
+        W_got, core_got = s.get_factors()
+        for a, b in zip(W_got, W_ref):
+            assert relerr(proj(a), proj(b)) < 1e-7, (rep, phase)
+        assert abs(np.linalg.norm(core_got) - np.linalg.norm(core_ref)) < 1e-8 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
