@@ -669,3 +669,29 @@ def test_bench_mode_matches_oracle(pp, ctx, lens, R, maxiter, resprint, tmp_path
             assert np.linalg.norm(a - b) < 1e-7 * (1 + np.linalg.norm(b)), phase
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("lens,R", [([20, 20, 20, 20], 5), ([24, 18, 16], 4)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_long_run_factor_parity(pp, ctx, lens, R, dtype):
+    """north_star's bar on a LONG run: 200 exact sweeps of a `-tensor r` problem (ALS on these
+    collinear U(0,1) problems needs ~100-200 sweeps to converge), factor matrices within 1e-5
+    relative Frobenius of the fp64 oracle for fp32 tensor storage (1e-8 for fp64 storage), checked
+    along the way as well (sweeps 25, 100, 200) so that a transient drift cannot hide"""
+    V, W = problem(lens, R, 11, "r")
+    G = O.init_factors(lens, R, 95)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    done = 0
+    W_ref, G_ref = W, G
+    for upto in (25, 100, 200):
+        _, _, W_ref, G_ref = O.als_cp_dt(V, W_ref, G_ref, tol=0.0, maxiter=upto - done - 1, resprint=10 ** 6)
+        s.sweeps_dt(upto - done)
+        done = upto
+        for a, b in zip(s.get_factors(), W_ref):
+            assert relerr(a, b) < FTOL[dtype], (upto, relerr(a, b))
+    r_ref = O.residual(V, W_ref)
+    assert abs(O.residual(V, s.get_factors()) - r_ref) < (1e-5 if dtype == 0 else 1e-9) * np.linalg.norm(V)
+    s.close()
+    t.close()

@@ -93,6 +93,57 @@ def test_cfg2_pp_driver_full_size(pp, ctx):
     V.close()
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_cfg3_pp_phase_pattern_and_factors_full_size(pp, ctx, dtype, tmp_path):
+    """BASELINE configs[2] (`-pp 1`, s = 200, R = 10) against alsCP_PP in closed form
+    (rank_structured.als_cp_pp, pinned to the oracle at small sizes): the SAME sequence of print
+    rows — iteration numbers and the DT/PP flag of every one, i.e. where each exact phase hands over
+    to pairwise perturbation and where PP restarts — gradnorm / diffV trajectories while above the
+    storage floor, and the final factor matrices (1e-5 for fp32 storage)."""
+    lens, A, W, G = _problem(pp, 200, 10)
+    V = pp.Tensor(ctx, lens, dtype).fill_cp(A)
+    Vn = RS.norm(A)
+    kw = dict(tol=1e-10 * Vn, tol_init=0.01, maxiter=120, resprint=1)
+    rows_ref, it_ref, W_ref, _ = RS.als_cp_pp(A, W, G, **kw)
+    s = pp.CP(ctx, V, 10)
+    s.set_factors(W, G)
+    csv = str(tmp_path / "pp.csv")
+    _, it = s.run_pp(csv=csv, **kw)
+    rows = [[float(x) for x in ln.split(",")] for ln in open(csv).read().splitlines()[1:] if ln]
+    assert it == it_ref and len(rows) == len(rows_ref)
+    assert [(int(r[1]), int(r[4])) for r in rows] == [(r[0], r[1]) for r in rows_ref]
+    assert sum(1 for r in rows_ref if r[1] == 1) > len(rows_ref) // 2   # mostly PP sweeps
+    floor = (2e-5 if dtype == 0 else 1e-9) * Vn
+    for got, ref in zip(rows, rows_ref):
+        if ref[2] > 100 * floor:
+            assert abs(got[2] - ref[2]) < 2e-3 * ref[2], (got, ref)
+        if ref[3] > floor:
+            assert abs(got[5] - ref[3]) < 2e-3 * ref[3] + floor, (got, ref)
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < (1e-5 if dtype == 0 else 1e-8), relerr(a, b)
+    s.close()
+    V.close()
+
+
+def test_cfg2_long_run_fp32_factor_parity(pp, ctx):
+    """north_star's bar at full size on a long run: 200 exact sweeps (s = 200, R = 10, fp32 tensor
+    storage), factors within 1e-5 relative Frobenius of the fp64 closed form at sweeps 50 and 200"""
+    lens, A, W, G = _problem(pp, 200, 10)
+    V = pp.Tensor(ctx, lens, 0).fill_cp(A)
+    s = pp.CP(ctx, V, 10)
+    s.set_factors(W, G)
+    W_ref, G_ref, done = W, G, 0
+    for upto in (50, 200):
+        W_ref, G_ref = RS.als_cp_dt(A, W_ref, G_ref, upto - done)
+        s.sweeps_dt(upto - done)
+        done = upto
+        for a, b in zip(s.get_factors(), W_ref):
+            assert relerr(a, b) < 1e-5, (upto, relerr(a, b))
+    assert s.residual() < 1e-6 * RS.norm(A)
+    s.close()
+    V.close()
+
+
 def test_cfg4_full_size(pp, ctx):
     """s = 400, R = 20 on ONE GPU (102 GB fp32 + the second resident layout): two n-tiles, 64-bit
     offsets everywhere. MTTKRPs and exact sweeps against the closed form."""
