@@ -42,9 +42,21 @@ def sweep_flops(lens, R, schedule="msdt"):
     return (4.0 / 3.0) * (2.0 * s ** 4 * R + 4.0 * s ** 3 * R + 6.0 * s ** 2 * R)
 
 
-def cpu_baseline(lens, R, budget_s=20.0):
-    """the fp64 oracle (CTF-like contraction sequence, OpenMP) timed on this host's cores on a
-    bounded sample: the same problem at reduced mode size, scaled by s^4"""
+def _mem_available_bytes():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def cpu_baseline(lens, R, budget_s=25.0):
+    """the fp64 oracle (the reference's TTM-by-TTM contraction sequence, OpenMP) timed on this
+    host's cores ON THE SAME PROBLEM AT FULL SIZE (cfg2: 12.8 GB of fp64 tensor in host memory,
+    SURVEY §8d) — a bounded sample of 2-3 sweeps. Only when the host cannot hold the tensor (or it
+    is not cfg2-sized) is the mode size reduced and the s^4 scaling law applied; `sample` says which."""
     import numpy as np
     import oracle_lib as O
     try:
@@ -52,43 +64,50 @@ def cpu_baseline(lens, R, budget_s=20.0):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     s_full = lens[0]
-    s = min(s_full, 96)
+    need = 8.0 * float(np.prod(lens)) * 1.2 + (4 << 30)
+    s = s_full if (need < _mem_available_bytes() and np.prod(lens) <= 2e9) else min(s_full, 96)
     small = [s] * len(lens)
     Wt = O.init_factors(small, R, 1000)
     V = O.build_V(Wt)
     W = O.init_factors(small, R, 2000)
     G = O.init_factors(small, R, 3000)
-    # pick the OpenMP team size that is fastest on this host (an oversubscribed or NUMA-spread
-    # team can be slower than a smaller one); the count used is what `cores` reports
+    # OpenMP team: all the cores this process may use (what `cores` reports); on a reduced problem
+    # also try smaller teams (an oversubscribed team can lose)
+    teams = [ncpu] if s == s_full else sorted({min(ncpu, 16), min(ncpu, 64), ncpu})
     best = None
-    for nt in sorted({min(ncpu, 16), min(ncpu, 64), ncpu}):
+    for nt in teams:
         O.lib().ppo_set_num_threads(nt)
-        O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # warm
+        if s != s_full:
+            O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # warm
         t0 = time.time()
-        O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # 1 sweep (+ print blocks)
+        O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # 1 sweep + 2 print blocks
         dt = time.time() - t0
         if best is None or dt < best[0]:
             best = (dt, nt)
     t_one, nthreads = best
     O.lib().ppo_set_num_threads(nthreads)
-    k = max(1, min(10, int(budget_s / max(t_one, 1e-3))))
-    t0 = time.time()
-    O.als_cp_dt(V, W, G, tol=0.0, maxiter=k - 1, resprint=10 ** 9)
-    t = time.time() - t0
-    # subtract the two untimed-in-the-reference print blocks (iter 0 and iter maxiter): measure one
+    # the print blocks (untimed in the reference, als_CP.cxx:167,189) are measured and subtracted
     t0 = time.time()
     O.residual(V, W)
     t_print = time.time() - t0
-    per_sweep_small = max((t - 2 * t_print) / k, 1e-9)
+    k = max(1, min(10, int((budget_s - t_one) / max(t_one - 2 * t_print, 1e-3))))
+    t0 = time.time()
+    O.als_cp_dt(V, W, G, tol=0.0, maxiter=k - 1, resprint=10 ** 9)
+    t = time.time() - t0
+    per_sweep = max((t - 2 * t_print) / k, 1e-9)
     scale = (s_full / s) ** 4
+    what = (f"{k} timed sweeps (after 1 warm-up sweep) of the SAME problem at full size s={s_full} "
+            f"(fp64 tensor, {8e-9 * float(np.prod(lens)):.1f} GB in host memory)" if s == s_full else
+            f"{k} sweeps at reduced size s={s}, scaled by (s/{s})^4 = {scale:.1f} to s={s_full} "
+            "(host memory cannot hold the full tensor)")
     return {
-        "value": 1.0 / (per_sweep_small * scale),
+        "value": 1.0 / (per_sweep * scale),
         "unit": "sweeps/s",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"{k} sweeps of the same CP order-4 R={R} problem at s={s} (fp64, OpenMP oracle "
-                  f"with the reference's TTM-by-TTM contraction order), {per_sweep_small:.3f} s/sweep, "
-                  f"scaled by (s/{s})^4 = {scale:.1f} to s={s_full}",
+        "sample": what + f": fp64 OpenMP oracle with the reference's TTM-by-TTM contraction order, "
+                         f"{per_sweep:.3f} s/sweep on {nthreads} threads, print blocks "
+                         f"({t_print:.2f} s each) subtracted as in als_CP.cxx:167,189",
     }
 
 
@@ -142,12 +161,6 @@ def main():
     Wtrue = ppals.init_factors(lens, R, 1000)
     W0 = ppals.init_factors(lens, R, 2000)
     G0 = ppals.init_factors(lens, R, 3000)
-    V = ppals.Tensor(ctx, lens, dtype).fill_cp(Wtrue)
-    cp = ppals.CP(ctx, V, R)
-    cp.set_factors(W0, G0)
-    if args.schedule:
-        cp.set_schedule(args.schedule)
-    schedule = cp.schedule
 
     def barrier():
         ctx.sync()
@@ -155,23 +168,44 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    cp.sweeps_dt(args.warmup)
-    barrier()
-    ctx.profile_reset()
-    ctx.profile_enable(1)  # HIP events around the tensor scans only (the roofline kernel)
-    t0 = time.perf_counter()
-    cp.sweeps_dt(args.steps)
-    ctx.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ctx.profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    barrier()
+    def measure(cp, steps, warmup):
+        """W untimed sweeps, then EXACTLY `steps` timed ones between barrier + synchronize on both
+        sides (max over ranks); HIP events on the engine's stream around the tensor scans only"""
+        cp.set_factors(W0, G0)
+        cp.sweeps_dt(warmup)
+        barrier()
+        ctx.profile_reset()
+        ctx.profile_enable(1)
+        t0 = time.perf_counter()
+        cp.sweeps_dt(steps)
+        ctx.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ctx.profile_enable(0)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        barrier()
+        launches, scan_ms, scan_bytes = ctx.profile_read(0)
+        rec = {"ms_per_step": 1e3 * elapsed / steps, "value": steps / elapsed, "steps": steps,
+               "schedule": cp.schedule}
+        if launches > 0:
+            avg_ms = scan_ms / launches
+            achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9
+            rec["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "launches": launches, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": scan_bytes / launches,
+                "scan_ms_per_step": scan_ms / steps, "scan_launches_per_step": launches / steps}
+        return rec
 
-    launches, scan_ms, scan_bytes = ctx.profile_read(0)
+    V = ppals.Tensor(ctx, lens, dtype).fill_cp(Wtrue)
+    cp = ppals.CP(ctx, V, R)
+    if args.schedule:
+        cp.set_schedule(args.schedule)
+    schedule = cp.schedule
+    head = measure(cp, args.steps, args.warmup)
     gradnorm = cp.gradnorm()
     resid = cp.residual()
     vnorm = V.norm()
@@ -186,9 +220,53 @@ def main():
     _, other_ms, _ = ctx.profile_read(1)
     other_ms_per_step = other_ms / extra
 
+    # ---- sub-records beside the headline (same JSON line, never `value`): the reference's own
+    # two-scan schedule (SURVEY §8d counts ITS bytes: 2 s^4 sizeof per sweep) and the reference's
+    # own precision (fp64 storage) at N = 1; the other shard plan at N > 1
+    sub = {}
+    sub_steps = max(4, min(args.steps, 10))
+    if world == 1 and not args.schedule and args.workload != "cp4_s400_r20":
+        other = "dt" if schedule == "msdt" else "msdt"
+        cp.set_schedule(other)
+        r = measure(cp, sub_steps, 2)
+        r["dtype"] = args.dtype
+        r["sweep_flops"] = sweep_flops(lens, R, other)
+        r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
+        sub[f"{other}_schedule_{args.dtype}"] = r
+        cp.set_schedule(schedule)
+    if world > 1:
+        # the plan north_star names (reduce-scatter of the s x R partials + row-block solve +
+        # all-gather) beside the default for these message sizes (one all-reduce + redundant fused
+        # update): PPALS_COMM_SMALL_BYTES moves the switch, read when a session is created
+        cp.close()
+        old = os.environ.get("PPALS_COMM_SMALL_BYTES")
+        os.environ["PPALS_COMM_SMALL_BYTES"] = "0"
+        cp = ppals.CP(ctx, V, R)
+        if args.schedule:
+            cp.set_schedule(args.schedule)
+        r = measure(cp, sub_steps, 2)
+        r["comm_plan"] = "reduce-scatter + row-block update + all-gather per mode"
+        sub["reduce_scatter_plan"] = r
+        if old is None:
+            del os.environ["PPALS_COMM_SMALL_BYTES"]
+        else:
+            os.environ["PPALS_COMM_SMALL_BYTES"] = old
+    cp.close()
+    V.close()
+    if world == 1 and args.dtype == "f32" and not args.schedule and args.workload == "cp4_s200_r10":
+        V64 = ppals.Tensor(ctx, lens, ppals.F64).fill_cp(Wtrue)
+        cp64 = ppals.CP(ctx, V64, R)
+        r = measure(cp64, sub_steps, 2)
+        r["dtype"] = "f64"
+        r["sweep_flops"] = sweep_flops(lens, R, cp64.schedule)
+        r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
+        sub[f"{cp64.schedule}_schedule_f64"] = r
+        cp64.close()
+        V64.close()
+
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        sweeps_s = args.steps / elapsed
+        ms_per_step = head["ms_per_step"]
+        sweeps_s = head["value"]
         flops = sweep_flops(lens, R, schedule)
         esz = 4 if args.dtype == "f32" else 8
         out = {
@@ -210,7 +288,9 @@ def main():
                                    f"stored {args.dtype} in HBM, factor/Gram/solve math fp64; "
                                    f"sweep schedule {schedule} (same ALS iterates either way)",
                        "lens": lens, "rank": R, "sharding": f"leading-mode block x{world}",
-                       "comm": "rccl" if use_comm else "none"},
+                       "comm": ("rccl: one all-reduce of the s x R partials per mode + redundant "
+                                "fused update (default below 1 MiB); sub_records.reduce_scatter_plan "
+                                "= the reduce-scatter / all-gather plan") if use_comm else "none"},
             "mttkrp_tflops": flops * sweeps_s / 1e12,
             "sweep_flops": flops,
             "final_gradnorm": gradnorm,
@@ -231,24 +311,20 @@ def main():
                                + " / ".join(sorted(ks)))
         except Exception:
             pass
-        if launches > 0:
-            avg_ms = scan_ms / launches
-            achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
+        if "roofline" in head:
+            rl = dict(head["roofline"])
+            rl.update({
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_scan_suffix_buf (tensor scan: one mode contracted per launch under msdt, "
                           "a mode half under dt)",
-                "launches": launches, "avg_launch_ms": avg_ms,
-                "algorithmic_bytes_per_launch": scan_bytes / launches,
-                "scan_ms_per_step": scan_ms / args.steps,
                 "other_profiled_ms_per_step": other_ms_per_step,
-                "scan_launches_per_step": launches / args.steps,
                 "note": f"algorithmic bytes = one read of the local tensor shard "
-                        f"({esz} B/elem) per scan launch; launches per sweep: 2 (dt) or N/(N-1) "
-                        f"(msdt: one first-level contraction serves N-1 mode updates)",
-            }
+                        f"({esz} B/elem) + the result the launch must write, per scan launch; "
+                        f"launches per sweep: 2 (dt) or N/(N-1) (msdt: one first-level "
+                        f"contraction serves N-1 mode updates)"})
+            out["roofline"] = rl
+        if sub:
+            out["sub_records"] = sub
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(lens, R)
@@ -257,8 +333,6 @@ def main():
                                        "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
 
-    cp.close()
-    V.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

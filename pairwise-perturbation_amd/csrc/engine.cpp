@@ -627,15 +627,20 @@ void CpEngine::ms_reserve(RTensor &t, size_t bytes) {
 // (profiles/README.md). k = 1 wins at order 4 (cfg2: 1.33 x 1.23 vs 2.0), k = 2 at order 6 with
 // s = 50, R = 6 (1.2 x 1.54 vs 1.5 x 1.01). PPALS_MSDT_ROOTS overrides.
 int CpEngine::ms_choose_roots() const {
+  // sharded: the root set is slid back past the partitioned mode 0 (ms_mode_update); it still has
+  // to end before the mode about to be updated, which needs 2k < N
+  const int kcap = dist_ ? std::max(1, (N_ - 1) / 2) : N_;
   if (const char *e = std::getenv("PPALS_MSDT_ROOTS")) {
     const int k = std::atoi(e);
-    if (k >= 1 && k <= N_ - 2) return k;
+    if (k >= 1 && k <= N_ - 2) return std::min(k, kcap);
   }
+  // (sharded: mode 0 is never in a root set, see ms_mode_update)
   double gm = 1;
-  for (int m = 0; m < N_; m++) gm *= std::pow((double)V_.glens[m], 1.0 / N_);
+  const int m_lo = (dist_ && N_ > 2) ? 1 : 0;
+  for (int m = m_lo; m < N_; m++) gm *= std::pow((double)V_.glens[m], 1.0 / (N_ - m_lo));
   int best = 1;
   double best_cost = 1e300;
-  for (int k = 1; k <= std::max(1, N_ / 2) && k <= N_ - 2; k++) {
+  for (int k = 1; k <= std::max(1, N_ / 2) && k <= N_ - 2 && k <= kcap; k++) {
     const double xfrac = R_ / std::pow(gm, k);
     const double cost = (double)N_ / (N_ - k) * (1.0 + 4.5 * xfrac);
     if (cost < best_cost) {
@@ -746,13 +751,36 @@ void CpEngine::ms_start_step(int first) {
                      L * T);
   ms_X_.pending = false;
   ms_X_.valid = true;
+  if (const char *tr = std::getenv("PPALS_TRACE_STEPS")) {  // tests: which root sets were scanned
+    if (FILE *f = std::fopen(tr, "a")) {
+      std::fprintf(f, "rank=%d root=%d k=%d layout=%s L=%lld J=%lld T=%lld\n", rank_, first, k,
+                   use_t ? "VT" : "V", (long long)L, (long long)J, (long long)T);
+      std::fclose(f);
+    }
+  }
 }
 
 // one mode update of the multi-sweep schedule: starts a new step when mode i belongs to the root
 // set of the running one (its factor was frozen into X), i.e. after N - k updates
 void CpEngine::ms_mode_update(int i, double lambda) {
   check_tensor_generation();
-  if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) ms_start_step((i - ms_k_ + N_) % N_);
+  if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) {
+    int first = (i - ms_k_ + N_) % N_;  // the k modes updated last: serves the next N - k updates
+    if (dist_) {
+      // Sharded: a root set that contains the partitioned mode 0 would make X a PARTIAL sum of
+      // full global size (s^(N-1) R per rank whatever P is: written once and read twice per step,
+      // 5.1 GB against a 12.8 GB shard at cfg4 / P = 8). Slide the root set back until it excludes
+      // mode 0: the step is then entered in the middle of its mode list and serves fewer updates
+      // (order 4, k = 1: runs 3,3,2 -> 3 scans per 2 sweeps instead of 8/3), every X keeps the
+      // local extent of mode 0 and scales with 1/P.
+      auto has0 = [&](int f) { return ((0 - f + N_) % N_) < ms_k_; };
+      int guard = 0;
+      while (has0(first) && guard++ < N_) first = (first - 1 + N_) % N_;
+      if (has0(first) || ((i - first + N_) % N_) < ms_k_)
+        throw std::runtime_error("ppals: no root set without the sharded mode");
+    }
+    ms_start_step(first);
+  }
   int pos = -1;
   for (size_t q = 0; q < ms_order_.size(); q++)
     if (ms_order_[q] == i) pos = (int)q;

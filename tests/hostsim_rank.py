@@ -91,7 +91,23 @@ def main():
         assert abs(s.residual() - O.residual(V, W)) < 1e-6 * O.residual(V, W)
         K = 4
         _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+        # shard-aware multi-sweep schedule: trace the root set of every first-level scan
+        trace = f"/tmp/ppals_gloo_steps_{os.getpid()}_{case_no}.txt"
+        if os.path.exists(trace):
+            os.remove(trace)
+        os.environ["PPALS_TRACE_STEPS"] = trace
         s.sweeps_dt(K)
+        del os.environ["PPALS_TRACE_STEPS"]
+        steps = [dict(kv.split("=") for kv in ln.split()) for ln in open(trace).read().splitlines()]
+        os.remove(trace)
+        N = len(lens)
+        assert steps, "no first-level scan traced"
+        for st in steps:   # no step contracts the partitioned mode 0 first (its X would be a
+            root, k = int(st["root"]), int(st["k"])   # partial sum of full global size)
+            assert all((root + q) % N != 0 for q in range(k)), st
+        # order 4, one root: 3 scans serve 8 mode updates (runs 3, 3, 2) instead of 8/3
+        if N == 4 and int(steps[0]["k"]) == 1:
+            assert len(steps) == 6 and [int(st["root"]) for st in steps] == [3, 2, 1, 3, 2, 1], steps
         W_got, G_got = s.get_factors(with_grad=True)
         for a, b in zip(W_got, W_ref):
             assert relerr(a, b) < (1e-8 if dtype == 1 else 1e-5), relerr(a, b)
