@@ -52,6 +52,30 @@ def _mem_available_bytes():
     return 0
 
 
+def _usable_cpus():
+    """cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU
+    box exposes all 256 hardware threads to a container that is scheduled on 16 of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(lens, R, budget_s=25.0):
     """the fp64 oracle (the reference's TTM-by-TTM contraction sequence, OpenMP) timed on this
     host's cores ON THE SAME PROBLEM AT FULL SIZE (cfg2: 12.8 GB of fp64 tensor in host memory,
@@ -59,10 +83,7 @@ def cpu_baseline(lens, R, budget_s=25.0):
     is not cfg2-sized) is the mode size reduced and the s^4 scaling law applied; `sample` says which."""
     import numpy as np
     import oracle_lib as O
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
+    ncpu = _usable_cpus()
     s_full = lens[0]
     need = 8.0 * float(np.prod(lens)) * 1.2 + (4 << 30)
     s = s_full if (need < _mem_available_bytes() and np.prod(lens) <= 2e9) else min(s_full, 96)
@@ -71,26 +92,32 @@ def cpu_baseline(lens, R, budget_s=25.0):
     V = O.build_V(Wt)
     W = O.init_factors(small, R, 2000)
     G = O.init_factors(small, R, 3000)
-    # OpenMP team: all the cores this process may use (what `cores` reports); on a reduced problem
-    # also try smaller teams (an oversubscribed team can lose)
-    teams = [ncpu] if s == s_full else sorted({min(ncpu, 16), min(ncpu, 64), ncpu})
+    # OpenMP team size: the fastest of a few candidates on a small instance of the same problem
+    # (what `cores` reports); an oversubscribed team loses badly
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= max(ncpu, 8)})
+    sp = [48] * len(lens)
+    Vp = O.build_V(O.init_factors(sp, R, 1000))
+    Wp, Gp = O.init_factors(sp, R, 2000), O.init_factors(sp, R, 3000)
     best = None
-    for nt in teams:
+    for nt in cands:
         O.lib().ppo_set_num_threads(nt)
-        if s != s_full:
-            O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # warm
+        O.als_cp_dt(Vp, Wp, Gp, tol=0.0, maxiter=0, resprint=10 ** 9)
         t0 = time.time()
-        O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # 1 sweep + 2 print blocks
+        O.als_cp_dt(Vp, Wp, Gp, tol=0.0, maxiter=2, resprint=10 ** 9)
         dt = time.time() - t0
         if best is None or dt < best[0]:
             best = (dt, nt)
-    t_one, nthreads = best
+    nthreads = best[1]
+    del Vp
     O.lib().ppo_set_num_threads(nthreads)
     # the print blocks (untimed in the reference, als_CP.cxx:167,189) are measured and subtracted
     t0 = time.time()
     O.residual(V, W)
     t_print = time.time() - t0
-    k = max(1, min(10, int((budget_s - t_one) / max(t_one - 2 * t_print, 1e-3))))
+    t0 = time.time()
+    O.als_cp_dt(V, W, G, tol=0.0, maxiter=0, resprint=10 ** 9)  # warm-up: 1 sweep + 2 print blocks
+    t_one = max(time.time() - t0 - 2 * t_print, 1e-3)
+    k = max(1, min(10, int((budget_s - 2 * t_print) / t_one)))
     t0 = time.time()
     O.als_cp_dt(V, W, G, tol=0.0, maxiter=k - 1, resprint=10 ** 9)
     t = time.time() - t0

@@ -307,6 +307,8 @@ CpEngine::~CpEngine() {
   for (auto p : Mm_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
   pp_clear();
+  for (auto &kv : pp_pool_) ops_.free(kv.second.buf);
+  ops_.free(pp_norms_);
   ops_.free(G_);
   ops_.free(S_);
   ops_.free(Sinv_);
@@ -501,7 +503,8 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
   double *Gi = G_ + (size_t)i * R_ * R_;
   if (!dist_) {
     ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
-                        pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_);
+                        pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_,
+                        (pp && pp_norms_) ? pp_norms_ + 2 * i : nullptr);
     return;
   } else if (i != 0 && (int64_t)sizeof(double) * s * R_ <= small_msg_bytes_) {
     // latency regime (s x R is a few KB): ONE all-reduce of the partial rows, then every rank runs
@@ -578,7 +581,8 @@ void CpEngine::normalize() {
     visit(ms_X_);
     for (auto &n : ms_nodes_) visit(n.t);
   }
-  ops_.normalize_ms(W_.data(), rows, N_, R_, G_, ms_scales_, masks, active, fresh);
+  ops_.normalize_ms(W_.data(), rows, N_, R_, G_, ms_scales_, masks, active, fresh,
+                    pp_norms_live_ ? pp_norms_ + 1 : nullptr);
 }
 
 // ---------------------------------------------------------------------------- multi-sweep tree
@@ -1091,9 +1095,21 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     op.elems = L * T;
     // (at order 3 a level-1 result already IS a pair operator: those stay fp64 like all the others)
     op.dt = (pp_fast_ && N_ > 3) ? V_.dtype : F64;
-    op.buf = ops_.alloc(dtype_size(op.dt) * (size_t)op.elems * R_);
-    ops_.scan_contract(use_vt ? VT_ : V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf, op.dt,
-                       L, op.elems);
+    if (pp_fast_ && N_ > 3 && schedule_ == 1 && ms_k_ == 1 && ms_root_ == mode && ms_X_.valid &&
+        ms_X_.dt == op.dt) {
+      // The exact sweep that ended just now left its first-level intermediate X = V x_mode W_mode
+      // in the multi-sweep cache, and W_mode has not changed since (a step never updates its own
+      // root; Normalize is the pending scalar): that IS this level-1 operator. One of the three
+      // tensor scans of the build (als_CP.cxx:377-379) is already there.
+      op.buf = ms_X_.buf;
+      op.owned = false;
+      op.scale = ms_scale_of(ms_X_);
+      op.modes = ms_X_.modes;
+    } else {
+      op.buf = pp_buffer(seq, dtype_size(op.dt) * (size_t)op.elems * R_);
+      ops_.scan_contract(use_vt ? VT_ : V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf,
+                         op.dt, L, op.elems);
+    }
   } else {
     const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
     bool before = true;
@@ -1106,8 +1122,8 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
       op.modes.push_back(m);
     }
     op.elems = L * T;
-    op.buf = ops_.alloc(sizeof(double) * (size_t)op.elems * R_);
-    ops_.mttv(par.buf, par.dt, L, ext(mode), T, &f, 1, R_, (double *)op.buf, op.elems, 0, nullptr);
+    op.buf = pp_buffer(seq, sizeof(double) * (size_t)op.elems * R_);
+    ops_.mttv(par.buf, par.dt, L, ext(mode), T, &f, 1, R_, (double *)op.buf, op.elems, 0, par.scale);
   }
   pp_[seq] = op;
   return pp_[seq];
@@ -1120,9 +1136,15 @@ void CpEngine::pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, do
   else  // T[keep, cmode, r]
     ops_.mttv(T.buf, F64, ext(T.modes[0]), ext(cmode), 1, &f, 1, R_, out, out_rows, 1, nullptr);
 }
-void CpEngine::pp_clear() {
-  for (auto &kv : pp_) ops_.free(kv.second.buf);
-  pp_.clear();
+void CpEngine::pp_clear() { pp_.clear(); }  // the buffers stay in the pool
+void *CpEngine::pp_buffer(const std::string &seq, size_t bytes) {
+  PPBuf &b = pp_pool_[seq];
+  if (b.cap < bytes) {
+    ops_.free(b.buf);
+    b.buf = ops_.alloc(bytes);
+    b.cap = bytes;
+  }
+  return b.buf;
 }
 static std::string all_but(int N, int i, int j = -1) {
   std::string s;
@@ -1141,7 +1163,6 @@ void CpEngine::pp_build_all() {
   // level-1 tensors
   for (auto it = pp_.begin(); it != pp_.end();) {
     if ((int)it->first.size() < N_ - 2) {
-      ops_.free(it->second.buf);
       it = pp_.erase(it);
     } else {
       ++it;
@@ -1170,23 +1191,39 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   return n;
 }
 
-// one approximate sweep: als_CP.cxx:754-825
+// one approximate sweep: als_CP.cxx:754-825. Per mode: ONE launch for M = M_i^0 + the N-1
+// first-order corrections, ONE for the whole mode update (which also leaves ||dW_i||^2); the
+// Normalize launch leaves ||W_i||^2: the restart test of the next iteration costs no launch.
 void CpEngine::sweep_pp(double lambda, double ratio) {
   ms_invalidate();  // PP moves the factors without touching the multi-sweep cache
   if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+  if (!pp_norms_) {
+    pp_norms_ = (double *)ops_.alloc(sizeof(double) * 2 * MAX_ORDER);
+    ops_.zero(pp_norms_, sizeof(double) * 2 * MAX_ORDER);
+  }
   for (int i = 0; i < N_; i++) {
     const int64_t si = ext(i);
     const PPOp &M0 = pp_get(all_but(N_, i));
-    ops_.d2d(Mbuf_, M0.buf, sizeof(double) * si * R_);
+    PPTerm terms[MAX_ORDER];
+    int nt = 0;
     for (int ii = 0; ii < N_; ii++) {
       if (ii == i) continue;
       const PPOp &T = pp_get(all_but(N_, std::min(i, ii), std::max(i, ii)));
-      FactorRef f = fref(ii, dW_.data());
-      pp_contract_pair(T, ii, f, Mbuf_, si);  // als_CP.cxx:785 / :793
+      if (T.modes.size() != 2 || T.dt != F64) throw std::runtime_error("ppals: not a pair operator");
+      FactorRef f = fref(ii, dW_.data());  // als_CP.cxx:785 / :793
+      terms[nt].T = (const double *)T.buf;
+      terms[nt].ny = ext(ii);
+      terms[nt].keep_first = T.modes[0] == i ? 1 : 0;
+      terms[nt].dW = f.ptr;
+      terms[nt].lddw = f.ld;
+      nt++;
     }
+    ops_.pp_correct((const double *)M0.buf, si, R_, terms, nt, Mbuf_);
     mode_update(i, Mbuf_, si, lambda, true, ratio);
   }
+  pp_norms_live_ = !dist_;
   normalize();
+  pp_norms_live_ = false;
   grad_from_sweep_ = true;
 }
 
@@ -1311,7 +1348,18 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
   for (; iter <= o.maxiter; iter++) {
     int num_dw_break = 0;
     if (!o.bench) {
-      read_norms(false, nd, nw);
+      if (iter == init_iter || dist_ || !pp_norms_) {
+        read_norms(false, nd, nw);  // dW as the exact phase left it
+      } else {  // left behind by the launches of the previous approximate sweep
+        double h[2 * MAX_ORDER];
+        ops_.d2h(h, pp_norms_, sizeof(double) * 2 * N_);
+        nd.resize(N_);
+        nw.resize(N_);
+        for (int i = 0; i < N_; i++) {
+          nd[i] = std::sqrt(h[2 * i]);
+          nw[i] = std::sqrt(h[2 * i + 1]);
+        }
+      }
       for (int i = 0; i < N_; i++)
         if (std::fabs(nd[i] / nw[i]) > o.tol_init) num_dw_break++;
     }

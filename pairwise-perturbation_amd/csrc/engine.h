@@ -110,7 +110,19 @@ class CpEngine {
     int dt = F64;            // level-1 operators are kept in the tensor's own precision
     int64_t elems = 0;
     std::vector<int> modes;  // remaining modes in STORAGE order (first fastest)
+    bool owned = true;       // false: borrowed from the multi-sweep cache (never freed here)
+    const double *scale = nullptr;  // pending Normalize factor of a borrowed tensor (device scalar)
   };
+  // grow-only pool of the PP operator buffers, by key: a PP phase re-uses the buffers of the
+  // previous one instead of allocating / freeing ~1 GB of operators around every phase
+  struct PPBuf {
+    void *buf = nullptr;
+    size_t cap = 0;
+  };
+  std::map<std::string, PPBuf> pp_pool_;
+  void *pp_buffer(const std::string &seq, size_t bytes);
+  bool pp_norms_live_ = false;  // Normalize is asked for ||W_i||^2 (inside sweep_pp)
+  double *pp_norms_ = nullptr;  // [2N]: ||dW_i||^2, ||W_i||^2 left by the fused PP mode updates
 
   // a cached intermediate of the multi-sweep schedule: modes in storage order (first fastest),
   // rank index last; `scale` (device scalar) is the Normalize factor still owed to its contents

@@ -1,0 +1,374 @@
+// kernels_eig.hip.h — the Tucker eigen-step (K12) on the matrix cores: leading eigenvectors of the
+// s x s Gram of an unfolding (als_Tucker.cxx:399-406, `MTM.svd(U,S,VT,rank)`) WITHOUT a full
+// eigen-decomposition.
+//
+// A full symmetric eigensolver is a chain of thousands of dependent tiny launches on a GPU
+// (rocSOLVER dsyevd at 400 x 400: ~13 000 launches, 9.3 ms — the whole cost of a HOOI sweep of
+// BASELINE config 5). HOOI only needs the invariant subspace of the `rank` largest eigenvalues, and
+// from the second sweep on it knows where the gap below them is. So:
+//   P = (I + sign(G - sigma I)) / 2,  sigma inside the gap below the rank-th eigenvalue,
+// is the orthogonal projector onto that subspace, and sign() is computed with the scaled
+// Newton-Schulz iteration X <- 1/2 mu X (3 I - mu^2 X^2), which is nothing but dense fp64 GEMMs
+// (v_mfma_f64_16x16x4_f64) — ~40 launches of a few microseconds each. trace(P) must come out as
+// `rank`: that check makes the result exact (to the conditioning eps*||G||/gap every solver has) or
+// the call falls back to the full solver. The eigenvectors inside the subspace (the reference
+// returns them one by one, sorted) come from a Rayleigh-Ritz step on a rank x rank matrix.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_small.hip.h"
+
+namespace ppals {
+
+// C[M x N] = alpha * A[M x K] * B[K x N] + beta * D[M x N]   (fp64, column-major, ld = rows)
+// B is handed over as Bt = B^T (N x K, column-major, ldb): element B[k][j] = Bt[j + ldb*k], so the
+// 16 lanes of an MFMA column group read 128 contiguous bytes for both operands. For the symmetric
+// iterates of the sign iteration Bt IS B. The matrices here are a few hundred rows: everything is
+// L2-resident and a launch is pure latency, so ONE 16 x 16 output tile is spread over a whole
+// workgroup — its 4 waves split K, each keeps UN steps (2*UN loads per lane) in flight, and the
+// four partial tiles meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, int64_t lda,
+                                                  const double *__restrict__ Bt, int64_t ldb,
+                                                  const double *__restrict__ D, int64_t ldd,
+                                                  double *__restrict__ C, int64_t ldc, int M, int N,
+                                                  int K, double alpha, double beta) {
+  constexpr int UN = 13;
+  __shared__ double part[3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  // clamped operand rows: lanes past the edge re-read the last row, their results are not stored
+  const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, N - 1);
+  const double *__restrict__ ap = A + ia;
+  const double *__restrict__ bp = Bt + jb;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (K + 3) / 4;
+  const int spw = (ksteps + 3) / 4;
+  const int s_begin = wave * spw, s_end = min(ksteps, s_begin + spw);
+  for (int s0 = s_begin; s0 < s_end; s0 += UN) {
+    double av[UN], bv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int k = (s0 + u) * 4 + g;
+      const bool ok = (s0 + u) < s_end && k < K;  // beyond the range: multiply by zero
+      const int kc = ok ? k : 0;
+      const double a = ap[(int64_t)lda * kc], b = bp[(int64_t)ldb * kc];
+      av[u] = ok ? a : 0.0;
+      bv[u] = ok ? b : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // D-matrix map of the f64 16x16x4 shape: lane holds column j = lane&15, rows (lane>>4) + 4*reg
+  const int j = j0 + l16;
+  if (j < N) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = i0 + g + 4 * r;
+      if (i < M) {
+        double v = alpha * (((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane]);
+        if (D) v += beta * D[i + ldd * (int64_t)j];
+        C[i + ldc * (int64_t)j] = v;
+      }
+    }
+  }
+}
+
+// X = (G - sigma I) / rho   (J x J)
+__global__ void k_shift_scale(const double *__restrict__ G, int64_t J, double sigma, double inv_rho,
+                              double *__restrict__ X) {
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    X[e] = (G[e] - (i == j ? sigma : 0.0)) * inv_rho;
+  }
+}
+
+// X = G - sum_{d < m} (lam[d] - tau) q_d q_d^T - sigma I   (deflation of the dominant eigenpairs:
+// their eigenvalues are moved down to tau, everything else is untouched), partial[blk] = the
+// block's share of ||X||_F^2. Q: J x m column-major.
+__global__ __launch_bounds__(256) void k_deflate_shift(const double *__restrict__ G, int64_t J,
+                                                       const double *__restrict__ Q, int m,
+                                                       const double *__restrict__ lam, double tau,
+                                                       double sigma, double *__restrict__ X,
+                                                       double *__restrict__ partial) {
+  __shared__ double lds[17];
+  double s = 0;
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    double v = G[e] - (i == j ? sigma : 0.0);
+    for (int d = 0; d < m; d++) v -= (lam[d] - tau) * Q[i + J * d] * Q[j + J * d];
+    X[e] = v;
+    s += v * v;
+  }
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void k_scale_inplace(double *__restrict__ X, int64_t n, double f) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    X[e] *= f;
+}
+// X <- (X + X^T) / 2. The sign iteration runs on k_dgemm_nt, which reads its second operand
+// transposed: an antisymmetric rounding residue in X would DOUBLE every iteration there
+// (X Y^T = S - A for X = S + A), so the iterate is kept exactly symmetric.
+__global__ void k_symmetrize(double *__restrict__ X, int64_t J) {
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    if (i < j) {
+      const double v = 0.5 * (X[e] + X[j + J * i]);
+      X[e] = v;
+      X[j + J * i] = v;
+    }
+  }
+}
+
+// *out = || GU - U diag(ev) ||_F^2  (residual of the returned eigenpairs; one block)
+__global__ __launch_bounds__(1024) void k_eig_residual(const double *__restrict__ GU,
+                                                       const double *__restrict__ U,
+                                                       const double *__restrict__ ev, int64_t J,
+                                                       int r, double *__restrict__ out) {
+  __shared__ double lds[17];
+  double s = 0;
+  for (int64_t e = threadIdx.x; e < J * r; e += blockDim.x) {
+    const double d = GU[e] - U[e] * ev[e / J];
+    s += d * d;
+  }
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// partial[blk] = sum over the block's elements of (G - sigma I)^2
+__global__ __launch_bounds__(256) void k_frob_shifted(const double *__restrict__ G, int64_t J,
+                                                      double sigma, double *__restrict__ partial) {
+  __shared__ double lds[17];
+  double s = 0;
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    const double d = G[e] - (i == j ? sigma : 0.0);
+    s += d * d;
+  }
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// partial[2*blk] += ||Y - I||_F^2 share, partial[2*blk+1] = trace(X) share (Y = X^2 of the last
+// iterate); summed by k_sum_pairs
+__global__ __launch_bounds__(256) void k_sign_check(const double *__restrict__ Y,
+                                                    const double *__restrict__ X, int64_t J,
+                                                    double *__restrict__ partial) {
+  __shared__ double lds[17];
+  double e2 = 0, tr = 0;
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    const double d = Y[e] - (i == j ? 1.0 : 0.0);
+    e2 += d * d;
+    if (i == j) tr += X[e];
+  }
+  e2 = block_sum(e2, lds);
+  tr = block_sum(tr, lds);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = e2;
+    partial[2 * blockIdx.x + 1] = tr;
+  }
+}
+__global__ __launch_bounds__(256) void k_sum_pairs(const double *__restrict__ partial, int n,
+                                                   double *__restrict__ out) {
+  __shared__ double lds[17];
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    a += partial[2 * i];
+    b += partial[2 * i + 1];
+  }
+  a = block_sum(a, lds);
+  b = block_sum(b, lds);
+  if (threadIdx.x == 0) {
+    out[0] = a;
+    out[1] = b;
+  }
+}
+
+// One power step on a single vector inside ONE workgroup (the deflation of a dominant eigenpair):
+// y = G q, q_out = y / ||y||, *lam = q^T y (the Rayleigh quotient of the INPUT vector).
+__global__ __launch_bounds__(1024) void k_power_step1(const double *__restrict__ G, int64_t J,
+                                                      const double *__restrict__ q,
+                                                      double *__restrict__ q_out,
+                                                      double *__restrict__ lam) {
+  extern __shared__ double sh[];  // q[J] | y[J] | red[17]
+  double *sq = sh, *sy = sh + J, *red = sy + J;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) sq[i] = q[i];
+  __syncthreads();
+  for (int64_t i = 4 * wave; i < J; i += 4 * nw) {  // G symmetric: row i = column i, contiguous
+    // four rows at a time: 4 independent load / FMA chains per lane
+    const double *c0 = G + J * i, *c1 = G + J * min(i + 1, J - 1), *c2 = G + J * min(i + 2, J - 1),
+                 *c3 = G + J * min(i + 3, J - 1);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t k = lane; k < J; k += 64) {
+      const double qk = sq[k];
+      s0 += c0[k] * qk;
+      s1 += c1[k] * qk;
+      s2 += c2[k] * qk;
+      s3 += c3[k] * qk;
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    if (lane == 0) {
+      sy[i] = s0;
+      if (i + 1 < J) sy[i + 1] = s1;
+      if (i + 2 < J) sy[i + 2] = s2;
+      if (i + 3 < J) sy[i + 3] = s3;
+    }
+  }
+  __syncthreads();
+  double n2 = 0, rq = 0;
+  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) {
+    n2 += sy[i] * sy[i];
+    rq += sy[i] * sq[i];
+  }
+  n2 = block_sum(n2, red);
+  rq = block_sum(rq, red);
+  const double inv = 1.0 / sqrt(n2);
+  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = sy[i] * inv;
+  if (threadIdx.x == 0) *lam = rq;
+}
+
+// C = A^T B for two tall matrices (rows x r, column-major, ld = rows): one wave per entry (p, q)
+__global__ void k_tn_small(const double *__restrict__ A, const double *__restrict__ B, int64_t rows,
+                           int r, double *__restrict__ C) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  for (int e = wid; e < r * r; e += nw) {
+    const int p = e % r, q = e / r;
+    const double *a = A + rows * p, *b = B + rows * q;
+    double s = 0;
+    for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
+    s = wave_sum(s);
+    if (lane == 0) C[p + r * q] = s;
+  }
+}
+
+// T = A^T B, A: rows x ra, B: rows x rb (column-major, ld = rows): one wave per entry
+__global__ void k_tn_rect(const double *__restrict__ A, int ra, const double *__restrict__ B, int rb,
+                          int64_t rows, double *__restrict__ T) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  for (int e = wid; e < ra * rb; e += nw) {
+    const int p = e % ra, q = e / ra;
+    const double *a = A + rows * p, *b = B + rows * q;
+    double s = 0;
+    for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
+    s = wave_sum(s);
+    if (lane == 0) T[p + ra * q] = s;
+  }
+}
+// Z (rows x rz) -= Q (rows x m) * T (m x rz)
+__global__ void k_sub_mult(double *__restrict__ Z, int64_t rows, int rz, const double *__restrict__ Q,
+                           int m, const double *__restrict__ T) {
+  const int64_t total = rows * rz;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % rows;
+    const int c = (int)(e / rows);
+    double acc = 0;
+    for (int d = 0; d < m; d++) acc += Q[i + rows * d] * T[d + m * c];
+    Z[e] -= acc;
+  }
+}
+
+// In place: C (r x r, SPD, column-major) -> Rinv = L^{-T} with C = L L^T, so that Z * Rinv has
+// orthonormal columns when C = Z^T Z (Cholesky QR). One wave, r <= 64, in LDS. *status = 1 when a
+// pivot is not safely positive (Z numerically rank deficient: the caller falls back).
+__global__ __launch_bounds__(64) void k_chol_rinv(double *__restrict__ C, int r,
+                                                  int *__restrict__ status) {
+  extern __shared__ double lds[];
+  double *L = lds;            // r x r, column-major, lower
+  double *X = lds + r * r;    // inverse of L (lower)
+  const int lane = threadIdx.x;
+  for (int e = lane; e < r * r; e += 64) {
+    L[e] = C[e];
+    X[e] = 0.0;
+  }
+  wave_sync();
+  double dmax = 0;
+  for (int k = 0; k < r; k++) dmax = fmax(dmax, L[k + r * k]);
+  bool bad = false;
+  for (int k = 0; k < r; k++) {
+    const double d = L[k + r * k];
+    if (!(d > 1e-12 * dmax)) {
+      bad = true;
+      break;
+    }
+    const double sk = sqrt(d);
+    wave_sync();
+    for (int i = k + lane; i < r; i += 64) L[i + r * k] = (i == k) ? sk : L[i + r * k] / sk;
+    wave_sync();
+    for (int e = lane; e < (r - k - 1) * (r - k - 1); e += 64) {  // trailing update, lower part
+      const int i = k + 1 + e % (r - k - 1), j = k + 1 + e / (r - k - 1);
+      if (i >= j) L[i + r * j] -= L[i + r * k] * L[j + r * k];
+    }
+    wave_sync();
+  }
+  if (lane == 0) *status = bad ? 1 : 0;
+  if (bad) return;
+  // X = L^{-1} by forward substitution, one column per lane
+  for (int c = lane; c < r; c += 64) {
+    for (int i = c; i < r; i++) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; k++) s -= L[i + r * k] * X[k + r * c];
+      X[i + r * c] = s / L[i + r * i];
+    }
+  }
+  wave_sync();
+  for (int e = lane; e < r * r; e += 64) {  // Rinv = X^T (upper triangular)
+    const int i = e % r, j = e / r;
+    C[e] = (i <= j) ? X[j + r * i] : 0.0;
+  }
+}
+
+// out[i, q] = sum_p Z[i, p] * T[p, q]   (rows x r times r x r; out may NOT alias Z)
+__global__ void k_right_mult(const double *__restrict__ Z, int64_t rows, int r,
+                             const double *__restrict__ T, double *__restrict__ out) {
+  extern __shared__ double sT[];
+  for (int e = threadIdx.x; e < r * r; e += blockDim.x) sT[e] = T[e];
+  __syncthreads();
+  const int64_t total = rows * r;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % rows;
+    const int q = (int)(e / rows);
+    double acc = 0;
+    for (int p = 0; p < r; p++) acc += Z[i + rows * p] * sT[p + r * q];
+    out[e] = acc;
+  }
+}
+
+// Z = 0.5 * (Omega + XO)   (projector applied to the previous basis)
+__global__ void k_half_sum(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                           double *__restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = 0.5 * (a[e] + b[e]);
+}
+
+}  // namespace ppals

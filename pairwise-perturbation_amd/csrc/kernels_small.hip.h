@@ -386,6 +386,82 @@ __global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
   }
 }
 
+// PP correction of one mode in ONE launch (K9, als_CP.cxx:778-794):
+//   M[x + rows*r] = M0[x + rows*r] + sum_t sum_y T_t[x,y,r] * dW_t[y + lddw_t*r]
+// block = 64 consecutive x for one r, NW waves. A term whose kept mode is stored fastest is read
+// with lanes along x (each wave takes every NW-th y); a term stored the other way round is read
+// with lanes along y (each wave takes every NW-th x and reduces its row across the lanes). The
+// partial sums meet in LDS and are added in a fixed order.
+struct PPTerms {
+  const double *T[MAX_ORDER];
+  const double *dW[MAX_ORDER];
+  int64_t ny[MAX_ORDER];
+  int64_t lddw[MAX_ORDER];
+  int keep_first[MAX_ORDER];
+  int n;
+};
+// block = 16 consecutive x for one r, 256 threads. Both storage orders are read with 16 lanes along
+// the contiguous index (128-byte segments) and every thread keeps 4 independent partial sums, so a
+// block has ~64 loads per thread in flight instead of a dependent chain: the launch is latency.
+__global__ __launch_bounds__(256) void k_pp_correct(const double *__restrict__ M0, int64_t rows,
+                                                    int R, PPTerms tm, double *__restrict__ M) {
+  __shared__ double part[16][17];
+  __shared__ double rowsum[16];
+  const int t = threadIdx.x;
+  const int lo = t & 15, hi = t >> 4;  // 16 x 16
+  const int64_t x0 = (int64_t)blockIdx.x * 16;
+  const int r = blockIdx.y;
+  double acc = 0.0;   // keep_first terms: this thread's (x = x0 + lo, y = hi, hi + 16, ...) share
+  double racc = 0.0;  // the other terms: row x0 + hi, y = lo, lo + 16, ...
+  for (int tt = 0; tt < tm.n; tt++) {
+    const double *__restrict__ T = tm.T[tt];
+    const double *__restrict__ dw = tm.dW[tt] + tm.lddw[tt] * r;
+    const int64_t ny = tm.ny[tt];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (tm.keep_first[tt]) {
+      const int64_t x = x0 + lo;
+      if (x < rows) {
+        const double *__restrict__ tp = T + x + rows * ny * (int64_t)r;
+        int64_t y = hi;
+        for (; y + 48 < ny; y += 64) {
+          s0 += tp[rows * y] * dw[y];
+          s1 += tp[rows * (y + 16)] * dw[y + 16];
+          s2 += tp[rows * (y + 32)] * dw[y + 32];
+          s3 += tp[rows * (y + 48)] * dw[y + 48];
+        }
+        for (; y < ny; y += 16) s0 += tp[rows * y] * dw[y];
+      }
+      acc += (s0 + s1) + (s2 + s3);
+    } else {
+      const int64_t x = x0 + hi;
+      if (x < rows) {
+        const double *__restrict__ tp = T + ny * (x + rows * (int64_t)r);
+        int64_t y = lo;
+        for (; y + 48 < ny; y += 64) {
+          s0 += tp[y] * dw[y];
+          s1 += tp[y + 16] * dw[y + 16];
+          s2 += tp[y + 32] * dw[y + 32];
+          s3 += tp[y + 48] * dw[y + 48];
+        }
+        for (; y < ny; y += 16) s0 += tp[y] * dw[y];
+      }
+      racc += (s0 + s1) + (s2 + s3);
+    }
+  }
+  // row sums: reduce racc over the 16 lanes that share a row (lanes lo = 0..15 of one hi)
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) racc += __shfl_xor(racc, off, 16);
+  if (lo == 0) rowsum[hi] = racc;
+  part[hi][lo] = acc;
+  __syncthreads();
+  if (t < 16 && x0 + t < rows) {
+    double s = M0[x0 + t + rows * (int64_t)r];
+#pragma unroll
+    for (int h = 0; h < 16; h++) s += part[h][t];
+    M[x0 + t + rows * (int64_t)r] = s + rowsum[t];
+  }
+}
+
 // *dst *= prod_{m in mask} scales[m]  (pending Normalize factor of a cached tensor); set_one: 1.0
 struct ScaleMasks {
   unsigned m[32];
@@ -813,7 +889,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     int64_t ldm, double *W, int64_t ldw, double *__restrict__ grad, int64_t ldg, int64_t rows,
     double *__restrict__ gradsq, const double *__restrict__ Winit, int64_t ldi,
     double *__restrict__ dW, int64_t ldd, double ratio, double *__restrict__ S_out,
-    double *__restrict__ Sinv_out) {
+    double *__restrict__ Sinv_out, double *__restrict__ dwsq) {
   extern __shared__ double lds[];
   const int ldA = R + 1;
   double *red = lds;
@@ -873,6 +949,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   }
   gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
   if (tid == 0) *gradsq = gs;
+  double dd = 0;
   for (int64_t e = tid; e < total; e += blockDim.x) {
     const int64_t i = e % rows;
     const int j = (int)(e / rows);
@@ -886,10 +963,15 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       const double wi = Winit[i + ldi * j];
       const double d = ratio * (acc - wi);
       dW[i + ldd * j] = d;
+      dd += d * d;
       if (ratio != 1.0) acc = wi + d;
     }
     W[i + ldw * j] = acc;
     if (STAGE) sW[e] = acc;  // old W is dead since the block_sum barrier
+  }
+  if (dwsq) {  // ||dW||^2 for the restart test of the PP phase (block-uniform branch)
+    dd = block_sum(dd, red);
+    if (tid == 0) *dwsq = dd;
   }
   __syncthreads();  // W_new visible to the whole workgroup (LDS, or same CU's L1)
   // G_mode = W^T W: one wave per (p <= q) pair
@@ -960,7 +1042,7 @@ __global__ __launch_bounds__(1024) void k_normalize_fused(double *__restrict__ G
                                                           PtrsN w, double *__restrict__ scales,
                                                           double *__restrict__ ms_dst,
                                                           ScaleMasks masks, unsigned active,
-                                                          unsigned fresh) {
+                                                          unsigned fresh, double *__restrict__ wsq) {
   __shared__ double nrm[MAX_ORDER], fs[MAX_ORDER];
   const int tid = threadIdx.x;
   if (tid < N) {
@@ -976,6 +1058,7 @@ __global__ __launch_bounds__(1024) void k_normalize_fused(double *__restrict__ G
     for (int i = 0; i < N; i++) {
       fs[i] = c / nrm[i];
       scales[i] = fs[i];
+      if (wsq) wsq[2 * i] = (nrm[i] * fs[i]) * (nrm[i] * fs[i]);  // ||W_i||^2 after the rescaling
     }
   }
   __syncthreads();
@@ -1106,7 +1189,8 @@ __global__ __launch_bounds__(256) void k_unfold_gram(const TV *__restrict__ X, i
 // eigenvalues ranked descending. Used for the Tucker eigen-step whenever the mode extent is small
 // (no vendor library involved). dynamic LDS: A[J][J+1] | Q[J][J+1] | cs[64] | pq[64 ints] | red[17]
 __global__ __launch_bounds__(256) void k_top_eig_small(const double *__restrict__ G, int J,
-                                                       int rank, double *__restrict__ U) {
+                                                       int rank, double *__restrict__ U,
+                                                       double *__restrict__ evals) {
   extern __shared__ double lds[];
   const int ldA = J + 1;
   double *A = lds;
@@ -1125,8 +1209,10 @@ __global__ __launch_bounds__(256) void k_top_eig_small(const double *__restrict_
       const double wj = A[j * ldA + j];
       if (wj > wk || (wj == wk && j < k)) pos++;
     }
-    if (pos < rank)
+    if (pos < rank) {
       for (int i = 0; i < J; i++) U[i + (int64_t)J * pos] = Q[i * ldA + k];
+      if (evals) evals[pos] = wk;  // descending
+    }
   }
 }
 

@@ -24,6 +24,16 @@ struct FactorRef {
   int64_t ld;
 };
 
+// one first-order correction term of a PP mode update (als_CP.cxx:778-794): a pair operator
+// T (two modes + the rank index, fp64) contracted over its mode of extent ny with dW (ny x R, lddw)
+struct PPTerm {
+  const double *T;
+  int64_t ny;
+  int keep_first;  // 1: T[x + rows*(y + ny*r)] (the kept mode is stored fastest), 0: T[y + ny*(x + rows*r)]
+  const double *dW;
+  int64_t lddw;
+};
+
 struct ProfileSlot {
   int64_t launches = 0;
   double ms = 0;
@@ -120,6 +130,23 @@ class Ops {
   virtual void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
                     int nf, int R, double *out, int64_t out_rstride, int accumulate,
                     const double *out_scale) = 0;
+  // PP correction of one mode in one call (K9, als_CP.cxx:754-794):
+  //   M[x + rows*r] = M0[x + rows*r] + sum_t sum_y T_t[x,y,r] * dW_t[y + lddw_t*r]
+  // (fixed summation order: results are reproducible run to run)
+  virtual void pp_correct(const double *M0, int64_t rows, int R, const PPTerm *terms, int nterms,
+                          double *M) {
+    d2d(M, M0, sizeof(double) * rows * R);
+    for (int t = 0; t < nterms; t++) {
+      FactorRef f;
+      f.ptr = terms[t].dW;
+      f.rows = terms[t].ny;
+      f.ld = terms[t].lddw;
+      if (terms[t].keep_first)
+        mttv(terms[t].T, F64, rows, terms[t].ny, 1, &f, 1, R, M, rows, 1, nullptr);
+      else
+        mttv(terms[t].T, F64, 1, terms[t].ny, rows, &f, 1, R, M, rows, 1, nullptr);
+    }
+  }
   // pending-Normalize bookkeeping of cached tensors: *dst = (set_one ? 1 : *dst) * prod_{m in
   // mask} scales[m]; `scales` is what normalize() last applied (see normalize_scales()).
   virtual void scale_update(double *dst, const double *scales, unsigned mask, int set_one) = 0;
@@ -132,11 +159,14 @@ class Ops {
   }
   // Normalize + the pending-scale update of the cached multi-sweep tensors (active == 0: none);
   // back ends may fold both into one launch
+  // wsq (device array, stride 2, may be null): wsq[2i] = ||W_i||_F^2 after the rescaling
   virtual void normalize_ms(double *const *W, const int64_t *rows, int N, int R, double *Gall,
-                            double *ms_dst, const unsigned *masks, unsigned active,
-                            unsigned fresh) {
+                            double *ms_dst, const unsigned *masks, unsigned active, unsigned fresh,
+                            double *wsq = nullptr) {
     normalize(W, rows, N, R, Gall);
     if (active) scale_update_many(ms_dst, normalize_scales(), masks, active, fresh);
+    if (wsq)
+      for (int i = 0; i < N; i++) sumsq(W[i], rows[i] * R, wsq + 2 * i);
   }
   virtual const double *normalize_scales() = 0;  // device array [N] written by normalize()
 
@@ -157,14 +187,18 @@ class Ops {
                          double ratio) = 0;
   // one whole single-rank mode update: gram_system + cp_update (W updated in place) + gram of the
   // new W into Gall[mode]. Backends may fuse it into one launch; S/Sinv may be nullptr.
+  // dwsq (device scalar, may be null; needs Winit and ldd == rows): *dwsq = ||dW||_F^2 afterwards
+  // (the restart test of the PP phase, als_CP.cxx:657-663, without a launch of its own).
   virtual void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
                               int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg,
                               int64_t rows, double *gradsq, const double *Winit, int64_t ldi,
-                              double *dW, int64_t ldd, double ratio, double *S, double *Sinv) {
+                              double *dW, int64_t ldd, double ratio, double *S, double *Sinv,
+                              double *dwsq = nullptr) {
     gram_system(Gall, N, mode, R, lambda, S, Sinv);
     cp_update(M, ldm, W, ldw, W, ldw, grad, ldg, rows, R, S, Sinv, gradsq, Winit, ldi, dW, ldd,
               ratio);
     gram(W, rows, ldw, R, Gall + (size_t)mode * R * R);
+    if (dwsq && Winit) sumsq(dW, rows * R, dwsq);
   }
   // Normalize (common.cxx:680-688) on N full factors using ||W_i||^2 = trace(G_i); rescales the
   // Grams consistently.
@@ -185,6 +219,13 @@ class Ops {
   virtual void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) = 0;
   // U (J x rank, column-major) = leading eigenvectors of symmetric PSD G (J x J), descending
   virtual void top_eigvecs(double *G, int64_t J, int rank, double *U) = 0;
+  // the same inside a HOOI iteration: `slot` names a sequence of calls on slowly changing matrices
+  // (one per mode), so a back end may keep what it learnt from the previous call of the slot —
+  // where the gap below the rank-th eigenvalue lies, the previous basis — and skip the full
+  // eigen-decomposition. The result is the same invariant subspace, eigenvectors sorted descending.
+  virtual void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int /*slot*/) {
+    top_eigvecs(G, J, rank, U);
+  }
   virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
   virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
   // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)

@@ -413,7 +413,7 @@ void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
     double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
     ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);                   // K12
-    ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
+    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], i);
     if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
   }
   // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408)
@@ -627,7 +627,7 @@ void TuckerEngine::sweep_pp() {
     }
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
     ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);
-    ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
+    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], i);
     ops_.sign_align(W_[i], Winit_[i], V_.glens[i], r_[i]);  // als_Tucker.cxx:874-885
     double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
     int64_t n[1] = {V_.glens[i] * r_[i]};

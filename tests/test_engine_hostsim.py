@@ -47,5 +47,6 @@ test_ttmc_matches_oracle = GT.test_ttmc_matches_oracle
 test_hosvd_and_dt_sweeps = GT.test_hosvd_and_dt_sweeps
 test_tucker_pp_driver_matches_oracle = GT.test_tucker_pp_driver_matches_oracle
 test_tucker_bench_mode_matches_oracle = GT.test_tucker_bench_mode_matches_oracle
+test_eigen_step_projector_route_matches_oracle = GT.test_eigen_step_projector_route_matches_oracle
 test_tensor_p_laplacian = G.test_tensor_p_laplacian
 test_tensor_c_collinear = G.test_tensor_c_collinear

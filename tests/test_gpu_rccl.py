@@ -43,4 +43,4 @@ def test_bench_under_torchrun_one_rank():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["launches"] > 0
-    assert out["config"].get("comm") == "rccl"
+    assert out["config"].get("comm", "").startswith("rccl")

@@ -160,3 +160,65 @@ def test_tucker_bench_mode_matches_oracle(pp, ctx, maxiter, resprint, tmp_path):
         assert abs(np.linalg.norm(core_got) - np.linalg.norm(core_ref)) < 1e-8 * np.linalg.norm(core_ref)
     s.close()
     t.close()
+
+
+def _decaying_tensor(lens, inner, seed, noise):
+    """a tensor of multilinear rank `inner` with a decaying core plus relative noise: the spectra
+    of its unfolding Grams have a clear gap below every requested rank <= inner"""
+    rng = np.random.default_rng(seed)
+    U = [np.linalg.qr(rng.standard_normal((s, r)))[0] for s, r in zip(lens, inner)]
+    core = rng.standard_normal(inner)
+    for m, r in enumerate(inner):   # decay along every mode
+        shape = [1] * len(inner)
+        shape[m] = r
+        core = core * (0.7 ** np.arange(r)).reshape(shape)
+    V = core
+    for m, u in enumerate(U):
+        V = np.moveaxis(np.tensordot(u, V, axes=(1, m)), 0, m)
+    E = rng.standard_normal(lens)
+    return np.asfortranarray(V + noise * np.linalg.norm(V) / np.linalg.norm(E) * E)
+
+
+@pytest.mark.parametrize("lens,ranks", [([96, 80, 72], [5, 6, 4]), ([130, 70, 66], [8, 3, 5])])
+def test_eigen_step_projector_route_matches_oracle(pp, ctx, lens, ranks, tmp_path, monkeypatch):
+    """mode extents above 64: from the second HOOI sweep on, the eigen-step is the spectral
+    projector by Newton-Schulz sign iteration on the matrix cores (kernels_eig.hip.h), checked by
+    trace(P) == rank, with the full solver as the first call and as fallback. Same iterates as the
+    oracle's full eigen-decomposition: projectors, ||core||, CSV rows of alsTucker_DT; and the same
+    as the engine with the route switched off (PPALS_EIG_FAST=0, fresh context)."""
+    V = _decaying_tensor(lens, [10, 9, 8], 5, 0.05)
+    W0, c0 = O.hosvd(V, ranks)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=6, csv=c_ref, resprint=1)
+    results = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("PPALS_EIG_FAST", fast)
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, 1).upload(V)
+        s = pp.Tucker(c2, t, ranks)
+        s.hosvd()
+        W_h, _ = s.get_factors()
+        for a, b in zip(W_h, W0):
+            assert relerr(proj(a), proj(b)) < 1e-8
+        s.set_factors(W0)
+        s.set_core(c0)
+        rc, it = s.run_dt(tol=0.0, maxiter=6, csv=c_got, resprint=1)
+        assert it == it_ref
+        W, core = s.get_factors()
+        for a, b, r in zip(W, W_ref, ranks):
+            assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+            assert relerr(proj(a), proj(b)) < 1e-7, (fast, relerr(proj(a), proj(b)))
+        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+        _, r1 = O.read_csv(c_ref)
+        _, r2 = O.read_csv(c_got)
+        assert len(r1) == len(r2)
+        for a, b in zip(r1, r2):
+            assert a[1] == b[1] and abs(a[5] - b[5]) < 1e-8 * np.linalg.norm(V)
+        results.append(W)
+        s.close()
+        t.close()
+        c2.close()
+    # eigenvectors one by one (sorted, up to sign): the two routes agree column by column
+    for a, b in zip(*results):
+        for k in range(a.shape[1]):
+            assert min(np.linalg.norm(a[:, k] - b[:, k]), np.linalg.norm(a[:, k] + b[:, k])) < 1e-6
