@@ -83,6 +83,8 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
     if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
+    if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
+    if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_power_step1,
@@ -184,9 +186,53 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
 
+  // K10 on the matrix cores (kernels_scan.hip.h: k_rank_mfma); false: shape not covered
+  template <typename TV, int MODE>
+  bool rank_mfma(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
+                 double *out) {
+    constexpr int VEC = ScanTraits<TV>::VEC;
+    if (!rank_mfma_ || R > 32 || M % VEC != 0 || M < VEC || (((uintptr_t)V) & 15) != 0 || K < 1)
+      return false;
+    const int RB = MODE == 2 ? 1 : (R + 3) / 4;
+    const int64_t nkb64 = (K + 15) / 16;
+    if (nkb64 > 0x7fffffff) return false;
+    const int nkb = (int)nkb64;
+    double *Ppk = nullptr;
+    if (MODE != 2) {
+      Ppk = (double *)ensure(ws_pack_, ws_pack_sz_, sizeof(double) * (size_t)nkb * RB * 64);
+      hipLaunchKernelGGL(k_rank_pack, dim3(grid_for((int64_t)nkb * RB * 64, 256)), dim3(256), 0, st_,
+                         P, K, R, RB, nkb, Ppk);
+    }
+    const int64_t n_mtiles = (M + 64 * VEC - 1) / (64 * VEC);
+    // enough workgroups to fill the chip several times, chunks of >= 8 column blocks
+    int nchunk = (int)std::min<int64_t>(nkb, std::max<int64_t>(1, ((int64_t)ncu_ * 16 + n_mtiles - 1) / n_mtiles));
+    int per = (nkb + nchunk - 1) / nchunk;
+    per = std::max(per, std::min(nkb, 8));
+    nchunk = (nkb + per - 1) / per;
+    if (n_mtiles > 0x7fffffff || nchunk > 65535) return false;
+    dim3 grid((unsigned)n_mtiles, (unsigned)nchunk);
+    double *part = nullptr;
+    const int64_t npart = (int64_t)n_mtiles * nchunk;
+    if (MODE != 0) part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
+    prof_begin(1, (double)M * K * sizeof(TV));
+    if (RB <= 4)
+      hipLaunchKernelGGL((k_rank_mfma<TV, MODE, 4>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
+                         RB, per, nkb, part);
+    else
+      hipLaunchKernelGGL((k_rank_mfma<TV, MODE, 8>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
+                         RB, per, nkb, part);
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+    if (MODE != 0) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, (int)npart, out);
+      HIP_CHECK(hipGetLastError());
+    }
+    return true;
+  }
   template <typename TV, int MODE>
   void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                    double *out) {
+    if (rank_mfma<TV, MODE>(V, M, K, Q, P, R, out)) return;
     int kch = 32;
     while ((K + kch - 1) / kch > 65535) kch *= 2;
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((K + kch - 1) / kch));
@@ -582,6 +628,24 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_gram_system_big, dim3(1), dim3(1024), 0, st_, Gall, N, mode, R, lambda, S,
                          Sinv, work, status);
       HIP_CHECK(hipGetLastError());
+      // a non-positive pivot (S not positive definite: a rank above a mode extent, collinear
+      // columns) leaves NaNs in Sinv: take the reference's route instead, the untruncated inverse
+      // through a full eigen-decomposition (vendor solver; this unfused path is not a fast path)
+      int bad = 0;
+      HIP_CHECK(hipMemcpyAsync(&bad, status, sizeof(int), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      if (bad || force_eiginv_) {
+        RocSolver &rs = rocsolver();
+        double *D = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * (2 * (size_t)R + 2));
+        double *E = D + R;
+        int *info = (int *)(E + R);
+        HIP_CHECK(hipMemcpyAsync(work, S, sizeof(double) * (size_t)R * R, hipMemcpyDeviceToDevice, st_));
+        if (rs.dsyevd(rs.handle, 211 /*evect_original*/, 121 /*fill_upper*/, R, work, R, D, E, info) != 0)
+          throw std::runtime_error("ppals: rocsolver_dsyevd failed (R x R normal equations)");
+        hipLaunchKernelGGL(k_eig_inverse, dim3(grid_for((int64_t)R * R, 256)), dim3(256), 0, st_, work,
+                           D, R, Sinv);
+        HIP_CHECK(hipGetLastError());
+      }
       return;
     }
     size_t lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
@@ -1132,6 +1196,8 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
+  int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)
   EigState eig_state_[16];
   void *ws_eig_ = nullptr;

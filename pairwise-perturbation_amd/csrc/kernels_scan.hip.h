@@ -1005,6 +1005,146 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rank-structured stream (K10, build_V / [diffV]): one pass over V[m,k] against the model
+// vhat[m,k] = sum_r Q[m,r] P[k,r] (Q, P = Khatri-Rao products of the two halves of the factors,
+// fp64), nothing materialised:
+//   MODE 0  V = vhat                      (build_V, common.cxx:135-197)
+//   MODE 1  partial[wg] = sum (V - vhat)^2   (als_CP.cxx:183-187)
+//   MODE 2  partial[wg] = sum V^2
+// The model tile comes off the matrix cores in fp64 (v_mfma_f64_16x16x4_f64, contraction over r):
+// fp32 products would carry ~1e-7 of |vhat| and drown a converged residual (~3e-8 of |V| with fp32
+// tensor storage). Tiling = the suffix scan's: a workgroup covers 256 consecutive rows (1 KiB of
+// every column), a lane owns VEC consecutive rows and the columns k = 16*kb + 4*u + g of a block:
+//   A[i = lane&15][kk = lane>>4] = P[16*kb + i, 4*rb + kk]   (packed: one 8-byte load per lane)
+//   B[kk = lane>>4][j = lane&15] = Q[m0 + VEC*j + jj, 4*rb + kk]   (tile-invariant registers)
+//   D[i = (lane>>4) + 4*reg][j]  -> the lane's element (row VEC*j + jj, column 16*kb + 4*reg + g)
+// which is exactly where its 16-byte tensor loads put V. 2*ceil(R/4)*4 flops per element at the
+// fp64 matrix rate keep the pipe ~40 % busy at HBM speed. Needs M % VEC == 0, R <= 32.
+template <typename TV, int MODE, int MAXRB>
+__global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M, int64_t K,
+                                                   const double *__restrict__ Q,
+                                                   const double *__restrict__ Ppk, int R, int RB,
+                                                   int kb_per_chunk, int nkb,
+                                                   double *__restrict__ partial) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  constexpr int VEC = TR::VEC;  // MAXRB: 4-wide contraction steps held in registers (R <= 4*MAXRB)
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * VEC);
+  const bool live = m0 < M;  // wave-uniform
+  const int64_t m = m0 + (int64_t)VEC * j16;
+  const bool row_ok = live && m < M;
+  const int64_t m_ld = live ? min(m, M - VEC) : 0;
+  const int kb0 = blockIdx.y * kb_per_chunk, kb1 = min(nkb, kb0 + kb_per_chunk);
+  double bq[VEC][MAXRB];
+  if constexpr (MODE != 2) {
+#pragma unroll
+    for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+      for (int rb = 0; rb < MAXRB; rb++) {
+        const int r = 4 * rb + g;
+        bq[jj][rb] = (rb < RB && r < R && live) ? Q[m_ld + jj + M * (int64_t)r] : 0.0;
+      }
+  }
+  double acc = 0.0;
+  TV *__restrict__ vp = V + m_ld;
+  // register double buffer: the tensor columns and the packed P values of block kb+1 are
+  // requested before block kb is multiplied (the last block is simply requested twice)
+  vec cv[4];
+  double ca[MAXRB];
+#define PPALS_RANK_LOAD(kb_, vv_, aa_)                                                        \
+  {                                                                                           \
+    if constexpr (MODE != 0) {                                                                \
+      _Pragma("unroll") for (int u = 0; u < 4; u++) {                                         \
+        const int64_t k_ = min((int64_t)(kb_)*16 + 4 * u + g, K - 1);                         \
+        vv_[u] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(vp + k_ * M));      \
+      }                                                                                       \
+    }                                                                                         \
+    if constexpr (MODE != 2) {                                                                \
+      _Pragma("unroll") for (int rb = 0; rb < MAXRB; rb++) if (rb < RB) aa_[rb] =             \
+          Ppk[(((int64_t)(kb_)*RB + rb) * 4 + g) * 16 + j16];                                 \
+    }                                                                                         \
+  }
+  if (live && kb0 < kb1) PPALS_RANK_LOAD(kb0, cv, ca);
+  for (int kb = kb0; kb < kb1 && live; kb++) {
+    vec nv[4];
+    double na[MAXRB];
+    const int kn = min(kb + 1, kb1 - 1);
+    PPALS_RANK_LOAD(kn, nv, na);
+    f64x4 d[VEC];
+    if constexpr (MODE != 2) {
+#pragma unroll
+      for (int jj = 0; jj < VEC; jj++) d[jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int rb = 0; rb < MAXRB; rb++) {
+        if (rb < RB) {
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++)
+            d[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[rb], bq[jj][rb], d[jj], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t k = (int64_t)kb * 16 + 4 * u + g;
+      const bool ok = k < K && row_ok;  // beyond K the loads were clamped: excluded here
+      if constexpr (MODE == 0) {
+        if (ok) {
+          vec o;
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) o[jj] = (TV)d[jj][u];
+          *reinterpret_cast<vec *>(V + m + k * M) = o;
+        }
+      } else {
+        double e2 = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++) {
+          double e = (double)cv[u][jj];
+          if constexpr (MODE == 1) e -= d[jj][u];
+          e2 += e * e;
+        }
+        acc += ok ? e2 : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) cv[u] = nv[u];
+#pragma unroll
+    for (int rb = 0; rb < MAXRB; rb++) ca[rb] = na[rb];
+  }
+#undef PPALS_RANK_LOAD
+  if constexpr (MODE != 0) {
+    acc = [&]() {
+      double v = acc;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      return v;
+    }();
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// Ppk[((kb*RB + rb)*4 + g)*16 + i] = P[16*kb + i, 4*rb + g]  (zero beyond K / R)
+__global__ void k_rank_pack(const double *__restrict__ P, int64_t K, int R, int RB, int nkb,
+                            double *__restrict__ Ppk) {
+  const int64_t total = (int64_t)nkb * RB * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e & 15), g = (int)((e >> 4) & 3);
+    const int64_t t = e >> 6;
+    const int rb = (int)(t % RB);
+    const int64_t kb = t / RB;
+    const int64_t k = kb * 16 + i;
+    const int r = 4 * rb + g;
+    Ppk[e] = (k < K && r < R) ? P[k + K * (int64_t)r] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Khatri-Rao operand packing (layouts described at the top of this file).
 struct KrpArgs {
   const double *ptr[MAX_ORDER];

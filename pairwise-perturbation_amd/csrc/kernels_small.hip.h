@@ -794,6 +794,18 @@ __global__ __launch_bounds__(1024) void k_gram_system_big(const double *__restri
     for (int e = tid; e < R * R; e += blockDim.x) Sinv[e] = __longlong_as_double(0x7ff8000000000000LL);
   }
 }
+// Sinv = Z diag(1/w) Z^T from the eigen-decomposition S = Z diag(w) Z^T (Z column-major, w any
+// order): for symmetric S this IS the reference's untruncated V diag(1/sigma) U^T
+// (common.cxx:717-722) — the defined answer when S is not positive definite
+__global__ void k_eig_inverse(const double *__restrict__ Z, const double *__restrict__ w, int R,
+                              double *__restrict__ Sinv) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < R * R; e += gridDim.x * blockDim.x) {
+    const int i = e % R, j = e / R;
+    double acc = 0;
+    for (int k = 0; k < R; k++) acc += Z[i + (int64_t)R * k] * (1.0 / w[k]) * Z[j + (int64_t)R * k];
+    Sinv[e] = acc;
+  }
+}
 // row-parallel mode update for any R: grad = -M + W_old S, W = M S^-1 (optional SVD_solve_mod
 // tail), per-block partial ||grad||^2. One block per 64 rows; a thread owns (row, column j).
 // Wnew must not alias Wold here (several blocks): the caller passes a scratch copy of W_old.

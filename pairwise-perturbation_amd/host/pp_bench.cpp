@@ -10,7 +10,7 @@ int main(int argc, char **argv) {
   double start_time = wtime();
   if (a.rank == 0) echo_args(a, false);
   if (a.resprint == 0) a.resprint = 1;
-  if (a.model[0] == 'T') CHECK(ppals_preload_eigensolver());  // before the GPU is touched
+  if (a.model[0] == 'T' || a.R > 64) CHECK(ppals_preload_eigensolver());  // before the GPU is touched
   ppals_ctx *ctx = nullptr;
   ppals_tensor *V = nullptr;
   std::vector<int64_t> lens;

@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
   if (a.rank == 0) echo_args(a, true);
   if (a.resprint == 0) a.resprint = 10;
   // Tucker's eigen-step may need the vendor eigensolver: cheap to load only before the GPU is touched
-  if (a.model[0] == 'T') CHECK(ppals_preload_eigensolver());
+  if (a.model[0] == 'T' || a.R > 64) CHECK(ppals_preload_eigensolver());
 
   ppals_ctx *ctx = nullptr;
   ppals_tensor *V = nullptr;

@@ -40,6 +40,7 @@ test_class_api_reference_test_case = G.test_class_api_reference_test_case
 test_tensor_refill_while_session_alive = G.test_tensor_refill_while_session_alive
 test_bench_mode_matches_oracle = G.test_bench_mode_matches_oracle
 test_long_run_factor_parity = G.test_long_run_factor_parity
+test_rank_stream_on_matrix_cores = G.test_rank_stream_on_matrix_cores
 
 import test_gpu_tucker as GT  # noqa: E402
 

@@ -695,3 +695,72 @@ def test_long_run_factor_parity(pp, ctx, lens, R, dtype):
     assert abs(O.residual(V, s.get_factors()) - r_ref) < (1e-5 if dtype == 0 else 1e-9) * np.linalg.norm(V)
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", [([8, 8, 8, 8], 3), ([12, 6, 7, 5], 10), ([20, 14, 9, 11], 20),
+                                    ([4, 9, 3, 7], 32), ([68, 4, 5, 3], 1), ([16, 18, 50], 7),
+                                    ([6, 10, 4, 3, 5, 2], 5)])
+def test_rank_stream_on_matrix_cores(pp, ctx, lens, R, dtype):
+    """K10 (build_V and the streaming residual / norm) through the fp64-MFMA kernel: row counts
+    that are / are not multiples of a workgroup's 256 rows, column counts with a partial last
+    16-block, ranks on both sides of a 4-wide contraction step, both storage types — tensor
+    generation, ||V||, ||V - [[W]]|| far from and AT the solution against the oracle"""
+    Wt = O.init_factors(lens, R, 41)
+    V = O.build_V(Wt)
+    Vn = np.linalg.norm(V)
+    t = pp.Tensor(ctx, lens, dtype).fill_cp(Wt)
+    eps = 1e-6 if dtype == 0 else 1e-13
+    assert relerr(t.download(), V) < eps
+    assert abs(t.norm() - Vn) < eps * Vn
+    s = pp.CP(ctx, t, R)
+    W = O.init_factors(lens, R, 42)
+    s.set_factors(W)
+    assert abs(s.residual() - O.residual(V, W)) < 10 * eps * O.residual(V, W)
+    s.set_factors(Wt)    # at the solution: only the storage rounding of V is left
+    assert s.residual() < (2e-7 if dtype == 0 else 1e-13) * Vn
+    s.close()
+    t.close()
+
+
+def test_rank_above_64_non_spd_fallback(pp, monkeypatch):
+    """R > 64 (the reference CLI's default is R = s/2): S^-1 by pivot-free Gauss-Jordan sweeps, and
+    when a pivot is not positive the untruncated inverse through a full eigen-decomposition (the
+    reference's SVD_solve, common.cxx:710-725) instead of NaNs. (1) the eigen route, forced on an
+    SPD problem, reproduces the sweep route; (2) a rank-deficient problem (R above three of the
+    four mode extents, R = s/2 of the long one) ends without a NaN and fits as well as the oracle."""
+    lens, R = [90, 85, 82], 80
+    V = O.build_V(O.init_factors(lens, 12, 1))
+    W, G = O.init_factors(lens, R, 2), O.init_factors(lens, R, 3)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("PPALS_FORCE_EIGINV", force)
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, 1).upload(V)
+        s = pp.CP(c2, t, R)
+        s.set_factors(W, G)
+        S, Si = s.gram_system(1, 0.0)
+        assert np.all(np.isfinite(Si))
+        assert relerr(Si @ S, np.eye(R)) < 1e-6 * np.linalg.cond(S)
+        outs.append(Si)
+        s.close()
+        t.close()
+        c2.close()
+    assert relerr(outs[1], outs[0]) < 1e-7 * np.linalg.cond(S)
+    monkeypatch.setenv("PPALS_FORCE_EIGINV", "0")
+    lens, R = [140, 9, 8, 7], 70
+    V = O.fill_uniform(int(np.prod(lens)), 5, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W, G = O.init_factors(lens, R, 2), O.init_factors(lens, R, 3)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.CP(c2, t, R)
+    s.set_factors(W, G)
+    s.sweeps_dt(2)
+    W_got = s.get_factors()
+    assert all(np.all(np.isfinite(w)) for w in W_got)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G, tol=0.0, maxiter=1, resprint=1000)
+    r_got, r_ref = O.residual(V, W_got), O.residual(V, W_ref)
+    assert r_got < 1.05 * r_ref + 1e-6 * np.linalg.norm(V), (r_got, r_ref)
+    s.close()
+    t.close()
+    c2.close()
