@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "hip_ops.h"
+#include "roctx_ranges.h"
 #include "kernels_scan.hip.h"
 #include "kernels_small.hip.h"
 #include "kernels_eig.hip.h"
@@ -267,6 +268,7 @@ class HipOps : public Ops {
   }
   void residual_sq(const void *V, int dt, int64_t M, int64_t K, const double *Q, const double *P,
                    int R, double *out) override {
+    RoctxRange roctx_("K10 residual / norm stream");
     void *v = const_cast<void *>(V);
     if (Q == nullptr) {
       if (dt == F32)
@@ -538,6 +540,7 @@ class HipOps : public Ops {
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
                      int nf, int R, void *out, int out_dt, int64_t out_tstride,
                      int64_t out_rstride) override {
+    RoctxRange roctx_("K1/K2/K8/K11 tensor scan");
     const int out32 = out_dt == F32 ? 1 : 0;
     if (dt == F32)
       scan_t<float>((const float *)V, L, J, T, f, nf, R, (double *)out, out_tstride, out_rstride,
@@ -554,7 +557,7 @@ class HipOps : public Ops {
     constexpr int VL = 16 / sizeof(TX);
     prof_begin(1, (double)L * J * T * R * sizeof(TX));
     if (L == 1) {
-      int64_t nw = T * R;
+      int64_t nw = ((T + 3) / 4) * R;
       int g = grid_for(nw * 64, 256, 16384);
       hipLaunchKernelGGL(k_mttv_1<TX>, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out, rs,
                          accumulate, scale);
@@ -581,6 +584,7 @@ class HipOps : public Ops {
   void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
             int R, double *out, int64_t out_rstride, int accumulate,
             const double *out_scale) override {
+    RoctxRange roctx_("K3/K9 mttv (cached intermediate)");
     const double *B;
     int64_t ldb;
     if (nf == 1) {
@@ -615,6 +619,7 @@ class HipOps : public Ops {
 
   // ------------------------------------------------------------------ R x R side
   void gram(const double *W, int64_t rows, int64_t ld, int R, double *G) override {
+    RoctxRange roctx_("K4 gram");
     int npairs = R * (R + 1) / 2;
     int g = std::min(64, (npairs + 15) / 16);
     hipLaunchKernelGGL(k_gram, dim3(g), dim3(1024), 0, st_, W, rows, ld, R, G);
@@ -657,6 +662,7 @@ class HipOps : public Ops {
                       int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
                       double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,
                       double ratio, double *S, double *Sinv, double *dwsq) override {
+    RoctxRange roctx_("K4-K6 mode update");
     if (R > 64) {  // unfused route: S / S^-1, row-parallel update, Gram refresh
       Ops::cp_mode_update(Gall, N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit,
                           ldi, dW, ldd, ratio, S, Sinv, dwsq);
@@ -683,6 +689,7 @@ class HipOps : public Ops {
   }
   void pp_correct(const double *M0, int64_t rows, int R, const PPTerm *terms, int nterms,
                   double *M) override {
+    RoctxRange roctx_("K9 pp_correct");
     if (nterms > MAX_ORDER) throw std::runtime_error("ppals: too many PP correction terms");
     PPTerms tm;
     tm.n = nterms;
@@ -744,6 +751,7 @@ class HipOps : public Ops {
   void normalize_ms(double *const *W, const int64_t *rows, int N, int R, double *Gall,
                     double *ms_dst, const unsigned *masks, unsigned active, unsigned fresh,
                     double *wsq) override {
+    RoctxRange roctx_("K7 normalize");
     int64_t tot = 0;
     for (int i = 0; i < N; i++) tot += rows[i] * R;
     if (tot > 65536) {  // big factors: the grid-wide scaling kernel pays off
@@ -787,6 +795,7 @@ class HipOps : public Ops {
   }
   // K12/K13: Gram of the mode unfolding (fp64 accumulation), reduction split over grid.z slabs
   void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) override {
+    RoctxRange roctx_("K12/K13 unfold gram");
     const int64_t C = L * T;
     const int tiles = (int)((J + 31) / 32);
     int nsplit = 1;
@@ -819,6 +828,7 @@ class HipOps : public Ops {
   // als_Tucker.cxx:20,402). SURVEY.md §2.1 K12 allows the vendor symmetric eigensolver here:
   // rocSOLVER dsyevd, resolved with dlopen on first use (only Tucker sessions ever load it).
   void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
+    RoctxRange roctx_("K12 eig (full solver)");
     if (J <= 64) {  // small modes: in-LDS Jacobi, one block
       size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64 + 17) + sizeof(int) * 64;
       hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, G, (int)J, rank, U,
@@ -914,6 +924,7 @@ class HipOps : public Ops {
                          sizeof(double) * r * r, st_, GB, J, r, Yr, GU);
   }
   void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int slot) override {
+    RoctxRange roctx_("K12 eig (projector route)");
     if (J <= 64 || rank > 64 || rank >= J || slot < 0 || slot >= 16 || !eig_fast_) {
       top_eigvecs(G, J, rank, U);
       return;

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
     __syncthreads();
   }
 }
-// variant 1 (L == 1): one wave per (t,r), lanes stride the contiguous j.
+// variant 1 (L == 1): one wave per 4 consecutive t of one r, lanes stride the contiguous j (four
+// independent load / FMA chains per lane: a row of J values is too little to hide a round trip).
 template <typename TX>
 __global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
                          const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
@@ -369,19 +370,35 @@ __global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t total = T * R;
+  const int64_t T4 = (T + 3) / 4;
+  const int64_t total = T4 * R;
   const double sc = mttv_scale(scale);
   for (int64_t e = wid; e < total; e += nw) {
-    const int64_t t = e % T;
-    const int r = (int)(e / T);
-    const TX *x = X + J * (t + T * (int64_t)r);
+    const int64_t t0 = (e % T4) * 4;
+    const int r = (int)(e / T4);
     const double *b = B + ldb * r;
-    double s = 0;
-    for (int64_t j = lane; j < J; j += 64) s += (double)x[j] * b[j];
-    s = wave_sum(s);
+    const TX *x0 = X + J * (t0 + T * (int64_t)r);
+    const TX *x1 = x0 + J * (t0 + 1 < T ? 1 : 0), *x2 = x0 + J * (t0 + 2 < T ? 2 : 0),
+             *x3 = x0 + J * (t0 + 3 < T ? 3 : 0);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t j = lane; j < J; j += 64) {
+      const double bj = b[j];
+      s0 += (double)x0[j] * bj;
+      s1 += (double)x1[j] * bj;
+      s2 += (double)x2[j] * bj;
+      s3 += (double)x3[j] * bj;
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
     if (lane == 0) {
-      double *o = out + t + rs * r;
-      *o = accumulate ? (*o + sc * s) : sc * s;
+      const double v[4] = {s0, s1, s2, s3};
+      for (int q = 0; q < 4; q++)
+        if (t0 + q < T) {
+          double *o = out + (t0 + q) + rs * r;
+          *o = accumulate ? (*o + sc * v[q]) : sc * v[q];
+        }
     }
   }
 }
@@ -915,6 +932,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   double *sM = (double *)(pq + 64);
   double *sW = sM + (STAGE ? rows * R : 0);
   const int64_t total = rows * R;
+  const int rows_i = (int)rows, total_i = (int)total;  // launcher: rows * R < 2^31 (32-bit index math)
 
   for (int e = tid; e < R * R; e += blockDim.x) {
     const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
@@ -931,9 +949,8 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       jacobi_inverse_wave(A, Q, cs, pq, R, sI);
     }
   } else if (STAGE) {
-    for (int64_t e = tid - 64; e < total; e += blockDim.x - 64) {
-      const int64_t i = e % rows;
-      const int j = (int)(e / rows);
+    for (int e = tid - 64; e < total_i; e += (int)blockDim.x - 64) {
+      const int i = e % rows_i, j = e / rows_i;
       sM[e] = M[i + ldm * j];
       sW[e] = W[i + ldw * j];
     }
@@ -946,12 +963,11 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     }
 
   double gs = 0;
-  for (int64_t e = tid; e < total; e += blockDim.x) {
-    const int64_t i = e % rows;
-    const int j = (int)(e / rows);
+  for (int e = tid; e < total_i; e += (int)blockDim.x) {
+    const int i = e % rows_i, j = e / rows_i;
     double acc = 0;
     if (STAGE) {
-      for (int k = 0; k < R; k++) acc += sW[i + rows * k] * sS[k + R * j];
+      for (int k = 0; k < R; k++) acc += sW[i + rows_i * k] * sS[k + R * j];
     } else {
       for (int k = 0; k < R; k++) acc += W[i + ldw * k] * sS[k + R * j];
     }
@@ -962,12 +978,11 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
   if (tid == 0) *gradsq = gs;
   double dd = 0;
-  for (int64_t e = tid; e < total; e += blockDim.x) {
-    const int64_t i = e % rows;
-    const int j = (int)(e / rows);
+  for (int e = tid; e < total_i; e += (int)blockDim.x) {
+    const int i = e % rows_i, j = e / rows_i;
     double acc = 0;
     if (STAGE) {
-      for (int k = 0; k < R; k++) acc += sM[i + rows * k] * sI[k + R * j];
+      for (int k = 0; k < R; k++) acc += sM[i + rows_i * k] * sI[k + R * j];
     } else {
       for (int k = 0; k < R; k++) acc += M[i + ldm * k] * sI[k + R * j];
     }

@@ -14,6 +14,8 @@
 
 #include "hip_ops.h"
 
+#include "roctx_ranges.h"
+
 namespace ppals {
 namespace {
 
@@ -77,15 +79,18 @@ class RcclComm : public Comm {
   int rank() const override { return rank_; }
   int size() const override { return size_; }
   void allreduce_sum(double *buf, int64_t n) override {
+    RoctxRange roctx_("C1/C3 all-reduce");
     check(api().AllReduce(buf, buf, (size_t)n, kNcclFloat64, kNcclSum, comm_, stream_),
           "ncclAllReduce");
   }
   void reduce_scatter_sum(const double *send, double *recv, int64_t recvcount) override {
+    RoctxRange roctx_("C1 reduce-scatter");
     check(api().ReduceScatter(send, recv, (size_t)recvcount, kNcclFloat64, kNcclSum, comm_,
                               stream_),
           "ncclReduceScatter");
   }
   void allgather(const double *send, double *recv, int64_t sendcount) override {
+    RoctxRange roctx_("C2 all-gather");
     check(api().AllGather(send, recv, (size_t)sendcount, kNcclFloat64, comm_, stream_),
           "ncclAllGather");
   }
