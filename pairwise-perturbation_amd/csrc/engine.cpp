@@ -269,6 +269,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (const char *e = std::getenv("PPALS_DT_SCHEDULE")) schedule_ = (std::string(e) == "dt") ? 0 : 1;
   if (N_ < 3) schedule_ = 0;
   if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PPALS_PLACE_TUNE")) ms_tune_enabled_ = std::atoi(e) != 0;
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
     ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
@@ -278,6 +279,16 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   // hipMalloc (≈ 1 s per 44 GB, several seconds on a fresh box) plus the transpose.
   if (V_.generation) tensor_gen_ = *V_.generation;
   ensure_transposed();
+  if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
+    // placement of the first-level intermediate, measured per root with the factors at hand
+    // (zeros: the timing does not depend on the values); nothing is kept but the offsets
+    for (int r = 0; r < N_; r++) {
+      if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
+      ms_start_step(r);
+    }
+    ms_invalidate();
+    ms_X_.valid = false;
+  }
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
   leaf_.assign(N_, -1);
@@ -321,7 +332,7 @@ CpEngine::~CpEngine() {
   ops_.free(Qbuf_);
   ops_.free(Pbuf_);
   ops_.free(VT_);
-  ops_.free(ms_X_.buf);
+  ops_.free(ms_X_base_);
   ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
     ops_.free(n.t.buf);
@@ -674,6 +685,13 @@ void CpEngine::ms_set_roots(int k) {
   ms_invalidate();
 }
 
+// room for the placement candidates of X (ms_start_step): none for small tensors, where a scan is
+// too short to time from the host and the effect does not matter
+size_t CpEngine::ms_X_slack() const {
+  const double bytes = (double)V_.nloc * dtype_size(V_.dtype);
+  return bytes >= 1.5e9 ? ((size_t)64 << 20) + 4096 : 0;
+}
+
 // new step: X = V contracted with the k root modes first, ..., first + k - 1 (cyclic) in ONE
 // tensor scan on whichever resident layout stores them next to each other and behind at least one
 // other mode; X is kept in the tensor's own precision
@@ -747,12 +765,60 @@ void CpEngine::ms_start_step(int first) {
   }
   ms_X_.dt = V_.dtype;
   ms_X_.contracted = mask;
-  ms_reserve(ms_X_, (size_t)L * T * R_ * dtype_size(ms_X_.dt));
+  // X at this root's offset inside the over-allocated block (see engine.h, ms_X_off_)
+  const size_t xbytes = (size_t)L * T * R_ * dtype_size(ms_X_.dt);
+  const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;
+  if (ms_X_cap_ < xbytes + slack) {
+    ops_.free(ms_X_base_);
+    ms_X_base_ = ops_.alloc(xbytes + slack);
+    ms_X_cap_ = xbytes + slack;
+    for (int q = 0; q < MAX_ORDER; q++) ms_tuned_[q] = false;
+  }
+  auto launch_scan = [&](int64_t off) {
+    ms_X_.buf = (char *)ms_X_base_ + off;
+    ops_.scan_contract(src, V_.dtype, L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt, L,
+                       L * T);
+  };
+  if (slack > 0 && !ms_tuned_[first]) {
+    // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
+    // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
+    ms_tuned_[first] = true;
+    ms_X_off_[first] = 0;
+    static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
+    static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
+    const double bytes = (double)L * J * T * dtype_size(V_.dtype);
+    if (bytes >= 1.5e9) {
+      const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
+      const int reps = large ? 1 : 2;
+      const int64_t *cand_mb = large ? cand_large : cand_small;
+      const int ncand = large ? 8 : 14;
+      double best = 1e300;
+      for (int ci = 0; ci < ncand; ci++) {
+        const int64_t mb = cand_mb[ci];
+        const int64_t off = mb << 20;
+        if ((size_t)off > slack) break;
+        double tmin = 1e300;
+        for (int rep = 0; rep < reps; rep++) {
+          ops_.sync();
+          const double t0 = now();
+          launch_scan(off);
+          ops_.sync();
+          tmin = std::min(tmin, now() - t0);
+        }
+        if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
+          best = tmin;
+          ms_X_off_[first] = off;
+        }
+      }
+      if (getenv("PPALS_DEBUG_ADDR"))
+        fprintf(stderr, "[ppals] root %d: X placed at +%lld MB (%.3f ms)\n", first,
+                (long long)(ms_X_off_[first] >> 20), best * 1e3);
+    }
+  }
   if (getenv("PPALS_DEBUG_ADDR"))
     fprintf(stderr, "[ppals] step roots %d..+%d: src %p (V %p VT %p) X %p L %lld J %lld T %lld\n",
             first, k, src, V_.data, (void *)VT_, ms_X_.buf, (long long)L, (long long)J, (long long)T);
-  ops_.scan_contract(src, V_.dtype, L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt, L,
-                     L * T);
+  launch_scan(ms_X_off_[first]);
   ms_X_.pending = false;
   ms_X_.valid = true;
   if (const char *tr = std::getenv("PPALS_TRACE_STEPS")) {  // tests: which root sets were scanned

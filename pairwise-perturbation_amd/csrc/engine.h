@@ -155,6 +155,17 @@ class CpEngine {
   void ms_set_roots(int k);
   void ms_mode_update(int i, double lambda);
   RTensor ms_X_;
+  // Placement of the first-level intermediate: the scan reads the tensor and writes X at the same
+  // time, and how the two streams fall onto the HBM channels depends on where X lies relative to
+  // the tensor buffer — 6-9 % of the launch between placements of one and the same kernel
+  // (profiles/r02l_place_bench_*.txt). X lives at a per-root offset inside an over-allocated block;
+  // the offsets are measured once per session (ms_tune_placement).
+  void *ms_X_base_ = nullptr;
+  size_t ms_X_cap_ = 0;
+  int64_t ms_X_off_[MAX_ORDER] = {0};
+  bool ms_tuned_[MAX_ORDER] = {false};
+  bool ms_tune_enabled_ = true;
+  size_t ms_X_slack() const;
   std::vector<MsNode> ms_nodes_;
   std::vector<int> ms_order_;  // the N-k modes of the step in update order
   std::vector<int> ms_leaf_;   // node index of each list position
