@@ -86,6 +86,7 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
     if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
+    if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_power_step1,
@@ -810,7 +811,14 @@ class HipOps : public Ops {
     if (nsplit > 1) dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * J * J);
     dim3 grid(tiles, tiles, nsplit);
     prof_begin(1, (double)C * J * dtype_size(dt));
-    if (dt == F32)
+    if (gram_mfma_ && J >= 16) {  // matrix cores (K13); tiny modes: the VALU tile kernel
+      if (dt == F32)
+        hipLaunchKernelGGL(k_unfold_gram_mfma<float>, grid, dim3(256), 0, st_, (const float *)X, L, J,
+                           T, per, dst);
+      else
+        hipLaunchKernelGGL(k_unfold_gram_mfma<double>, grid, dim3(256), 0, st_, (const double *)X, L,
+                           J, T, per, dst);
+    } else if (dt == F32)
       hipLaunchKernelGGL(k_unfold_gram<float>, grid, dim3(256), 0, st_, (const float *)X, L, J, T,
                          per, dst);
     else
@@ -1207,6 +1215,7 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  int gram_mfma_ = 1;     // PPALS_GRAM_MFMA=0: the fp64 VALU Gram kernel (A/B, tests)
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)

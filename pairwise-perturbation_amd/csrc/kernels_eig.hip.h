@@ -81,6 +81,64 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, 
   }
 }
 
+// K13 on the matrix cores: Gram of the mode-`pos` unfolding (unroll_tensor_contraction,
+// common.cxx:205-223; the HOSVD initialisation runs it on the full tensor: N * 2 s^(N+1) flops, the
+// largest single cost of a Tucker run and MFMA-bound).
+//   G[p + J*q] (slab blockIdx.z) = sum_{c in chunk} A[p][c] * A[q][c],  A[p][c] = X[l + L*(p + J*t)]
+// 32 x 32 output tile per workgroup, the reduction index staged through LDS 32 at a time AS fp64
+// (an fp32 tensor is widened there: its products are exact in fp64, so the Gram carries fp64
+// rounding only — eigenvectors of a matrix whose lambda_1 is 1e6 x the rest need that), four waves
+// = four 16 x 16 v_mfma_f64_16x16x4_f64 tiles. Loads are arranged so that consecutive threads touch
+// consecutive addresses (p fastest when L == 1, c fastest otherwise), as in k_unfold_gram.
+template <typename TV>
+__global__ __launch_bounds__(256) void k_unfold_gram_mfma(const TV *__restrict__ X, int64_t L,
+                                                          int64_t J, int64_t T, int64_t c_per_split,
+                                                          double *__restrict__ slab) {
+  __shared__ double As[32][33];
+  __shared__ double Bs[32][33];
+  const int64_t C = L * T;
+  const int64_t p0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32;
+  const int64_t c_begin = (int64_t)blockIdx.z * c_per_split;
+  const int64_t c_end = min(C, c_begin + c_per_split);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty in [0,8)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int wi = (wave & 1) * 16, wj = (wave >> 1) * 16;
+  const bool p_fast = (L == 1);
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int a = tx, b = ty + 8 * i;
+      const int pi = p_fast ? a : b, ci = p_fast ? b : a;
+      const int64_t c = c0 + ci;
+      double va = 0, vb = 0;
+      if (c < c_end) {
+        const int64_t l = c % L, t = c / L;
+        if (p0 + pi < J) va = (double)X[l + L * ((p0 + pi) + J * t)];
+        if (q0 + pi < J) vb = (double)X[l + L * ((q0 + pi) + J * t)];
+      }
+      As[pi][ci] = va;
+      Bs[pi][ci] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cq = 0; cq < 8; cq++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[wi + l16][4 * cq + g], Bs[wj + l16][4 * cq + g],
+                                                 acc, 0, 0, 0);
+    __syncthreads();
+  }
+  double *gs = slab + (int64_t)blockIdx.z * J * J;
+  const int64_t q = q0 + wj + l16;  // D: lane holds column j = lane&15, rows (lane>>4) + 4*reg
+  if (q < J) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t pp_ = p0 + wi + g + 4 * r;
+      if (pp_ < J) gs[pp_ + J * q] = acc[r];
+    }
+  }
+}
+
 // X = (G - sigma I) / rho   (J x J)
 __global__ void k_shift_scale(const double *__restrict__ G, int64_t J, double sigma, double inv_rho,
                               double *__restrict__ X) {
