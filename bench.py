@@ -342,8 +342,10 @@ def main():
             rl = dict(head["roofline"])
             rl.update({
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_scan_suffix_buf (tensor scan: one mode contracted per launch under msdt, "
-                          "a mode half under dt)",
+                "kernel": ("k_scan_suffix_buf" if (R <= 16 or esz == 8) else "k_scan_suffix_fast")
+                          + " (tensor scan: one mode contracted per launch under msdt, a mode half "
+                            "under dt; _buf = persistent buffer-load form, one n-tile or fp64 storage; "
+                            "_fast = global-load form, fp32 with 16 < R)",
                 "other_profiled_ms_per_step": other_ms_per_step,
                 "note": f"algorithmic bytes = one read of the local tensor shard "
                         f"({esz} B/elem) + the result the launch must write, per scan launch; "

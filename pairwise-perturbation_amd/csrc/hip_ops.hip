@@ -107,6 +107,7 @@ class HipOps : public Ops {
     if (ws_big_) hipFree(ws_big_);
     if (ws_big2_) hipFree(ws_big2_);
     if (ws_eig_) hipFree(ws_eig_);
+    if (ws_orth_) hipFree(ws_orth_);
     for (auto &es : eig_state_) {
       if (es.Q) hipFree(es.Q);
       if (es.ev) hipFree(es.ev);
@@ -352,14 +353,24 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
   void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) override {
+    transpose_batched(src, dt, rows, cols, 1, dst);
+  }
+  void transpose_batched(const void *src, int dt, int64_t rows, int64_t cols, int64_t batch,
+                         void *dst) override {
     const int64_t nb = ((rows + 63) / 64) * ((cols + 63) / 64);
     if (nb > 0x7fffffff) throw std::runtime_error("ppals: transpose grid too large");
-    if (dt == F32)
-      hipLaunchKernelGGL(k_transpose<float>, dim3((unsigned)nb), dim3(256), 0, st_,
-                         (const float *)src, rows, cols, (float *)dst);
-    else
-      hipLaunchKernelGGL(k_transpose<double>, dim3((unsigned)nb), dim3(256), 0, st_,
-                         (const double *)src, rows, cols, (double *)dst);
+    const size_t step = (size_t)rows * cols * dtype_size(dt);
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {  // grid.y limit
+      const unsigned nby = (unsigned)std::min<int64_t>(65535, batch - b0);
+      const char *s = (const char *)src + b0 * step;
+      char *d = (char *)dst + b0 * step;
+      if (dt == F32)
+        hipLaunchKernelGGL(k_transpose<float>, dim3((unsigned)nb, nby), dim3(256), 0, st_,
+                           (const float *)s, rows, cols, (float *)d);
+      else
+        hipLaunchKernelGGL(k_transpose<double>, dim3((unsigned)nb, nby), dim3(256), 0, st_,
+                           (const double *)s, rows, cols, (double *)d);
+    }
     HIP_CHECK(hipGetLastError());
   }
 
@@ -916,6 +927,37 @@ class HipOps : public Ops {
     }
     return cur;
   }
+  // block Gram-Schmidt with re-orthogonalisation: 64 columns at a time are cleared of the columns
+  // before them (twice) and made orthonormal by Cholesky QR (twice)
+  bool orthonormalize(double *U, int64_t rows, int r) override {
+    if (r <= 0) return true;
+    if (r > 2048) throw std::runtime_error("ppals: orthonormalize supports at most 2048 columns");
+    const int nblk = (r + 63) / 64;
+    double *w = (double *)ensure(ws_orth_, ws_orth_sz_,
+                                 sizeof(double) * ((size_t)rows * 64 + 64 * 64 + (size_t)r * 64) +
+                                     sizeof(int) * 2 * 64);
+    double *tmp = w, *C = tmp + (size_t)rows * 64, *T = C + 64 * 64;
+    int *status = (int *)(T + (size_t)r * 64);
+    HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int) * 2 * nblk, st_));
+    for (int b = 0; b < nblk; b++) {
+      const int b0 = b * 64, rb = std::min(64, r - b0);
+      double *Zb = U + (size_t)rows * b0;
+      for (int pass = 0; pass < 2 && b0 > 0; pass++) {
+        hipLaunchKernelGGL(k_tn_rect, dim3((b0 * rb + 15) / 16), dim3(1024), 0, st_, U, b0, Zb, rb,
+                           rows, T);
+        hipLaunchKernelGGL(k_sub_mult, dim3(grid_for(rows * rb, 256)), dim3(256), 0, st_, Zb, rows,
+                           rb, U, b0, T);
+      }
+      double *res = chol_qr2(Zb, tmp, rows, rb, C, status + 2 * b);  // two passes: ends in Zb
+      if (res != Zb) throw std::logic_error("ppals: orthonormalize buffer parity");
+    }
+    int hs[2 * 32];
+    HIP_CHECK(hipMemcpyAsync(hs, status, sizeof(int) * 2 * nblk, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    for (int e = 0; e < 2 * nblk; e++)
+      if (hs[e]) return false;
+    return true;
+  }
   // Rayleigh-Ritz of G on the orthonormal basis B (J x r): U = eigenvectors sorted descending,
   // ev (device) = eigenvalues; GB/H/Yr/Bt scratch. Leaves G*U in GU when GU != nullptr.
   void rayleigh_ritz(const double *G, const double *B, int64_t J, int r, double *Bt, double *GB,
@@ -1220,8 +1262,8 @@ class HipOps : public Ops {
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)
   EigState eig_state_[16];
-  void *ws_eig_ = nullptr;
-  size_t ws_eig_sz_ = 0;
+  void *ws_eig_ = nullptr, *ws_orth_ = nullptr;
+  size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;

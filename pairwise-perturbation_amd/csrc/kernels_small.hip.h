@@ -195,11 +195,14 @@ __global__ __launch_bounds__(256) void k_rank_stream_any(TV *__restrict__ V, int
   }
 }
 
-// dst[c + cols*r] = src[r + rows*c]: 64x64 tiles through LDS (both sides coalesced)
+// dst[c + cols*r] = src[r + rows*c]: 64x64 tiles through LDS (both sides coalesced); blockIdx.y
+// walks over independent rows x cols blocks stored one after another
 template <typename TV>
 __global__ __launch_bounds__(256) void k_transpose(const TV *__restrict__ src, int64_t rows,
                                                    int64_t cols, TV *__restrict__ dst) {
   __shared__ TV tile[64][65];
+  src += (int64_t)blockIdx.y * rows * cols;
+  dst += (int64_t)blockIdx.y * rows * cols;
   const int64_t tiles_r = (rows + 63) / 64;
   const int64_t r0 = (int64_t)(blockIdx.x % tiles_r) * 64, c0 = (int64_t)(blockIdx.x / tiles_r) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty in [0,4)

@@ -89,6 +89,14 @@ class Ops {
   // dst[c + cols*r] = src[r + rows*c] (same element type dt): builds the second resident layout
   // of the tensor (right-half modes fastest) so that BOTH first-level tree nodes are suffix scans
   virtual void transpose2d(const void *src, int dt, int64_t rows, int64_t cols, void *dst) = 0;
+  // `batch` independent transposes of consecutive rows x cols blocks:
+  //   dst[c + cols*(r + rows*b)] = src[r + rows*(c + cols*b)]
+  virtual void transpose_batched(const void *src, int dt, int64_t rows, int64_t cols, int64_t batch,
+                                 void *dst) {
+    const size_t step = (size_t)rows * cols * dtype_size(dt);
+    for (int64_t b = 0; b < batch; b++)
+      transpose2d((const char *)src + b * step, dt, rows, cols, (char *)dst + b * step);
+  }
   // full[a + s0*c] = stage_p[(a - p*blk) + l_p*c] for the rank p that owns row a (l_p rows each,
   // element type dt); stage_p starts at byte offset p*chunk_bytes. Re-assembles the leading-mode
   // shards of a tensor after an all-gather (Tucker HOSVD of the sharded mode).
@@ -226,6 +234,11 @@ class Ops {
   virtual void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int /*slot*/) {
     top_eigvecs(G, J, rank, U);
   }
+  // U (rows x r, column-major, ld = rows) -> orthonormal columns spanning the same nested
+  // subspaces (column k stays in span(U[:, :k+1]) with a positive component on the old column k:
+  // a QR factorisation's Q). Returns false, leaving U unspecified, when U is numerically rank
+  // deficient.
+  virtual bool orthonormalize(double *U, int64_t rows, int r) = 0;
   virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
   virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
   // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)

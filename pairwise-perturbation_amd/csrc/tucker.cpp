@@ -46,6 +46,7 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   ops_.zero(core_, sizeof(double) * ncore_);
   ops_.zero(core_prev_, sizeof(double) * ncore_);
   G_ = (double *)ops_.alloc(sizeof(double) * maxs * maxs);
+  if (const char *e = std::getenv("PPALS_TUCKER_THIN")) thin_enabled_ = std::atoi(e) != 0;
   scal_ = (double *)ops_.alloc(sizeof(double) * 64);
   yend_elems_ = ncore_ / r_[N_ - 1] * V_.glens[N_ - 1];
   Yend_ = (double *)ops_.alloc(sizeof(double) * yend_elems_);
@@ -94,6 +95,7 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(core_prev_);
   ops_.free(Yend_);
   ops_.free(G_);
+  ops_.free(thin_);
   ops_.free(scal_);
   ops_.free(Yfull_);
   ops_.free(gather_);
@@ -398,6 +400,38 @@ void TuckerEngine::hosvd() {
   ops_.sync();
 }
 
+// K12 (als_Tucker.cxx:399-406: Gram of the unfolding by unroll_tensor_contraction, then
+// `MTM.svd(U,S,VT,rank)`): the factor is the r_i leading left singular vectors of the s_i x (L*T)
+// unfolding Y_(i). The reference always takes them from the s_i x s_i Gram Y_(i) Y_(i)^T. When the
+// unfolding is TALL (s_i > L*T: the long mode of an image stack, 7200 x 300 for the coil-100
+// shape) the same vectors come from the small side: eigenvectors v_k of the (L*T)^2 Gram
+// Y_(i)^T Y_(i), then u_k = Y_(i) v_k / |Y_(i) v_k| — same squared conditioning, O(s c^2) instead
+// of O(s^3) work. The columns are re-orthonormalised (they are orthogonal only to
+// eps * lambda_1 / lambda_k); a numerically rank-deficient unfolding takes the s_i x s_i route.
+void TuckerEngine::factor_update(int i, const double *Y, int64_t L, int64_t T) {
+  const int64_t s = V_.glens[i], c = L * T;
+  if (thin_enabled_ && c < s && r_[i] <= c) {
+    const int64_t need = s * c + c * r_[i];
+    if (thin_cap_ < need) {
+      ops_.free(thin_);
+      thin_ = (double *)ops_.alloc(sizeof(double) * need);
+      thin_cap_ = need;
+    }
+    const double *Ym = Y;  // [s, c] with the mode fastest
+    if (L > 1) {
+      ops_.transpose_batched(Y, F64, L, s, T, thin_);
+      Ym = thin_;
+    }
+    double *Vr = thin_ + s * c;
+    ops_.unfold_gram(Ym, F64, s, c, 1, G_);  // c x c (c < s: fits G_)
+    ops_.top_eigvecs_warm(G_, c, r_[i], Vr, i);
+    ops_.ttm_keep(Ym, F64, s, c, 1, Vr, c, r_[i], W_[i]);
+    if (ops_.orthonormalize(W_[i], s, r_[i])) return;
+  }
+  ops_.unfold_gram(Y, F64, L, s, T, G_);
+  ops_.top_eigvecs_warm(G_, s, r_[i], W_[i], i);
+}
+
 void TuckerEngine::sweep_dt() { sweep_body(nullptr); }
 
 // one HOOI sweep; align_ref != nullptr: column signs aligned with that factor set after every
@@ -412,8 +446,7 @@ void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
     for (int q = i + 1; q < N_; q++) T *= r_[q];
     double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
-    ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);                   // K12
-    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], i);
+    factor_update(i, Y, L, T);  // K12
     if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
   }
   // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408)
@@ -626,8 +659,7 @@ void TuckerEngine::sweep_pp() {
       }
     }
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
-    ops_.unfold_gram(Y, F64, L, V_.glens[i], T, G_);
-    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], i);
+    factor_update(i, Y, L, T);  // K12
     ops_.sign_align(W_[i], Winit_[i], V_.glens[i], r_[i]);  // als_Tucker.cxx:874-885
     double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
     int64_t n[1] = {V_.glens[i] * r_[i]};

@@ -39,6 +39,8 @@ class TuckerEngine {
   // leaf tensor Y_i complete on every rank (all-gather of the leading-mode rows for i = 0,
   // all-reduce of the partial sums otherwise); returns the buffer holding it
   double *complete_leaf(int i, double *Yloc, int64_t elems_local);
+  // W_i = the r_i leading left singular vectors of the mode-i unfolding of Y = [L, s_i, T]
+  void factor_update(int i, const double *Y, int64_t L, int64_t T);
   void compute_core_full();
   double core_norm();
   bool agree(bool local);
@@ -67,6 +69,9 @@ class TuckerEngine {
   std::map<std::string, PPOp> pp_;
   std::vector<double *> Wprev_, Winit_, dW_;
   double *Ytmp_ = nullptr, *Yacc_ = nullptr;
+  double *thin_ = nullptr;  // [s_i x (L*T) unfolding | (L*T) x r_i right vectors] of the thin route
+  int64_t thin_cap_ = 0;
+  bool thin_enabled_ = true;  // PPALS_TUCKER_THIN=0: always the s_i x s_i Gram (A/B, tests)
   void *VT_ = nullptr;  // second resident layout [(right modes), (left modes)], nullptr: not held
   uint64_t tensor_gen_ = 0;  // generation of the tensor contents VT_ and the caches were built from
   void check_tensor_generation();

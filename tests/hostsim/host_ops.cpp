@@ -390,6 +390,28 @@ class HostOps : public Ops {
     for (int k = 0; k < rank; k++)
       for (int64_t i = 0; i < J; i++) U[i + J * k] = Q[i + (size_t)J * ord[k]];
   }
+  bool orthonormalize(double *U, int64_t rows, int r) override {  // modified Gram-Schmidt, twice
+    double nmax = 0;
+    for (int k = 0; k < r; k++) {
+      double *u = U + rows * k;
+      double n0 = 0;
+      for (int64_t i = 0; i < rows; i++) n0 += u[i] * u[i];
+      nmax = std::max(nmax, n0);
+      for (int pass = 0; pass < 2; pass++)
+        for (int d = 0; d < k; d++) {
+          const double *q = U + rows * d;
+          double c = 0;
+          for (int64_t i = 0; i < rows; i++) c += q[i] * u[i];
+          for (int64_t i = 0; i < rows; i++) u[i] -= c * q[i];
+        }
+      double n1 = 0;
+      for (int64_t i = 0; i < rows; i++) n1 += u[i] * u[i];
+      if (!(n1 > 1e-12 * nmax)) return false;
+      const double inv = 1.0 / std::sqrt(n1);
+      for (int64_t i = 0; i < rows; i++) u[i] *= inv;
+    }
+    return true;
+  }
   void sign_align(double *W, const double *Wref, int64_t rows, int r) override {
     for (int k = 0; k < r; k++) {
       double c = 0;

@@ -51,3 +51,5 @@ test_tucker_bench_mode_matches_oracle = GT.test_tucker_bench_mode_matches_oracle
 test_eigen_step_projector_route_matches_oracle = GT.test_eigen_step_projector_route_matches_oracle
 test_tensor_p_laplacian = G.test_tensor_p_laplacian
 test_tensor_c_collinear = G.test_tensor_c_collinear
+test_tall_unfolding_thin_route_matches_oracle = GT.test_tall_unfolding_thin_route_matches_oracle
+test_tall_unfolding_rank_deficient_falls_back = GT.test_tall_unfolding_rank_deficient_falls_back

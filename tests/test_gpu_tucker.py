@@ -222,3 +222,66 @@ def test_eigen_step_projector_route_matches_oracle(pp, ctx, lens, ranks, tmp_pat
     for a, b in zip(*results):
         for k in range(a.shape[1]):
             assert min(np.linalg.norm(a[:, k] - b[:, k]), np.linalg.norm(a[:, k] + b[:, k])) < 1e-6
+
+
+TALL = [([300, 6, 5], [5, 3, 2]),        # leading mode tall (L = 1: no re-ordering needed)
+        ([6, 200, 5], [3, 8, 4]),        # middle mode tall (batched transposition)
+        ([5, 4, 150, 3], [3, 2, 9, 2]),  # order 4
+        ([20, 12, 400], [10, 8, 70])]    # last mode tall, more than 64 columns to orthonormalise
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("lens,ranks", TALL)
+def test_tall_unfolding_thin_route_matches_oracle(pp, ctx, lens, ranks, dtype, tmp_path, monkeypatch):
+    """a mode longer than the product of the other modes' ranks (the 7200-frame mode of the
+    coil-100 shape): the factor comes from the SMALL Gram of the unfolding, Y^T Y, and one product
+    with Y (TuckerEngine::factor_update) instead of the s x s Gram the reference always forms
+    (als_Tucker.cxx:399-406). Same iterates as the oracle (which follows the reference) and as
+    the engine with the route switched off."""
+    inner = [min(s, r + 3) for s, r in zip(lens, ranks)]
+    V = _decaying_tensor(lens, inner, 11, 0.02)
+    W0, c0 = O.hosvd(V, ranks)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=4, csv=c_ref, resprint=1)
+    tol = 2e-4 if dtype == 0 else 1e-7
+    for thin in ("1", "0"):
+        monkeypatch.setenv("PPALS_TUCKER_THIN", thin)
+        t = pp.Tensor(ctx, lens, dtype).upload(V)
+        s = pp.Tucker(ctx, t, ranks)
+        s.set_factors(W0)
+        s.set_core(c0)
+        rc, it = s.run_dt(tol=0.0, maxiter=4, csv=c_got, resprint=1)
+        assert it == it_ref
+        W, core = s.get_factors()
+        for a, b, r in zip(W, W_ref, ranks):
+            assert np.allclose(a.T @ a, np.eye(r), atol=1e-10), thin
+            assert relerr(proj(a), proj(b)) < tol, (thin, relerr(proj(a), proj(b)))
+        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < tol * np.linalg.norm(core_ref)
+        _, r1 = O.read_csv(c_ref)
+        _, r2 = O.read_csv(c_got)
+        assert len(r1) == len(r2)
+        for a, b in zip(r1, r2):
+            assert a[1] == b[1] and abs(a[5] - b[5]) < tol * np.linalg.norm(V)
+        s.close()
+        t.close()
+
+
+def test_tall_unfolding_rank_deficient_falls_back(pp, ctx):
+    """requested rank above the tensor's multilinear rank: Y^T Y has zero eigenvalues among the
+    wanted ones, Y v has null columns, the Cholesky QR reports it and the s x s route completes
+    the basis — orthonormal factors and the oracle's residual either way"""
+    lens, ranks = [120, 5, 4], [4, 3, 3]
+    V = _decaying_tensor(lens, [2, 2, 2], 3, 0.0)
+    W0, c0 = O.hosvd(V, ranks)
+    _, _, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=2)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.run_dt(tol=0.0, maxiter=2)
+    W, core = s.get_factors()
+    for a, r in zip(W, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()

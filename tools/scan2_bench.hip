@@ -84,6 +84,24 @@ int run(int64_t M, int K, int R, int rounds) {
                        (double *)out, M, (int64_t)0, (int64_t)0, R, 1, (int64_t)n_mt);               \
   }
   vs.push_back({"fast (launcher choice r01)", fast(out), (const void *)k_scan_suffix_fast<float, NT, 1>, {}});
+  // XCD-aware block order (each XCD a contiguous eighth of the tile space) and, for the same bytes,
+  // the batched shape [L = M/T2 rows | K | T2 batches] the middle-mode roots scan
+  vs.push_back({"fast nt+xcd order", [=]() {
+                  hipLaunchKernelGGL((k_scan_suffix_fast<float, NT, 3>), dim3((unsigned)n_mt), dim3(256), 0,
+                                     0, V, M, (int64_t)K, M * K, P, n_mt, 1, nblk, nblk, (double *)out, M,
+                                     (int64_t)0, (int64_t)0, R, 1);
+                },
+                (const void *)k_scan_suffix_fast<float, NT, 3>, {}});
+  {
+    const int64_t T2 = K, M2 = M / T2;  // e.g. 64e6 rows = 160000 x 400 batches
+    const int n_mt2 = (int)((M2 + 255) / 256);
+    vs.push_back({"fast batched shape", [=]() {
+                    hipLaunchKernelGGL((k_scan_suffix_fast<float, NT, 1>), dim3((unsigned)(n_mt2 * T2)),
+                                       dim3(256), 0, 0, V, M2, (int64_t)K, M2 * K, P, n_mt2, 1, nblk, nblk,
+                                       (double *)out, M2 * T2, (int64_t)0, M2, R, 1);
+                  },
+                  (const void *)k_scan_suffix_fast<float, NT, 1>, {}});
+  }
   vs.push_back({"buf  U4 fp64 x40", PERSIST((k_scan_suffix_buf<float, NT, 1>), 40), (const void *)k_scan_suffix_buf<float, NT, 1>, {}});
 #define LEAN(NAME, U_, ACC_, W_, mult)                                                      \
   vs.push_back({NAME, PERSIST((k_scan_suffix_lean<NT, U_, ACC_, W_>), mult),                \
