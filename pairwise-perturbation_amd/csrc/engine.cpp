@@ -278,6 +278,12 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   // here rather than at the first sweep, whose [dtime] would otherwise carry a one-off multi-GB
   // hipMalloc (≈ 1 s per 44 GB, several seconds on a fresh box) plus the transpose.
   if (V_.generation) tensor_gen_ = *V_.generation;
+  {
+    Layout nat;
+    nat.ptr = V_.data;
+    for (int m = 0; m < N_; m++) nat.order.push_back(m);
+    lay_.push_back(nat);
+  }
   ensure_transposed();
   if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
     // placement of the first-level intermediate, measured per root with the factors at hand
@@ -331,7 +337,8 @@ CpEngine::~CpEngine() {
   ops_.free(Mbuf_);
   ops_.free(Qbuf_);
   ops_.free(Pbuf_);
-  ops_.free(VT_);
+  for (auto &l : lay_)
+    if (l.owned) ops_.free(l.ptr);
   ops_.free(ms_X_base_);
   ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
@@ -347,18 +354,150 @@ CpEngine::~CpEngine() {
 // it; cfg2: +6.4 GB, cfg4: +102 GB) and one transpose per session; the bytes read per sweep do
 // not change. Built once, when the session is created. PPALS_TRANSPOSED_COPY=0 or an allocation
 // failure falls back to the prefix scan (and to single-mode root sets).
+//
+// Padded layouts (engine.h, Layout): the leading block of q modes is padded when that makes more
+// root positions 128-B aligned than the plain order has (q < first aligned position) at a cost of
+// at most PPALS_PAD_WASTE (default 3 %) extra bytes — s = 50: 2500 -> 2528 elements, +1.1 %.
+// PPALS_PAD_LAYOUT=0 never pads, =1 pads whatever the tensor's size (tests); by default tensors
+// below 1 GB are left alone. The padded copy in the tensor's own order is a THIRD copy of the
+// tensor: built only if the allocation succeeds.
+static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+void CpEngine::fill_layout(const Layout &l) {
+  // the layout is the tensor rotated by h modes: transposition of [first h modes | the rest]
+  int h = l.order[0];
+  const int64_t rows = h == 0 ? 1 : prod_ext(0, h - 1);
+  const int64_t cols = h == 0 ? V_.nloc : prod_ext(h, N_ - 1);
+  if (l.q == 0)
+    ops_.transpose2d(V_.data, V_.dtype, rows, cols, l.ptr);
+  else
+    ops_.pad_layout(V_.data, V_.dtype, rows, cols, l.blk, l.ld, l.ptr);
+}
+
 void CpEngine::ensure_transposed() {
   if (vt_state_ != 0) return;
   vt_state_ = -1;
   const char *env = std::getenv("PPALS_TRANSPOSED_COPY");
   if (env && std::atoi(env) == 0) return;
   if (N_ < 3) return;
+  const size_t esz = dtype_size(V_.dtype);
+  const int64_t line = 128 / (int64_t)esz;  // elements per 128 B
+  int pad_mode = -1;                         // auto
+  if (const char *e = std::getenv("PPALS_PAD_LAYOUT")) pad_mode = std::atoi(e);
+  double max_waste = 0.03;
+  if (const char *e = std::getenv("PPALS_PAD_WASTE")) max_waste = std::atof(e);
+  const bool may_pad = pad_mode == 1 || (pad_mode != 0 && (double)V_.nloc * esz >= 1e9);
+  // leading block of a storage order worth padding: the smallest q whose padding is cheap, if the
+  // plain order has no aligned position that early
+  auto choose_pad = [&](Layout &l, int qmax) {
+    l.q = 0;
+    if (!may_pad) return;
+    int q_nat = N_;
+    int64_t b = 1;
+    for (int p = 1; p < N_; p++) {
+      b *= ext(l.order[p - 1]);
+      if (b % line == 0) {
+        q_nat = p;
+        break;
+      }
+    }
+    b = 1;
+    for (int q = 1; q < q_nat && q <= qmax; q++) {
+      b *= ext(l.order[q - 1]);
+      const int64_t ld = round_up(b, line);
+      if ((double)(ld - b) <= max_waste * (double)b) {
+        l.q = q;
+        l.blk = b;
+        l.ld = ld;
+        return;
+      }
+    }
+  };
+  auto bytes_of = [&](const Layout &l) {
+    return l.q ? (size_t)l.ld * (size_t)(V_.nloc / l.blk) * esz : (size_t)V_.nloc * esz;
+  };
   const int mid = (N_ - 1) / 2;
-  const int64_t rows = prod_ext(0, mid), cols = prod_ext(mid + 1, N_ - 1);
-  VT_ = ops_.try_alloc((size_t)rows * cols * dtype_size(V_.dtype));
-  if (!VT_) return;
-  ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
+  Layout t;
+  for (int m = mid + 1; m < N_; m++) t.order.push_back(m);
+  for (int m = 0; m <= mid; m++) t.order.push_back(m);
+  choose_pad(t, std::min(N_ - 2, N_ - 1 - mid));  // the block must lie inside the right half
+  t.ptr = ops_.try_alloc(bytes_of(t));
+  if (!t.ptr) return;
+  t.owned = true;
+  fill_layout(t);
+  lay_.push_back(t);
   vt_state_ = 1;
+  Layout a;
+  for (int m = 0; m < N_; m++) a.order.push_back(m);
+  choose_pad(a, N_ - 2);
+  if (a.q > 0) {
+    a.ptr = ops_.try_alloc(bytes_of(a));
+    if (a.ptr) {
+      a.owned = true;
+      fill_layout(a);
+      lay_.push_back(a);
+    }
+  }
+}
+
+// The scan that contracts modes first .. first+k-1 (cyclic) on the best resident layout: the set
+// must be stored adjacently (no wrap-around) and, on a padded layout, behind the padded block.
+// Among those, 128-B aligned columns of at least a tile of rows win, then the most rows in front
+// of the set (long contiguous runs per reduction index; a leading set would be a column-strided
+// prefix scan). false: no layout stores the set adjacently.
+bool CpEngine::plan_scan(int first, int k, bool natural_only, ScanPlan &plan) {
+  auto in_set = [&](int m) { return ((m - first + N_) % N_) < k; };
+  const int64_t line = 128 / (int64_t)dtype_size(V_.dtype);
+  const Layout *best = nullptr;
+  int best_p0 = 0;
+  int64_t best_L = 0;
+  bool best_al = false;
+  const size_t nlay = natural_only ? 1 : lay_.size();
+  for (size_t li = 0; li < nlay; li++) {
+    const Layout &l = lay_[li];
+    int p0 = -1;
+    for (int p = 0; p < N_; p++)
+      if (in_set(l.order[p])) {
+        p0 = p;
+        break;
+      }
+    int len = 0;
+    while (p0 + len < N_ && in_set(l.order[p0 + len])) len++;
+    if (len != k || (l.q > 0 && p0 < l.q)) continue;
+    int64_t L = 1;
+    for (int p = 0; p < p0; p++) L *= ext(l.order[p]);
+    const bool al = L >= 256 && (l.q > 0 || L % line == 0);
+    if (!best || (al && !best_al) ||
+        (al == best_al && (L > best_L || (L == best_L && l.q > 0 && best->q == 0)))) {
+      best = &l;
+      best_p0 = p0;
+      best_L = L;
+      best_al = al;
+    }
+  }
+  if (!best) return false;
+  plan = ScanPlan();
+  plan.lay = best;
+  for (int p = 0; p < N_; p++) {
+    const int m = best->order[p];
+    if (p < best_p0) {
+      plan.Lc *= ext(m);
+      plan.kept.push_back(m);
+    } else if (p < best_p0 + k) {
+      plan.J *= ext(m);
+      plan.set.push_back(m);
+    } else {
+      plan.T *= ext(m);
+      plan.kept.push_back(m);
+    }
+  }
+  plan.L = plan.Lc;
+  if (best->q > 0) {
+    plan.L = plan.Lc / best->blk * best->ld;
+    plan.pad.ld = best->ld;
+    plan.pad.valid = best->blk;
+  }
+  return true;
 }
 
 // The tensor handle stays writable while sessions exist (ppals_tensor_fill_*/upload). Everything
@@ -368,10 +507,8 @@ void CpEngine::ensure_transposed() {
 void CpEngine::check_tensor_generation() {
   if (!V_.generation || *V_.generation == tensor_gen_) return;
   tensor_gen_ = *V_.generation;
-  if (vt_state_ == 1) {
-    const int mid = (N_ - 1) / 2;
-    ops_.transpose2d(V_.data, V_.dtype, prod_ext(0, mid), prod_ext(mid + 1, N_ - 1), VT_);
-  }
+  for (const auto &l : lay_)
+    if (l.owned) fill_layout(l);
   for (auto &n : nodes_) n.valid = false;
   ms_invalidate();
   pp_clear();
@@ -432,14 +569,18 @@ void CpEngine::compute_node(int idx) {
   const int64_t J = prod_ext(n.slo, n.shi);
   const bool sib_is_suffix = n.slo > n.hi;
   if (n.parent < 0) {
-    if (sib_is_suffix) {
-      ops_.scan_contract(V_.data, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, F64, n.elems, n.elems);
+    // a half of the modes is contracted: a suffix scan of the tensor (right half) or of the second
+    // resident layout (left half); without that layout the left half is a prefix scan
+    ScanPlan pl;
+    if (!plan_scan(n.slo, n.shi - n.slo + 1, false, pl))
+      throw std::runtime_error("ppals: internal error (tree node not adjacent)");
+    if (pl.Lc == 1 && !sib_is_suffix) {
+      ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, F64, 1, n.elems);
     } else {
-      ensure_transposed();
-      if (vt_state_ == 1)  // V^T[(right modes), (left modes)]: the same contraction as a suffix scan
-        ops_.scan_contract(VT_, V_.dtype, n.elems, J, 1, f, nf, R_, n.buf, F64, n.elems, n.elems);
-      else
-        ops_.scan_contract(V_.data, V_.dtype, 1, J, n.elems, f, nf, R_, n.buf, F64, 1, n.elems);
+      if (pl.T != 1 || pl.Lc != n.elems || pl.J != J)
+        throw std::runtime_error("ppals: internal error (tree node scan shape)");
+      ops_.scan_contract(pl.lay->ptr, V_.dtype, pl.L, J, 1, f, nf, R_, n.buf, F64, n.elems, n.elems,
+                         pl.pad);
     }
   } else {
     compute_node(n.parent);
@@ -698,46 +839,11 @@ size_t CpEngine::ms_X_slack() const {
 void CpEngine::ms_start_step(int first) {
   const int k = ms_k_;
   ms_root_ = first;
-  auto in_set = [&](int m) { return ((m - first + N_) % N_) < k; };
   ms_order_.clear();
   for (int q = k; q < N_; q++) ms_order_.push_back((first + q) % N_);
   for (auto &n : ms_nodes_) n.t.valid = false;
-  const int mid = (N_ - 1) / 2;
-  // candidate storage orders: the tensor itself, and its second resident layout
-  std::vector<int> lay_v, lay_t;
-  for (int m = 0; m < N_; m++) lay_v.push_back(m);
-  for (int m = mid + 1; m < N_; m++) lay_t.push_back(m);
-  for (int m = 0; m <= mid; m++) lay_t.push_back(m);
-  // (position of the first root mode, number of consecutive root modes from there)
-  auto run_of = [&](const std::vector<int> &lay) {
-    int p0 = -1;
-    for (int p = 0; p < N_; p++)
-      if (in_set(lay[p])) {
-        p0 = p;
-        break;
-      }
-    int len = 0;
-    while (p0 + len < N_ && in_set(lay[p0 + len])) len++;
-    return std::make_pair(p0, len);
-  };
-  auto rows_before = [&](const std::vector<int> &lay, int p0) {
-    int64_t l = 1;
-    for (int p = 0; p < p0; p++) l *= ext(lay[p]);
-    return l;
-  };
-  // among the layouts that store the root modes next to each other, scan the one with the most
-  // rows in front of them (long contiguous runs per reduction index; a leading root set would be
-  // a column-strided scan)
-  const auto rv = run_of(lay_v), rt = run_of(lay_t);
-  const bool v_ok = rv.second == k, t_ok = rt.second == k;
-  const int64_t Lv = v_ok ? rows_before(lay_v, rv.first) : 0;
-  const int64_t Lt = t_ok ? rows_before(lay_t, rt.first) : 0;
-  bool use_t = false;
-  if (t_ok && Lt > Lv) {
-    ensure_transposed();
-    use_t = vt_state_ == 1;
-  }
-  if (!v_ok && !use_t) {
+  ScanPlan pl;
+  if (!plan_scan(first, k, false, pl)) {
     // a root set that wraps around the last mode is adjacent only in the second layout; without
     // it (allocation failed / PPALS_TRANSPOSED_COPY=0) fall back to single-mode roots for good
     if (k == 1) throw std::runtime_error("ppals: internal error (single root not adjacent)");
@@ -745,23 +851,14 @@ void CpEngine::ms_start_step(int first) {
     ms_start_step((first + k - 1) % N_);  // the mode just before the one about to be updated
     return;
   }
-  const std::vector<int> &layout = use_t ? lay_t : lay_v;
-  const void *src = use_t ? VT_ : V_.data;
-  int64_t L = 1, J = 1, T = 1;
-  bool before = true;
-  ms_X_.modes.clear();
+  const void *src = pl.lay->ptr;
+  const int64_t L = pl.Lc, J = pl.J, T = pl.T;
+  ms_X_.modes = pl.kept;
   std::vector<FactorRef> f;
   unsigned mask = 0;
-  for (int m : layout) {
-    if (in_set(m)) {
-      before = false;
-      J *= ext(m);
-      f.push_back(fref(m, W_.data()));  // storage order: first listed = fastest
-      mask |= 1u << m;
-      continue;
-    }
-    (before ? L : T) *= ext(m);
-    ms_X_.modes.push_back(m);
+  for (int m : pl.set) {
+    f.push_back(fref(m, W_.data()));  // storage order: first listed = fastest
+    mask |= 1u << m;
   }
   ms_X_.dt = V_.dtype;
   ms_X_.contracted = mask;
@@ -776,8 +873,8 @@ void CpEngine::ms_start_step(int first) {
   }
   auto launch_scan = [&](int64_t off) {
     ms_X_.buf = (char *)ms_X_base_ + off;
-    ops_.scan_contract(src, V_.dtype, L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt, L,
-                       L * T);
+    ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
+                       L, L * T, pl.pad);
   };
   if (slack > 0 && !ms_tuned_[first]) {
     // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
@@ -816,15 +913,18 @@ void CpEngine::ms_start_step(int first) {
     }
   }
   if (getenv("PPALS_DEBUG_ADDR"))
-    fprintf(stderr, "[ppals] step roots %d..+%d: src %p (V %p VT %p) X %p L %lld J %lld T %lld\n",
-            first, k, src, V_.data, (void *)VT_, ms_X_.buf, (long long)L, (long long)J, (long long)T);
+    fprintf(stderr, "[ppals] step roots %d..+%d: src %p (layout %d of %d) X %p L %lld J %lld T %lld\n",
+            first, k, src, (int)(pl.lay - lay_.data()), (int)lay_.size(), ms_X_.buf, (long long)L,
+            (long long)J, (long long)T);
   launch_scan(ms_X_off_[first]);
   ms_X_.pending = false;
   ms_X_.valid = true;
   if (const char *tr = std::getenv("PPALS_TRACE_STEPS")) {  // tests: which root sets were scanned
     if (FILE *f = std::fopen(tr, "a")) {
-      std::fprintf(f, "rank=%d root=%d k=%d layout=%s L=%lld J=%lld T=%lld\n", rank_, first, k,
-                   use_t ? "VT" : "V", (long long)L, (long long)J, (long long)T);
+      const int li = (int)(pl.lay - lay_.data());
+      std::fprintf(f, "rank=%d root=%d k=%d layout=%s%s L=%lld J=%lld T=%lld\n", rank_, first, k,
+                   li == 1 ? "VT" : "V", pl.lay->q > 0 ? "pad" : "", (long long)L, (long long)J,
+                   (long long)T);
       std::fclose(f);
     }
   }
@@ -1136,28 +1236,12 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     // level 1 = one tensor scan. Modes of the left half are contracted on the second resident
     // layout, where they sit behind the right half, so that EVERY level-1 scan is a
     // row-contiguous suffix-type scan; the s^(N-1) R result is kept in the tensor's precision.
-    const int mid = (N_ - 1) / 2;
-    bool use_vt = false;
-    if (pp_fast_ && N_ >= 3 && mode <= mid) {
-      ensure_transposed();
-      use_vt = vt_state_ == 1;
-    }
-    std::vector<int> layout;
-    if (use_vt) {
-      for (int m = mid + 1; m < N_; m++) layout.push_back(m);
-      for (int m = 0; m <= mid; m++) layout.push_back(m);
-    } else {
-      for (int m = 0; m < N_; m++) layout.push_back(m);
-    }
-    bool before = true;
-    for (int m : layout) {
-      if (m == mode) {
-        before = false;
-        continue;
-      }
-      (before ? L : T) *= ext(m);
-      op.modes.push_back(m);
-    }
+    ScanPlan pl;
+    if (!plan_scan(mode, 1, !(pp_fast_ && N_ >= 3), pl))
+      throw std::runtime_error("ppals: internal error (single mode not adjacent)");
+    L = pl.Lc;
+    T = pl.T;
+    op.modes = pl.kept;
     op.elems = L * T;
     // (at order 3 a level-1 result already IS a pair operator: those stay fp64 like all the others)
     op.dt = (pp_fast_ && N_ > 3) ? V_.dtype : F64;
@@ -1173,8 +1257,8 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
       op.modes = ms_X_.modes;
     } else {
       op.buf = pp_buffer(seq, dtype_size(op.dt) * (size_t)op.elems * R_);
-      ops_.scan_contract(use_vt ? VT_ : V_.data, V_.dtype, L, ext(mode), T, &f, 1, R_, op.buf,
-                         op.dt, L, op.elems);
+      ops_.scan_contract(pl.lay->ptr, V_.dtype, pl.L, ext(mode), T, &f, 1, R_, op.buf, op.dt, L,
+                         op.elems, pl.pad);
     }
   } else {
     const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));

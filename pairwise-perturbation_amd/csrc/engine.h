@@ -211,10 +211,34 @@ class CpEngine {
   double *sendbuf_ = nullptr, *recvbuf_ = nullptr, *gatherbuf_ = nullptr;
   double *Mbuf_ = nullptr;    // PP: M_i^0 + corrections
   double *Qbuf_ = nullptr, *Pbuf_ = nullptr;  // residual KRP operands
-  void *VT_ = nullptr;        // second resident layout of V: right-half modes fastest
-  int vt_state_ = 0;          // 0 not tried, 1 built, -1 unavailable (disabled / no memory)
-  uint64_t tensor_gen_ = 0;   // generation of the tensor contents VT_ and the caches were built from
-  void ensure_transposed();
+  // Resident storage orders of the local tensor that the scans may read. [0] is the tensor itself.
+  // [1] (if built) lists the right-half modes first, so that contractions of left-half modes are
+  // row-contiguous suffix scans too. When the tensor's column strides are not multiples of 128 B
+  // (s = 50, 324: the reference scripts' shapes) — a scan then runs at 0.61 instead of 0.82 of
+  // peak, profiles/r02s_stride_bench.txt — [1] is stored with its leading block of `q` modes
+  // padded to 128 B, and [2] is such a padded copy in the tensor's own mode order; every root set
+  // at a position >= q of a padded layout reads 128-B aligned columns, and the scan writes its
+  // result compact (RowPad), so nothing else knows about the padding.
+  struct Layout {
+    void *ptr = nullptr;
+    std::vector<int> order;   // modes, fastest first
+    int q = 0;                // leading modes in the padded block (0: not padded)
+    int64_t blk = 0, ld = 0;  // real / stored elements of that block
+    bool owned = false;
+  };
+  std::vector<Layout> lay_;
+  int vt_state_ = 0;          // 0 not tried, 1 second layout built, -1 unavailable (disabled / no memory)
+  uint64_t tensor_gen_ = 0;   // generation of the tensor contents the layouts and caches were built from
+  void ensure_transposed();   // builds lay_[1] (and [2]) once
+  void fill_layout(const Layout &l);
+  // one tensor scan that contracts the (cyclically) consecutive modes first .. first+k-1
+  struct ScanPlan {
+    const Layout *lay = nullptr;
+    int64_t L = 1, Lc = 1, J = 1, T = 1;  // stored / compact rows in front, contracted, behind
+    RowPad pad;
+    std::vector<int> set, kept;  // contracted / kept modes in storage order
+  };
+  bool plan_scan(int first, int k, bool natural_only, ScanPlan &plan);
   void check_tensor_generation();
   // s x R partials up to this size use one all-reduce + redundant update instead of
   // reduce-scatter + row-block update + all-gather (PPALS_COMM_SMALL_BYTES overrides)

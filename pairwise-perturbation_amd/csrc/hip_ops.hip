@@ -400,11 +400,13 @@ class HipOps : public Ops {
   // ------------------------------------------------------------------ scans
   template <typename TV>
   void scan_t(const TV *V, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf, int R,
-              double *out, int64_t out_tstride, int64_t out_rstride, int out32) {
+              double *out, int64_t out_tstride, int64_t out_rstride, int out32, RowPad pad) {
     constexpr int VEC = ScanTraits<TV>::VEC;
     int64_t Jc;
     KrpArgs a = krp_args(f, nf, &Jc);
     if (Jc != J) throw std::runtime_error("ppals: scan_contract factor extents do not match J");
+    if (pad.ld && (L % pad.ld || pad.ld % VEC || pad.valid > pad.ld || pad.valid <= 0 || L == 1))
+      throw std::runtime_error("ppals: scan_contract padded rows inconsistent");
     const bool aligned_base = (((uintptr_t)V) & 15) == 0;
     for (int col0 = 0; col0 < R; col0 += 64) {
       const int ncols = std::min(64, R - col0);
@@ -473,7 +475,8 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(K * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, K, ncols, o, out_tstride, out_rstride, out32);
+                             nsplit, dst_ss, K, ncols, o, out_tstride, out_rstride, out32,
+                             (int64_t)0, (int64_t)0);
           HIP_CHECK(hipGetLastError());
         }
       } else {
@@ -504,17 +507,23 @@ class HipOps : public Ops {
         if (nblocks > 0x7fffffff) throw std::runtime_error("ppals: scan grid too large");
         dim3 grid((unsigned)nblocks);
         prof_begin(0, bytes);
+        // padded layout: the kernel compacts the rows as it stores them — unless the partial sums
+        // of several k-splits go through the slab, which k_slab_reduce compacts
+        const int64_t k_ld = nsplit > 1 ? 0 : pad.ld, k_valid = nsplit > 1 ? 0 : pad.valid;
 #define LAUNCH_SUFFIX(NTv, ALv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld, \
+                     k_valid)
 #define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
   hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld, \
+                     k_valid)
         // persistent launch: ncu*40 workgroups (measured best of 3..40 per CU), each walks over its tiles
         dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
 #define LAUNCH_SUFFIX_BUF(NTv)                                                                     \
   hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks)
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks, \
+                     k_ld, k_valid)
         // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
@@ -543,23 +552,47 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
           hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32);
+                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32, pad.ld,
+                             pad.valid);
           HIP_CHECK(hipGetLastError());
         }
       }
     }
   }
+  using Ops::scan_contract;
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
                      int nf, int R, void *out, int out_dt, int64_t out_tstride,
-                     int64_t out_rstride) override {
+                     int64_t out_rstride, RowPad pad) override {
     RoctxRange roctx_("K1/K2/K8/K11 tensor scan");
     const int out32 = out_dt == F32 ? 1 : 0;
     if (dt == F32)
       scan_t<float>((const float *)V, L, J, T, f, nf, R, (double *)out, out_tstride, out_rstride,
-                    out32);
+                    out32, pad);
     else
       scan_t<double>((const double *)V, L, J, T, f, nf, R, (double *)out, out_tstride,
-                     out_rstride, out32);
+                     out_rstride, out32, pad);
+  }
+  // padded resident layout, see ops.h: a pitched copy (rows == 1) or a transposition whose
+  // destination rows are padded
+  void pad_layout(const void *src, int dt, int64_t rows, int64_t cols, int64_t blk, int64_t ld,
+                  void *dst) override {
+    if (cols % blk || ld < blk) throw std::runtime_error("ppals: pad_layout block inconsistent");
+    const size_t esz = dtype_size(dt);
+    HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)ld * (cols / blk) * rows * esz, st_));
+    if (rows == 1) {
+      HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)ld * esz, src, (size_t)blk * esz, (size_t)blk * esz,
+                                 (size_t)(cols / blk), hipMemcpyDeviceToDevice, st_));
+      return;
+    }
+    const int64_t nb = ((rows + 63) / 64) * ((cols + 63) / 64);
+    if (nb > 0x7fffffff) throw std::runtime_error("ppals: transpose grid too large");
+    if (dt == F32)
+      hipLaunchKernelGGL(k_transpose_pad<float>, dim3((unsigned)nb), dim3(256), 0, st_,
+                         (const float *)src, rows, cols, blk, ld, (float *)dst);
+    else
+      hipLaunchKernelGGL(k_transpose_pad<double>, dim3((unsigned)nb), dim3(256), 0, st_,
+                         (const double *)src, rows, cols, blk, ld, (double *)dst);
+    HIP_CHECK(hipGetLastError());
   }
 
   // ------------------------------------------------------------------ mttv
@@ -839,7 +872,7 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
     if (nsplit > 1) {
       hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(J * J, 256)), dim3(256), 0, st_, dst, nsplit,
-                         J * J, J * J, 1, G, (int64_t)1, (int64_t)0, 0);
+                         J * J, J * J, 1, G, (int64_t)1, (int64_t)0, 0, (int64_t)0, (int64_t)0);
       HIP_CHECK(hipGetLastError());
     }
   }

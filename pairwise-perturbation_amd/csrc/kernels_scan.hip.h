@@ -90,6 +90,28 @@ __device__ inline typename ScanTraits<TV>::vec load_vec(const TV *__restrict__ b
   return v;
 }
 
+// Rows of a padded resident layout (Ops::pad_layout): stored row m is row m % row_ld of block
+// m / row_ld, and only the first row_valid rows of a block exist. The scans read stored rows and
+// write the COMPACT result: `mo` = where the lane's first row lands, `nvalid` = how many of its
+// VEC consecutive rows exist (a lane's rows never straddle a block: row_ld % VEC == 0).
+struct ScanRowMap {
+  int64_t mo;
+  int nvalid;
+};
+template <int VEC>
+__device__ inline ScanRowMap scan_row_map(int64_t m, int64_t M, int64_t row_ld, int64_t row_valid) {
+  ScanRowMap r;
+  if (row_ld == 0) {
+    r.mo = m;
+    r.nvalid = (int)max((int64_t)0, min((int64_t)VEC, M - m));
+  } else {
+    const int64_t q = m / row_ld, rem = m - q * row_ld;
+    r.mo = q * row_valid + rem;
+    r.nvalid = m < M ? (int)max((int64_t)0, min((int64_t)VEC, row_valid - rem)) : 0;
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // suffix scan (K1 / batched single-mode TTM):
 //   out[m + n*out_nstride (+ split/batch offsets)] = sum_{k in split} V[m + M*k (+batch)] * B[k,n]
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols, int out32) {
+    int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -173,6 +195,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
   }
 
   const int64_t obase = split * out_split_stride + batch * out_batch_stride;
+  const ScanRowMap rm = scan_row_map<VEC>(m, M, row_ld, row_valid);
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -183,7 +206,8 @@ __global__ __launch_bounds__(256) void k_scan_suffix(
         for (int jj = 0; jj < VEC; jj++) {
           double val = (double)acc[jj][nt][r];
           if constexpr (TR::NEEDS_FLUSH) val += acc64[jj][nt][r];
-          if (m + jj < M) scan_store(out, obase + (int64_t)n * out_nstride + m + jj, val, out32);
+          if (jj < rm.nvalid)
+            scan_store(out, obase + (int64_t)n * out_nstride + rm.mo + jj, val, out32);
         }
       }
     }
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols, int out32) {
+    int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -417,13 +441,15 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per column
   // (16 lanes x VEC rows = 16*VEC contiguous elements); scalar stores only for unaligned strides
   const int64_t obase = split * out_split_stride + batch * out_batch_stride;
-  const bool vec_ok = (((obase | out_nstride) & (VEC - 1)) == 0);
+  const ScanRowMap rm = scan_row_map<VEC>(m, M, row_ld, row_valid);
+  const bool vec_ok =
+      (((obase | out_nstride | rm.mo) & (VEC - 1)) == 0) && rm.nvalid == VEC;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int n = 16 * nt + TR::row(lane, r);
-      if (n < ncols && m < M) {
+      if (n < ncols && rm.nvalid > 0) {
         double val[VEC];
 #pragma unroll
         for (int jj = 0; jj < VEC; jj++) {
@@ -432,7 +458,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
           else
             val[jj] = (double)acc[jj][nt][r];
         }
-        const int64_t idx = obase + (int64_t)n * out_nstride + m;
+        const int64_t idx = obase + (int64_t)n * out_nstride + rm.mo;
         if (vec_ok && out32) {
           typedef float ovec_t __attribute__((ext_vector_type(VEC)));
           ovec_t ov;
@@ -447,7 +473,8 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
           }
         } else {
 #pragma unroll
-          for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
+          for (int jj = 0; jj < VEC; jj++)
+            if (jj < rm.nvalid) scan_store(out, idx + jj, val[jj], out32);
         }
       }
     }
@@ -482,7 +509,8 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols, int out32, int64_t ntiles) {
+    int64_t out_batch_stride, int ncols, int out32, int64_t ntiles, int64_t row_ld = 0,
+    int64_t row_valid = 0) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -606,13 +634,15 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     }
     // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per
     // column (16 lanes x VEC rows contiguous); scalar stores only for unaligned strides
-    const bool vec_ok = (((cur.obase | out_nstride) & (VEC - 1)) == 0);
+    const ScanRowMap rm = scan_row_map<VEC>(cur.m, M, row_ld, row_valid);
+    const bool vec_ok =
+        (((cur.obase | out_nstride | rm.mo) & (VEC - 1)) == 0) && rm.nvalid == VEC;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = 16 * nt + TR::row(lane, r);
-        if (n < ncols && cur.m < M) {
+        if (n < ncols && rm.nvalid > 0) {
           double val[VEC];
 #pragma unroll
           for (int jj = 0; jj < VEC; jj++) {
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             else
               val[jj] = (double)acc[jj][nt][r];
           }
-          const int64_t idx = cur.obase + (int64_t)n * out_nstride + cur.m;
+          const int64_t idx = cur.obase + (int64_t)n * out_nstride + rm.mo;
           if (vec_ok && out32) {
             typedef float ovec_t __attribute__((ext_vector_type(VEC)));
             ovec_t ov;
@@ -636,7 +666,8 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             }
           } else {
 #pragma unroll
-            for (int jj = 0; jj < VEC; jj++) scan_store(out, idx + jj, val[jj], out32);
+            for (int jj = 0; jj < VEC; jj++)
+              if (jj < rm.nvalid) scan_store(out, idx + jj, val[jj], out32);
           }
         }
       }
@@ -1185,18 +1216,21 @@ __global__ void k_krp_pack(TV *__restrict__ P, int nblk, int NT, int prefix_layo
   }
 }
 
-// out[m*out_mstride + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols
+// out[m'*out_mstride + out_rstride*n] = sum_s slab[s*split_stride + n*M + m],  n < ncols;
+// m' = m, or the compact row of stored row m of a padded layout (scan_row_map)
 __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64_t split_stride,
                               int64_t M, int ncols, double *__restrict__ out, int64_t out_mstride,
-                              int64_t out_rstride, int out32) {
+                              int64_t out_rstride, int out32, int64_t row_ld, int64_t row_valid) {
   const int64_t total = M * ncols;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = e % M;
     const int64_t n = e / M;
+    const ScanRowMap rm = scan_row_map<1>(m, M, row_ld, row_valid);
+    if (rm.nvalid == 0) continue;
     double s = 0;
     for (int sp = 0; sp < nsplit; sp++) s += slab[sp * split_stride + e];
-    scan_store(out, m * out_mstride + out_rstride * n, s, out32);
+    scan_store(out, rm.mo * out_mstride + out_rstride * n, s, out32);
   }
 }
 

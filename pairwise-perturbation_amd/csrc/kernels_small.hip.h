@@ -219,6 +219,33 @@ __global__ __launch_bounds__(256) void k_transpose(const TV *__restrict__ src, i
   }
 }
 
+// the same transposition into a padded layout (Ops::pad_layout): column index c of the source is
+// the fast index of the destination, stored in blocks of `blk` padded to `ld`:
+//   dst[(c % blk) + ld*(c / blk + (cols / blk)*r)] = src[r + rows*c]
+template <typename TV>
+__global__ __launch_bounds__(256) void k_transpose_pad(const TV *__restrict__ src, int64_t rows,
+                                                       int64_t cols, int64_t blk, int64_t ld,
+                                                       TV *__restrict__ dst) {
+  __shared__ TV tile[64][65];
+  const int64_t tiles_r = (rows + 63) / 64;
+  const int64_t r0 = (int64_t)(blockIdx.x % tiles_r) * 64, c0 = (int64_t)(blockIdx.x / tiles_r) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t nblkc = cols / blk;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+    if (r < rows && c < cols) tile[ty + 4 * i][tx] = src[r + rows * c];
+  }
+  __syncthreads();
+  const int64_t c = c0 + tx;
+  const int64_t cq = c / blk, cr = c - cq * blk;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int64_t r = r0 + ty + 4 * i;
+    if (r < rows && c < cols) dst[cr + ld * (cq + nblkc * r)] = tile[tx][ty + 4 * i];
+  }
+}
+
 template <typename TV>
 __global__ void k_unpack_shards(const char *__restrict__ stage, int64_t s0, int64_t rest,
                                 int64_t blk, int P, int64_t chunk_bytes, TV *__restrict__ full) {

@@ -15,6 +15,11 @@ namespace ppals {
 enum DType { F32 = 0, F64 = 1 };
 inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 8; }
 
+// row blocks of a padded layout: `ld` stored rows per block, the first `valid` of them real
+struct RowPad {
+  int64_t ld = 0, valid = 0;  // ld == 0: not padded
+};
+
 constexpr int MAX_ORDER = 8;
 
 // a factor-matrix operand of a Khatri-Rao product: `rows` rows starting at `ptr`, leading dim ld
@@ -97,6 +102,12 @@ class Ops {
     for (int64_t b = 0; b < batch; b++)
       transpose2d((const char *)src + b * step, dt, rows, cols, (char *)dst + b * step);
   }
+  // A resident layout whose leading block of `blk` elements is padded to `ld` (a multiple of
+  // 128 B), optionally transposing on the way:
+  //   dst[(c % blk) + ld*(c / blk + (cols / blk)*r)] = src[r + rows*c]    (cols % blk == 0)
+  // rows == 1 is a plain pitched copy. Pad elements are set to zero. See CpEngine::build_layouts.
+  virtual void pad_layout(const void *src, int dt, int64_t rows, int64_t cols, int64_t blk,
+                          int64_t ld, void *dst) = 0;
   // full[a + s0*c] = stage_p[(a - p*blk) + l_p*c] for the rank p that owns row a (l_p rows each,
   // element type dt); stage_p starts at byte offset p*chunk_bytes. Re-assembles the leading-mode
   // shards of a tensor after an all-gather (Tucker HOSVD of the sharded mode).
@@ -117,9 +128,18 @@ class Ops {
   // cached fp64 intermediate (dt = F64).
   // The result is written as fp64 (out_dt = F64) or fp32 (out_dt = F32, used for the large
   // first-level intermediate of the multi-sweep schedule).
+  // A PADDED resident layout (pad_layout below) stores its rows in blocks of `pad.ld` of which the
+  // first `pad.valid` exist: L then counts the stored rows (a multiple of pad.ld), and the result
+  // is written COMPACT — stored row l lands at (l / ld) * valid + l % ld, the pad rows nowhere —
+  // so nothing downstream of a scan knows about the padding.
   virtual void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T,
                              const FactorRef *f, int nf, int R, void *out, int out_dt,
-                             int64_t out_tstride, int64_t out_rstride) = 0;
+                             int64_t out_tstride, int64_t out_rstride, RowPad pad) = 0;
+  void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
+                     int nf, int R, void *out, int out_dt, int64_t out_tstride,
+                     int64_t out_rstride) {
+    scan_contract(V, dt, L, J, T, f, nf, R, out, out_dt, out_tstride, out_rstride, RowPad());
+  }
   // Tucker mode product keeping the mode in place (fp64 in/out or V-typed in):
   //   out[l + L*(k + Kc*t)] = sum_j X[l,j,t] * W[j + ldw*k]      (als_Tucker.cxx:102,224)
   virtual void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,

@@ -205,20 +205,37 @@ class HostOps : public Ops {
     std::vector<double> B = krp_mat(f, nf, col0, ncols, &J);
     std::copy(B.begin(), B.end(), out);
   }
+  using Ops::scan_contract;
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
-                     int nf, int R, void *out, int out_dt, int64_t ts, int64_t rs) override {
+                     int nf, int R, void *out, int out_dt, int64_t ts, int64_t rs,
+                     RowPad pad) override {
     int64_t Jc;
     std::vector<double> B = krp_mat(f, nf, 0, R, &Jc);
     if (Jc != J) throw std::runtime_error("hostsim: scan_contract extent mismatch");
+    if (pad.ld && (L % pad.ld || pad.valid > pad.ld))
+      throw std::runtime_error("hostsim: scan_contract padded rows inconsistent");
     prof[0].launches++;
     prof[0].bytes += (double)L * J * T * dtype_size(dt);
     for (int r = 0; r < R; r++)
       for (int64_t t = 0; t < T; t++)
         for (int64_t l = 0; l < L; l++) {
+          int64_t lo = l;
+          if (pad.ld) {
+            if (l % pad.ld >= pad.valid) continue;
+            lo = (l / pad.ld) * pad.valid + l % pad.ld;
+          }
           double acc = 0;
           for (int64_t j = 0; j < J; j++) acc += ld(V, dt, l + L * (j + J * t)) * B[j + J * r];
-          st(out, out_dt, l + ts * t + rs * r, acc);
+          st(out, out_dt, lo + ts * t + rs * r, acc);
         }
+  }
+  void pad_layout(const void *src, int dt, int64_t rows, int64_t cols, int64_t blk, int64_t ldp,
+                  void *dst) override {
+    if (cols % blk) throw std::runtime_error("hostsim: pad_layout block does not divide cols");
+    std::memset(dst, 0, (size_t)ldp * (cols / blk) * rows * dtype_size(dt));
+    for (int64_t c = 0; c < cols; c++)
+      for (int64_t r = 0; r < rows; r++)
+        st(dst, dt, (c % blk) + ldp * (c / blk + (cols / blk) * r), ld(src, dt, r + rows * c));
   }
   void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W,
                 int64_t ldw, int Kc, double *out) override {

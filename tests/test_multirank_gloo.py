@@ -19,8 +19,10 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_sharded_engine_matches_oracle(world):
+@pytest.mark.parametrize("world,padded", [(2, False), (3, False), (4, False), (2, True)])
+def test_sharded_engine_matches_oracle(world, padded):
+    """padded: the same run with the padded resident layouts forced on (their leading block holds
+    the LOCAL rows of the partitioned mode)"""
     import hostsim_util
     hostsim_util.load()  # build once, before the ranks race for it
     port = free_port()
@@ -28,6 +30,8 @@ def test_sharded_engine_matches_oracle(world):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        if padded:
+            env.update(PPALS_PAD_LAYOUT="1", PPALS_PAD_WASTE="100")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "hostsim_rank.py")],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
