@@ -359,7 +359,7 @@ CpEngine::~CpEngine() {
 // root positions 128-B aligned than the plain order has (q < first aligned position) at a cost of
 // at most PPALS_PAD_WASTE (default 3 %) extra bytes — s = 50: 2500 -> 2528 elements, +1.1 %.
 // PPALS_PAD_LAYOUT=0 never pads, =1 pads whatever the tensor's size (tests); by default tensors
-// below 1 GB are left alone. The padded copy in the tensor's own order is a THIRD copy of the
+// below 100 MB are left alone. The padded copy in the tensor's own order is a THIRD copy of the
 // tensor: built only if the allocation succeeds.
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -386,7 +386,7 @@ void CpEngine::ensure_transposed() {
   if (const char *e = std::getenv("PPALS_PAD_LAYOUT")) pad_mode = std::atoi(e);
   double max_waste = 0.03;
   if (const char *e = std::getenv("PPALS_PAD_WASTE")) max_waste = std::atof(e);
-  const bool may_pad = pad_mode == 1 || (pad_mode != 0 && (double)V_.nloc * esz >= 1e9);
+  const bool may_pad = pad_mode == 1 || (pad_mode != 0 && (double)V_.nloc * esz >= 1e8);
   // leading block of a storage order worth padding: the smallest q whose padding is cheap, if the
   // plain order has no aligned position that early
   auto choose_pad = [&](Layout &l, int qmax) {
