@@ -1,0 +1,135 @@
+"""Seeded random campaign over the knobs that choose code paths: order, extents (tile edges,
+unaligned row counts), rank (one / two / four n-tiles), storage type, sweep schedule, number of
+root modes, padded resident layouts on or off — CP exact sweeps, the PP driver and Tucker HOOI
+against the fp64 oracle. The default run is a dozen cases; a campaign sets PPALS_FUZZ_CASES (and
+PPALS_FUZZ_SEED) — e.g. 2000 (profiles/README.md)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import test_gpu_cp as G
+import test_gpu_tucker as GT
+
+pytestmark = pytest.mark.gpu
+
+NCASES = int(os.environ.get("PPALS_FUZZ_CASES", "12"))
+SEED = int(os.environ.get("PPALS_FUZZ_SEED", "20261004"))
+
+
+@pytest.fixture(scope="module")
+def pp():
+    import ppals
+    return ppals
+
+
+@pytest.fixture(scope="module")
+def ctx(pp):
+    c = pp.Context(0)
+    yield c
+    c.close()
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.integers(3, 7))
+        big = rng.random() < 0.5
+        lens = [int(rng.integers(2, 70 if big else 12)) for _ in range(N)]
+        size = int(np.prod(lens))
+        if size > 2.5e6 or size < 500:
+            continue
+        R = min(int(rng.choice([1, 2, 3, 5, 8, 10, 16, 17, 24, 33, 40])), min(lens))
+        out.append(dict(lens=lens, R=R, dtype=int(rng.integers(0, 2)),
+                        sched=str(rng.choice(["dt", "msdt"])), roots=int(rng.integers(0, 4)),
+                        pad=int(rng.integers(0, 2)), kind=str(rng.choice(["r", "r2"])),
+                        seed=int(rng.integers(0, 1 << 30))))
+    return out
+
+
+def _setenv(monkeypatch, c):
+    if c["roots"] > 0 and c["roots"] <= len(c["lens"]) - 2:
+        monkeypatch.setenv("PPALS_MSDT_ROOTS", str(c["roots"]))
+    monkeypatch.setenv("PPALS_PAD_LAYOUT", str(c["pad"]))
+    monkeypatch.setenv("PPALS_PAD_WASTE", "100")
+
+
+@pytest.mark.parametrize("c", _cases(NCASES, SEED), ids=lambda c: "-".join(map(str, c["lens"])) + f"-R{c['R']}")
+def test_cp_sweeps(pp, ctx, c, monkeypatch):
+    _setenv(monkeypatch, c)
+    lens, R, dtype = c["lens"], c["R"], c["dtype"]
+    V, W = G.problem(lens, R, c["seed"] % 1000, c["kind"])
+    Gr = O.init_factors(lens, R, 7 + c["seed"] % 100)
+    K = 3
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, Gr, tol=0.0, maxiter=K - 1, resprint=1000)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_schedule(c["sched"])
+    s.set_factors(W, Gr)
+    for m in range(len(lens)):
+        assert G.relerr(s.mttkrp(m), O.mttkrp(V, W, m, 0)) < G.KTOL[dtype], (c, m)
+    s.sweeps_dt(K)
+    W_got, _ = s.get_factors(with_grad=True)
+    # ill-conditioned random problems amplify storage rounding: compare through the residual too
+    r_got, r_ref = O.residual(V, W_got), O.residual(V, W_ref)
+    assert abs(r_got - r_ref) < (1e-6 if dtype == 1 else 1e-3) * max(r_ref, 1e-3 * np.linalg.norm(V)), c
+    if c["kind"] == "r" and dtype == 1:
+        for a, b in zip(W_got, W_ref):
+            assert G.relerr(a, b) < 1e-6, (c, G.relerr(a, b))
+    s.close()
+    t.close()
+
+
+@pytest.mark.parametrize("c", _cases(max(2, NCASES // 3), SEED + 1),
+                         ids=lambda c: "-".join(map(str, c["lens"])) + f"-R{c['R']}")
+def test_cp_pp_driver(pp, ctx, c, monkeypatch, tmp_path):
+    _setenv(monkeypatch, c)
+    lens, R = c["lens"], min(c["R"], 6)
+    V, W = G.problem(lens, R, c["seed"] % 1000, "r")
+    Gr = O.init_factors(lens, R, 97)
+    Vn = np.linalg.norm(V)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    kw = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=25, resprint=1)
+    O.als_cp_pp(V, W, Gr, csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, 1).upload(V)
+    Wl = [w.copy(order="F") for w in W]
+    Gl = [g.copy(order="F") for g in Gr]
+    pp.alsCP_PP(t, Wl, Gl, kw["tol"], kw["tol_init"], 5e3, kw["maxiter"], 0.0, 1.0, c_got, 1,
+                False, ctx)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    n = min(len(r1), len(r2))
+    for a, b in zip(r1[:n], r2[:n]):
+        if a[5] < 1e-4 * Vn:
+            break
+        assert a[1] == b[1] and a[4] == b[4], (c, a, b)
+        assert abs(a[5] - b[5]) <= 1e-5 * abs(a[5]) + 1e-9 * Vn, (c, a, b)
+    t.close()
+
+
+@pytest.mark.parametrize("c", [x for x in _cases(max(2, NCASES // 3), SEED + 2) if len(x["lens"]) <= 5],
+                         ids=lambda c: "-".join(map(str, c["lens"])))
+def test_tucker_sweeps(pp, ctx, c, monkeypatch, tmp_path):
+    lens = c["lens"]
+    rng = np.random.default_rng(c["seed"])
+    ranks = [int(rng.integers(1, max(2, min(s, 6)))) for s in lens]
+    for i, r in enumerate(ranks):   # a rank above the product of the others is ill-posed
+        ranks[i] = min(r, int(np.prod([q for j, q in enumerate(ranks) if j != i])))
+    inner = [min(s, r + 2) for s, r in zip(lens, ranks)]
+    V = GT._decaying_tensor(lens, inner, c["seed"] % 997, 0.02)
+    W0, c0 = O.hosvd(V, ranks)
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=3)
+    t = pp.Tensor(ctx, lens, c["dtype"]).upload(V)
+    s = pp.Tucker(ctx, t, ranks)
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.run_dt(tol=0.0, maxiter=3)
+    W, core = s.get_factors()
+    tol = 5e-4 if c["dtype"] == 0 else 1e-7
+    for a, r in zip(W, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9), c
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < tol * np.linalg.norm(core_ref), c
+    s.close()
+    t.close()
