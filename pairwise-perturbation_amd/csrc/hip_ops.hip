@@ -89,8 +89,6 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_power_step1,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
   }
   ~HipOps() override {
     hipSetDevice(dev_);
@@ -108,6 +106,9 @@ class HipOps : public Ops {
     if (ws_big2_) hipFree(ws_big2_);
     if (ws_eig_) hipFree(ws_eig_);
     if (ws_orth_) hipFree(ws_orth_);
+    if (ws_pow_) hipFree(ws_pow_);
+    if (eig_host_) hipHostFree(eig_host_);
+    if (ws_part2_) hipFree(ws_part2_);
     for (auto &es : eig_state_) {
       if (es.Q) hipFree(es.Q);
       if (es.ev) hipFree(es.ev);
@@ -904,11 +905,11 @@ class HipOps : public Ops {
     int64_t J = 0;
     int rank = 0;
     bool valid = false;
-    double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, ||G - sigma I||_F last time
+    double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, largest eigenvalue
+    double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
     double *Q = nullptr;                  // previous basis (J x rank)
     double *ev = nullptr;                 // eigenvalues of the last Rayleigh-Ritz step (device)
     double evh[64] = {0};                 // ... and on the host (descending), once read back
-    bool ev_pending = false;
     int fast = 0, full = 0;
   };
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
@@ -945,13 +946,17 @@ class HipOps : public Ops {
     es.J = J;
     es.rank = rank;
     HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
-    es.ev_pending = false;
+    es.rho_frob = 0;  // the next projector step reads its norm once
     es.valid = es.lamR > 0 && es.lamR1 >= 0 && es.lamR > es.lamR1 * (1 + 1e-9);
   }
-  // Z (J x r) -> orthonormal columns, Cholesky QR twice; returns the buffer holding the result
-  double *chol_qr2(double *cur, double *nxt, int64_t J, int r, double *C, int *status) {
+  // Z (J x r) -> orthonormal columns, Cholesky QR twice (status 2 of a pass = "far from
+  // orthonormal" is no failure here: the second pass repairs it); returns the buffer holding the
+  // result. npass = 1: for a Z that is close to orthonormal already — the caller must treat ANY
+  // non-zero status as a failure then.
+  double *chol_qr2(double *cur, double *nxt, int64_t J, int r, double *C, int *status,
+                   int npass = 2) {
     const size_t lds_chol = sizeof(double) * 2 * (size_t)r * r;
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < npass; pass++) {
       hipLaunchKernelGGL(k_tn_small, dim3((r * r + 15) / 16), dim3(1024), 0, st_, cur, cur, J, r, C);
       hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(64), lds_chol, st_, C, r, status + pass);
       hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * r, 256)), dim3(256),
@@ -987,8 +992,8 @@ class HipOps : public Ops {
     int hs[2 * 32];
     HIP_CHECK(hipMemcpyAsync(hs, status, sizeof(int) * 2 * nblk, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
-    for (int e = 0; e < 2 * nblk; e++)
-      if (hs[e]) return false;
+    for (int b = 0; b < nblk; b++)  // first pass: 2 = "far from orthonormal" is what the second is for
+      if (hs[2 * b] == 1 || hs[2 * b + 1] != 0) return false;
     return true;
   }
   // Rayleigh-Ritz of G on the orthonormal basis B (J x r): U = eigenvectors sorted descending,
@@ -1014,19 +1019,15 @@ class HipOps : public Ops {
     }
     EigState &es = eig_state_[slot];
     if (es.valid && (es.J != J || es.rank != rank)) es.valid = false;
-    if (es.valid && es.ev_pending) {  // eigenvalues of the slot's previous Rayleigh-Ritz step
-      HIP_CHECK(hipMemcpyAsync(es.evh, es.ev, sizeof(double) * rank, hipMemcpyDeviceToHost, st_));
-      HIP_CHECK(hipStreamSynchronize(st_));
-      const double shift = es.evh[rank - 1] - es.lamR;
-      es.lamR = es.evh[rank - 1];
-      es.lamR1 = std::min(std::max(0.0, es.lamR1 + shift), es.lamR);
-      es.ev_pending = false;
-      if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;
-    }
     if (!es.valid) {
       eig_bootstrap(es, G, J, rank, U);
       return;
     }
+    // The whole step is enqueued without a read-back: what the host needs in order to schedule it
+    // (where the gap lies, the scale of the shifted matrix) it knows from the previous call of the
+    // slot, and everything that decides whether the result is accepted (||X^2 - I||, trace(P),
+    // Cholesky pivots, eigenpair residual) is read once, at the end, together with the new
+    // eigenvalues and the norm the next call will schedule with.
     const int Ji = (int)J;
     const size_t nJJ = (size_t)J * J, nJR = (size_t)J * rank;
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
@@ -1034,9 +1035,13 @@ class HipOps : public Ops {
     double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
     double *Ot = Y + nJJ, *Z = Ot + nJR, *Z2 = Z + nJR, *GZ = Z2 + nJR, *Ut = GZ + nJR,
            *GU = Ut + nJR, *QD = GU + nJR, *QD2 = QD + nJR;
+    // the tail of the workspace is what the one read-back fetches in a single copy:
+    //   chk[16] (0,1: sign check, 4: residual, 8: ||.||_F^2) | evW[64] | status[8 ints] | lamD[64]
     double *C = QD2 + nJR, *H = C + 64 * 64, *Yr = H + 64 * 64, *chk = Yr + 64 * 64,
-           *lamD = chk + 16;
-    int *status = (int *)(lamD + 64);
+           *evW = chk + 16;
+    int *status = (int *)(evW + 64);
+    double *lamD = evW + 64 + 4;
+    constexpr size_t kReadback = sizeof(double) * (16 + 64) + sizeof(int) * 8;
     HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
     const double sigma = 0.5 * (es.lamR + es.lamR1);
     // ---- dominant eigenpairs (a relative gap >= 20 above the rest of the wanted ones): refined
@@ -1051,20 +1056,24 @@ class HipOps : public Ops {
         ratio = es.evh[d] / es.evh[d - 1];
       }
     double tau = 0;
-    if (m == 1 && J <= 4096) {
-      // one dominant eigenpair (a tensor with a mean component): single-workgroup power steps;
-      // the last one also leaves the Rayleigh quotient of its (converged) input
-      // the previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
+    if (m == 1) {
+      // one dominant eigenpair (a tensor with a mean component): power steps on one vector. The
+      // previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
       // Rayleigh quotient left by the last step is that of its input: second order in its error.
       const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-15) / std::log(ratio)))) + 1;
+      const int nb = (int)((J + 7) / 8);
+      double *pw = (double *)ensure(ws_pow_, ws_pow_sz_, sizeof(double) * 4 * (size_t)nb);
+      double *pbuf[2] = {pw, pw + 2 * (size_t)nb};
+      double *ybuf[2] = {QD2, Z2};  // (Z2 is free until the Cholesky QR of the projected basis)
       const double *src = es.Q;
-      double *bufs[2] = {QD, QD2};
-      const size_t lds = sizeof(double) * (2 * (size_t)J + 17);
+      const double *pin = nullptr;
       for (int it = 0; it < nsteps; it++) {
-        hipLaunchKernelGGL(k_power_step1, dim3(1), dim3(1024), lds, st_, G, J, src, bufs[it & 1], lamD);
-        src = bufs[it & 1];
+        hipLaunchKernelGGL(k_power_mv, dim3(nb), dim3(256), 0, st_, G, J, src, pin, nb, ybuf[it & 1],
+                           pbuf[it & 1]);
+        src = ybuf[it & 1];
+        pin = pbuf[it & 1];
       }
-      if (src != QD) HIP_CHECK(hipMemcpyAsync(QD, src, sizeof(double) * J, hipMemcpyDeviceToDevice, st_));
+      hipLaunchKernelGGL(k_power_finish, dim3(1), dim3(256), 0, st_, src, J, pin, nb, QD, lamD);
       tau = es.lamR * 1.5 + 1e-300;
     } else if (m > 0) {
       const int nsteps = std::min(14, std::max(3, (int)std::ceil(std::log(1e-18) / std::log(ratio))));
@@ -1083,32 +1092,41 @@ class HipOps : public Ops {
       tau = es.lamR * 1.5 + 1e-300;  // still above sigma: they keep counting as "wanted"
     }
     // X = (G - deflation - sigma I) / rho, rho = its Frobenius norm >= every |eigenvalue| (safe:
-    // an eigenvalue of the scaled matrix beyond 1 would be folded back by the scaled iteration)
+    // an eigenvalue of the scaled matrix beyond 1 would be folded back by the scaled iteration).
+    // The norm stays on the device; the host schedules the iteration with the norm of the slot's
+    // previous call (the matrices of consecutive HOOI sweeps differ by a few per cent at most, and
+    // an under-estimated lower bound `ell` only costs a fraction of an iteration).
     const int gdef = grid_for(nJJ, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * (gdef + 1));
+    double *fro2_d = chk + 8;
     hipLaunchKernelGGL(k_deflate_shift, dim3(gdef), dim3(256), 0, st_, G, J, QD, m, lamD, tau, sigma,
                        X, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, gdef, part + gdef);
-    double fro2 = 0;
-    HIP_CHECK(hipMemcpyAsync(&fro2, part + gdef, sizeof(double), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipStreamSynchronize(st_));
-    const double rho = 1.0001 * std::sqrt(fro2);
-    if (!(rho > 0) || !std::isfinite(rho)) {
-      es.valid = false;
-      eig_bootstrap(es, G, J, rank, U);
-      return;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, gdef, fro2_d);
+    double rho = es.rho_frob;
+    if (!(rho > 0)) {  // first projector step of the slot: read the norm
+      double fro2 = 0;
+      HIP_CHECK(hipMemcpyAsync(&fro2, fro2_d, sizeof(double), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      rho = 1.0001 * std::sqrt(fro2);
+      if (!(rho > 0) || !std::isfinite(rho)) {
+        es.valid = false;
+        eig_bootstrap(es, G, J, rank, U);
+        return;
+      }
     }
-    hipLaunchKernelGGL(k_scale_inplace, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X,
-                       (int64_t)nJJ, 1.0 / rho);
-    const double ell0 = 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
-    es.rho = rho;
+    hipLaunchKernelGGL(k_scale_by_frob, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, (int64_t)nJJ,
+                       fro2_d);
+    const double ell0 = 0.9 * 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
     double ell = std::max(ell0, 1e-14);
     int iters = 0;
+    const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
     auto ns_step = [&](double mu) {
-      gemm_nt(X, J, X, J, nullptr, 0, Y, J, Ji, Ji, Ji, 1.0, 0.0);                      // Y = X^2
-      gemm_nt(X, J, Y, J, X, J, Xn, J, Ji, Ji, Ji, -0.5 * mu * mu * mu, 1.5 * mu);        // X(aI+bX^2)
+      // Y = X^2, X <- X (a I + b X^2): symmetric products, stored symmetric bit for bit
+      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
+                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
+      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, Y, J, X, J, Xn, J, Ji, Ji,
+                         -0.5 * mu * mu * mu, 1.5 * mu);
       std::swap(X, Xn);
-      hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, J);
       iters++;
     };
     while (1.0 - ell > 1e-3 && iters < 80) {
@@ -1117,79 +1135,79 @@ class HipOps : public Ops {
       ell = 0.5 * mu * ell * (3.0 - mu * mu * ell * ell);
     }
     for (int k = 0; k < 2; k++) ns_step(1.0);
-    bool ok = false;
-    for (int attempt = 0; attempt < 3 && !ok; attempt++) {
-      gemm_nt(X, J, X, J, nullptr, 0, Y, J, Ji, Ji, Ji, 1.0, 0.0);
+    const double gap = es.lamR - es.lamR1;
+    for (int attempt = 0;; attempt++) {
+      // ---- check of the sign iteration: ||X^2 - I||_F^2 and trace(X) (-> chk[0], chk[1])
+      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
+                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
       {
         const int gc = grid_for(nJJ, 256, 256);
-        double *pc = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * (2 * gc + 2));
+        double *pc = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * gc + 2));
         hipLaunchKernelGGL(k_sign_check, dim3(gc), dim3(256), 0, st_, Y, X, J, pc);
         hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st_, pc, gc, chk);
       }
-      double h[2];
-      HIP_CHECK(hipMemcpyAsync(h, chk, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
+      // ---- Z = P * Omega = (Omega + X Omega) / 2 with the previous basis, Cholesky-QR twice, then
+      // Rayleigh-Ritz inside the subspace: the eigenvectors one by one, sorted descending
+      // (the deflated directions come from the power iteration, accurate to machine precision: the
+      // projector of the DEFLATED matrix carries them only to eps * lambda_1 / gap. So the basis is
+      // [Q_D | (I - Q_D Q_D^T) P Omega_rest].)
+      transpose2d(es.Q, F64, J, rank, Ot);  // Omega^T (rank x J): coalesced B operand
+      gemm_nt(X, J, Ot, rank, es.Q, J, Z, J, Ji, rank, Ji, 0.5, 0.5);
+      if (m > 0) {
+        double *Zr = Z + (size_t)J * m;
+        const int nz = rank - m;
+        for (int pass = 0; pass < 2; pass++) {
+          hipLaunchKernelGGL(k_tn_rect, dim3((m * nz + 15) / 16), dim3(1024), 0, st_, QD, m, Zr, nz, J, H);
+          hipLaunchKernelGGL(k_sub_mult, dim3(grid_for((int64_t)J * nz, 256)), dim3(256), 0, st_, Zr, J,
+                             nz, QD, m, H);
+        }
+        HIP_CHECK(hipMemcpyAsync(Z, QD, sizeof(double) * J * m, hipMemcpyDeviceToDevice, st_));
+      }
+      // (P Omega is within a HOOI sweep's change of orthonormal: one pass, verified by status)
+      double *B = chol_qr2(Z, Z2, J, rank, C, status, 1);
+      rayleigh_ritz(G, B, J, rank, Ut, GZ, H, Yr, U, evW, GU);
+      hipLaunchKernelGGL(k_eig_residual, dim3(1), dim3(1024), 0, st_, GU, U, evW, J, rank, chk + 4);
+      // ---- the one read-back of the step (one copy into pinned memory)
+      if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
+      HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
-      const double cnt = 0.5 * (h[1] + (double)J);
+      HIP_CHECK(hipGetLastError());
+      const double *hc = (const double *)eig_host_, *evn = hc + 16;
+      const int *hs = (const int *)(evn + 64);
+      const double cnt = 0.5 * (hc[1] + (double)J), res = std::sqrt(hc[4]);
+      const double rho_now = 1.0001 * std::sqrt(hc[8]);
+      const bool converged = hc[0] <= 1e-20 * (double)J;
+      // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
+      // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
+      const double res_tol = std::max(1e-9 * gap, 1e-14 * es.evh[0]) * std::sqrt((double)rank);
+      const bool good = converged && std::fabs(cnt - rank) < 1e-6 && hs[0] == 0 && hs[2] != 1 && hs[3] == 0 &&
+                        res <= res_tol && std::isfinite(rho_now);
       if (eig_debug_)
-        fprintf(stderr, "[ppals eig]   check %d: ||X^2-I||^2 %.3e count %.6f\n", attempt, h[0], cnt);
-      if (h[0] <= 1e-20 * (double)J) {
-        ok = std::fabs(cnt - rank) < 1e-6;  // converged: exactly `rank` eigenvalues above sigma?
-        break;
+        fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
+                        "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
+                        "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
+                slot, (long long)J, rank, es.lamR, es.lamR1, m, rho, rho_now, ell0, iters, hc[0], cnt,
+                res, gap, hs[0], hs[1], hs[2], hs[3],
+                good ? "accepted" : (converged ? "full solver" : "more steps"), es.fast, es.full);
+      if (good) {
+        for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
+        const double shift = evn[rank - 1] - es.lamR;
+        es.lamR = evn[rank - 1];
+        es.lamR1 = std::min(std::max(0.0, es.lamR1 + shift), es.lamR);
+        es.rho_frob = rho_now;
+        if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;  // next call: full solver
+        HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
+        es.fast++;
+        return;
       }
-      ns_step(1.0);  // the gap was narrower than estimated
+      if (converged || attempt >= 2) break;
+      ns_step(1.0);  // the gap was narrower than estimated: two more steps, then the tail again
       ns_step(1.0);
+      HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), st_));  // (the Cholesky QR of the tail)
     }
-    if (eig_debug_)
-      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
-                      "ell0 %.2e iters %d ok %d (fast %d full %d)\n", slot, (long long)J, rank,
-              es.lamR, es.lamR1, m, rho, ell0, iters, (int)ok, es.fast, es.full);
-    if (!ok) {  // sigma no longer separates rank eigenvalues (or no convergence): full solver
-      es.valid = false;
-      eig_bootstrap(es, G, J, rank, U);
-      return;
-    }
-    // Z = P * Omega = (Omega + X Omega) / 2 with the previous basis, Cholesky-QR twice, then
-    // Rayleigh-Ritz inside the subspace: the eigenvectors one by one, sorted descending
-    // (the deflated directions come from the power iteration, accurate to machine precision: the
-    // projector of the DEFLATED matrix carries them only to eps * lambda_1 / gap. So the basis is
-    // [Q_D | (I - Q_D Q_D^T) P Omega_rest].)
-    transpose2d(es.Q, F64, J, rank, Ot);  // Omega^T (rank x J): coalesced B operand
-    gemm_nt(X, J, Ot, rank, es.Q, J, Z, J, Ji, rank, Ji, 0.5, 0.5);
-    if (m > 0) {
-      double *Zr = Z + (size_t)J * m;
-      const int nz = rank - m;
-      for (int pass = 0; pass < 2; pass++) {
-        hipLaunchKernelGGL(k_tn_rect, dim3((m * nz + 15) / 16), dim3(1024), 0, st_, QD, m, Zr, nz, J, H);
-        hipLaunchKernelGGL(k_sub_mult, dim3(grid_for((int64_t)J * nz, 256)), dim3(256), 0, st_, Zr, J,
-                           nz, QD, m, H);
-      }
-      HIP_CHECK(hipMemcpyAsync(Z, QD, sizeof(double) * J * m, hipMemcpyDeviceToDevice, st_));
-    }
-    double *B = chol_qr2(Z, Z2, J, rank, C, status);
-    rayleigh_ritz(G, B, J, rank, Ut, GZ, H, Yr, U, es.ev, GU);
-    hipLaunchKernelGGL(k_eig_residual, dim3(1), dim3(1024), 0, st_, GU, U, es.ev, J, rank, chk + 4);
-    int hs[8];
-    double res2 = 0;
-    HIP_CHECK(hipMemcpyAsync(hs, status, 8 * sizeof(int), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(&res2, chk + 4, sizeof(double), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipStreamSynchronize(st_));
-    HIP_CHECK(hipGetLastError());
-    const double gap = es.lamR - es.lamR1;
-    // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
-    // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
-    const double res_tol = std::max(1e-9 * gap, 1e-14 * es.evh[0]) * std::sqrt((double)rank);
-    const bool good = !(hs[0] | hs[1] | hs[2] | hs[3]) && std::sqrt(res2) <= res_tol;
-    if (eig_debug_)
-      fprintf(stderr, "[ppals eig]   residual %.3e (gap %.3e) chol %d%d%d%d -> %s\n", std::sqrt(res2),
-              gap, hs[0], hs[1], hs[2], hs[3], good ? "accepted" : "full solver");
-    if (!good) {  // lost a direction / deflation not accurate enough: the full solver decides
-      es.valid = false;
-      eig_bootstrap(es, G, J, rank, U);
-      return;
-    }
-    HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
-    es.ev_pending = true;
-    es.fast++;
+    // sigma no longer separates `rank` eigenvalues, a lost direction, no convergence: full solver
+    es.valid = false;
+    eig_bootstrap(es, G, J, rank, U);
   }
   double frob_shifted(const double *G, int64_t J, double sigma) {
     const int g = grid_for(J * J, 256, 1024);
@@ -1295,8 +1313,9 @@ class HipOps : public Ops {
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)
   EigState eig_state_[16];
-  void *ws_eig_ = nullptr, *ws_orth_ = nullptr;
-  size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0;
+  void *eig_host_ = nullptr;  // pinned: the read-back of a projector step
+  void *ws_eig_ = nullptr, *ws_orth_ = nullptr, *ws_pow_ = nullptr, *ws_part2_ = nullptr;
+  size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;
   hipStream_t st_ = nullptr;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;

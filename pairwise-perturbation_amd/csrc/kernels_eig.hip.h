@@ -9,7 +9,7 @@
 //   P = (I + sign(G - sigma I)) / 2,  sigma inside the gap below the rank-th eigenvalue,
 // is the orthogonal projector onto that subspace, and sign() is computed with the scaled
 // Newton-Schulz iteration X <- 1/2 mu X (3 I - mu^2 X^2), which is nothing but dense fp64 GEMMs
-// (v_mfma_f64_16x16x4_f64) — ~40 launches of a few microseconds each. trace(P) must come out as
+// (v_mfma_f64_16x16x4_f64) — ~30 launches of a few microseconds each, enqueued without a read-back. trace(P) must come out as
 // `rank`: that check makes the result exact (to the conditioning eps*||G||/gap every solver has) or
 // the call falls back to the full solver. The eigenvectors inside the subspace (the reference
 // returns them one by one, sorted) come from a Rayleigh-Ritz step on a rank x rank matrix.
@@ -76,6 +76,76 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, 
         double v = alpha * (((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane]);
         if (D) v += beta * D[i + ldd * (int64_t)j];
         C[i + ldc * (int64_t)j] = v;
+      }
+    }
+  }
+}
+
+// The same product for a SYMMETRIC result (the iterates of the sign iteration: X^2 and
+// X (a I + b X^2) with X symmetric): only the tiles on and above the diagonal are computed
+// (blockIdx.x enumerates them), every value is stored at (i, j) and at (j, i). The result is
+// symmetric bit for bit — k_dgemm_nt reads its second operand transposed, where an antisymmetric
+// rounding residue would double per iteration — without a separate symmetrisation pass. NW waves
+// split K (8 at J = 400: one round of 13 steps per wave instead of two).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restrict__ A, int64_t lda,
+                                                      const double *__restrict__ Bt, int64_t ldb,
+                                                      const double *__restrict__ D, int64_t ldd,
+                                                      double *__restrict__ C, int64_t ldc, int M,
+                                                      int K, double alpha, double beta) {
+  constexpr int UN = 13;
+  __shared__ double part[NW - 1][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  // blockIdx.x -> (ti <= tj): row ti of the upper triangle holds nt - ti tiles
+  const int nt = (M + 15) / 16;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ti++;
+  }
+  const int tj = ti + rem;
+  const int i0 = ti * 16, j0 = tj * 16;
+  const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, M - 1);
+  const double *__restrict__ ap = A + ia;
+  const double *__restrict__ bp = Bt + jb;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (K + 3) / 4;
+  const int spw = (ksteps + NW - 1) / NW;
+  const int s_begin = wave * spw, s_end = min(ksteps, s_begin + spw);
+  for (int s0 = s_begin; s0 < s_end; s0 += UN) {
+    double av[UN], bv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int k = (s0 + u) * 4 + g;
+      const bool ok = (s0 + u) < s_end && k < K;
+      const int kc = ok ? k : 0;
+      const double a = ap[(int64_t)lda * kc], b = bp[(int64_t)ldb * kc];
+      av[u] = ok ? a : 0.0;
+      bv[u] = ok ? b : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  const int j = j0 + l16;
+  if (j < M) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = i0 + g + 4 * r;
+      if (i < M && i <= j) {  // (a diagonal tile stores its upper half only, mirrored)
+        double v = acc[r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) v += part[w][r][lane];  // fixed order
+        v *= alpha;
+        if (D) v += beta * D[i + ldd * (int64_t)j];
+        C[i + ldc * (int64_t)j] = v;
+        if (i != j) C[j + ldc * (int64_t)i] = v;
       }
     }
   }
@@ -172,26 +242,6 @@ __global__ __launch_bounds__(256) void k_deflate_shift(const double *__restrict_
   s = block_sum(s, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-__global__ void k_scale_inplace(double *__restrict__ X, int64_t n, double f) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-       e += (int64_t)gridDim.x * blockDim.x)
-    X[e] *= f;
-}
-// X <- (X + X^T) / 2. The sign iteration runs on k_dgemm_nt, which reads its second operand
-// transposed: an antisymmetric rounding residue in X would DOUBLE every iteration there
-// (X Y^T = S - A for X = S + A), so the iterate is kept exactly symmetric.
-__global__ void k_symmetrize(double *__restrict__ X, int64_t J) {
-  const int64_t total = J * J;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = e % J, j = e / J;
-    if (i < j) {
-      const double v = 0.5 * (X[e] + X[j + J * i]);
-      X[e] = v;
-      X[j + J * i] = v;
-    }
-  }
-}
 
 // *out = || GU - U diag(ev) ||_F^2  (residual of the returned eigenpairs; one block)
 __global__ __launch_bounds__(1024) void k_eig_residual(const double *__restrict__ GU,
@@ -262,51 +312,81 @@ __global__ __launch_bounds__(256) void k_sum_pairs(const double *__restrict__ pa
   }
 }
 
-// One power step on a single vector inside ONE workgroup (the deflation of a dominant eigenpair):
-// y = G q, q_out = y / ||y||, *lam = q^T y (the Rayleigh quotient of the INPUT vector).
-__global__ __launch_bounds__(1024) void k_power_step1(const double *__restrict__ G, int64_t J,
-                                                      const double *__restrict__ q,
-                                                      double *__restrict__ q_out,
-                                                      double *__restrict__ lam) {
-  extern __shared__ double sh[];  // q[J] | y[J] | red[17]
-  double *sq = sh, *sy = sh + J, *red = sy + J;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) sq[i] = q[i];
-  __syncthreads();
-  for (int64_t i = 4 * wave; i < J; i += 4 * nw) {  // G symmetric: row i = column i, contiguous
-    // four rows at a time: 4 independent load / FMA chains per lane
-    const double *c0 = G + J * i, *c1 = G + J * min(i + 1, J - 1), *c2 = G + J * min(i + 2, J - 1),
-                 *c3 = G + J * min(i + 3, J - 1);
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int64_t k = lane; k < J; k += 64) {
-      const double qk = sq[k];
-      s0 += c0[k] * qk;
-      s1 += c1[k] * qk;
-      s2 += c2[k] * qk;
-      s3 += c3[k] * qk;
-    }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    s3 = wave_sum(s3);
-    if (lane == 0) {
-      sy[i] = s0;
-      if (i + 1 < J) sy[i + 1] = s1;
-      if (i + 2 < J) sy[i + 2] = s2;
-      if (i + 3 < J) sy[i + 3] = s3;
-    }
+// One power step on a single vector (the deflation of a dominant eigenpair), spread over the
+// device (one workgroup reads the 1.3 MB of a 400 x 400 Gram at the bandwidth of ONE CU: 25 us; 50
+// workgroups: ~5 us): y = G q with q = y_in * s, s = 1 / ||y_in||
+// taken from the partial sums the previous step left (pin == nullptr: y_in is already a unit
+// vector). 8 columns per workgroup (G symmetric: row i = column i, contiguous).
+//   pout[2*blk] = the block's share of ||y||^2, pout[2*blk+1] = its share of q^T y
+__global__ __launch_bounds__(256) void k_power_mv(const double *__restrict__ G, int64_t J,
+                                                  const double *__restrict__ y_in,
+                                                  const double *__restrict__ pin, int npin,
+                                                  double *__restrict__ y_out,
+                                                  double *__restrict__ pout) {
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double scale = 1.0;
+  if (pin) {
+    double n2 = 0;
+    for (int i = lane; i < npin; i += 64) n2 += pin[2 * i];
+    n2 = __shfl(wave_sum(n2), 0, 64);  // (lane 0 holds the sum)
+    scale = 1.0 / sqrt(n2);
+  }
+  const int64_t i0 = (int64_t)blockIdx.x * 8 + 2 * wave;
+  const double *c0 = G + J * min(i0, J - 1), *c1 = G + J * min(i0 + 1, J - 1);
+  double s0 = 0, s1 = 0;
+  for (int64_t k = lane; k < J; k += 64) {
+    const double qk = y_in[k] * scale;
+    s0 += c0[k] * qk;
+    s1 += c1[k] * qk;
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  double n2 = 0, rq = 0;
+  if (i0 < J) {
+    n2 += s0 * s0;
+    rq += s0 * (y_in[i0] * scale);
+  }
+  if (i0 + 1 < J) {
+    n2 += s1 * s1;
+    rq += s1 * (y_in[i0 + 1] * scale);
+  }
+  if (lane == 0) {
+    if (i0 < J) y_out[i0] = s0;
+    if (i0 + 1 < J) y_out[i0 + 1] = s1;
+    red[0][wave] = n2;
+    red[1][wave] = rq;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    pout[2 * blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    pout[2 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  }
+}
+// q_out = y / ||y||, *lam = the Rayleigh quotient of the vector that WENT INTO the last k_power_mv
+__global__ __launch_bounds__(256) void k_power_finish(const double *__restrict__ y, int64_t J,
+                                                      const double *__restrict__ p, int np,
+                                                      double *__restrict__ q_out,
+                                                      double *__restrict__ lam) {
+  __shared__ double red[17];
   double n2 = 0, rq = 0;
-  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) {
-    n2 += sy[i] * sy[i];
-    rq += sy[i] * sq[i];
+  for (int i = threadIdx.x; i < np; i += blockDim.x) {
+    n2 += p[2 * i];
+    rq += p[2 * i + 1];
   }
   n2 = block_sum(n2, red);
   rq = block_sum(rq, red);
   const double inv = 1.0 / sqrt(n2);
-  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = sy[i] * inv;
+  for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = y[i] * inv;
   if (threadIdx.x == 0) *lam = rq;
+}
+// X *= 1 / (1.0001 * sqrt(*fro2)): the scaling of the sign iteration by a norm that stays on the
+// device (no read-back between the deflation and the first product)
+__global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double *__restrict__ fro2) {
+  const double f = 1.0 / (1.0001 * sqrt(*fro2));
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    X[e] *= f;
 }
 
 // C = A^T B for two tall matrices (rows x r, column-major, ld = rows): one wave per entry (p, q)
@@ -356,7 +436,8 @@ __global__ void k_sub_mult(double *__restrict__ Z, int64_t rows, int rz, const d
 
 // In place: C (r x r, SPD, column-major) -> Rinv = L^{-T} with C = L L^T, so that Z * Rinv has
 // orthonormal columns when C = Z^T Z (Cholesky QR). One wave, r <= 64, in LDS. *status = 1 when a
-// pivot is not safely positive (Z numerically rank deficient: the caller falls back).
+// pivot is not safely positive (Z numerically rank deficient: the caller falls back), 2 when the
+// pivots spread by more than a factor 4.
 __global__ __launch_bounds__(64) void k_chol_rinv(double *__restrict__ C, int r,
                                                   int *__restrict__ status) {
   extern __shared__ double lds[];
@@ -371,12 +452,14 @@ __global__ __launch_bounds__(64) void k_chol_rinv(double *__restrict__ C, int r,
   double dmax = 0;
   for (int k = 0; k < r; k++) dmax = fmax(dmax, L[k + r * k]);
   bool bad = false;
+  double pmin = dmax;  // smallest pivot: dmax / pmin <= cond(C)
   for (int k = 0; k < r; k++) {
     const double d = L[k + r * k];
     if (!(d > 1e-12 * dmax)) {
       bad = true;
       break;
     }
+    pmin = fmin(pmin, d);
     const double sk = sqrt(d);
     wave_sync();
     for (int i = k + lane; i < r; i += 64) L[i + r * k] = (i == k) ? sk : L[i + r * k] / sk;
@@ -387,7 +470,10 @@ __global__ __launch_bounds__(64) void k_chol_rinv(double *__restrict__ C, int r,
     }
     wave_sync();
   }
-  if (lane == 0) *status = bad ? 1 : 0;
+  // status 2: factorised, but C is not close to the identity (pivots spread by more than 4): ONE
+  // Cholesky-QR pass leaves an orthogonality error of eps * cond(C), a caller that runs a single
+  // pass treats that as a failure
+  if (lane == 0) *status = bad ? 1 : (dmax > 4.0 * pmin ? 2 : 0);
   if (bad) return;
   // X = L^{-1} by forward substitution, one column per lane
   for (int c = lane; c < r; c += 64) {
