@@ -529,7 +529,10 @@ class HipOps : public Ops {
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
         // loses to the global-load kernel, so it is used for one n-tile / fp64 storage only)
-        if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8)) {
+        // (and: K-split scans of an fp64 tensor — few, long work items of half-size blocks — run
+        // at 0.80 of peak on the global-load kernel against 0.70 here: tools/r02_f64.sh)
+        if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
+            !(sizeof(TV) == 8 && nsplit > 1)) {
           if (NT == 1) LAUNCH_SUFFIX_BUF(1);
           else if (NT == 2) LAUNCH_SUFFIX_BUF(2);
           else LAUNCH_SUFFIX_BUF(4);
