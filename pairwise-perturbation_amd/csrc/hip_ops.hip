@@ -111,7 +111,6 @@ class HipOps : public Ops {
     if (ws_part2_) hipFree(ws_part2_);
     for (auto &es : eig_state_) {
       if (es.Q) hipFree(es.Q);
-      if (es.ev) hipFree(es.ev);
     }
     hipStreamDestroy(st_);
   }
@@ -911,8 +910,7 @@ class HipOps : public Ops {
     double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, largest eigenvalue
     double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
     double *Q = nullptr;                  // previous basis (J x rank)
-    double *ev = nullptr;                 // eigenvalues of the last Rayleigh-Ritz step (device)
-    double evh[64] = {0};                 // ... and on the host (descending), once read back
+    double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
     int fast = 0, full = 0;
   };
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
@@ -942,9 +940,7 @@ class HipOps : public Ops {
     es.rho = lam[rank];
     if (!es.Q || es.J != J || es.rank != rank) {
       if (es.Q) hipFree(es.Q);
-      if (es.ev) hipFree(es.ev);
       HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
-      HIP_CHECK(hipMalloc(&es.ev, sizeof(double) * 64));
     }
     es.J = J;
     es.rank = rank;
