@@ -167,10 +167,14 @@ def test_cfg4_full_size(pp, ctx):
 
 
 @pytest.mark.parametrize("roots", [1, 2])
-def test_script_order6_full_size(pp, ctx, roots, monkeypatch):
+def test_script_order6_full_size(pp, ctx, roots, monkeypatch, tmp_path):
     """the shape of the reference's own job scripts (script/*.py: -dim 6 -size 50 -rank 6; 62.5 GB
-    in fp32) with one and with two modes contracted per tensor scan, against the closed form"""
+    in fp32) with one and with two modes contracted per tensor scan, against the closed form.
+    Its column strides (50^k * 4 B) are not multiples of 128 B: the scans read the padded resident
+    layouts (when the three copies fit) and write compact results."""
     monkeypatch.setenv("PPALS_MSDT_ROOTS", str(roots))
+    trace = tmp_path / "steps.txt"
+    monkeypatch.setenv("PPALS_TRACE_STEPS", str(trace))
     lens, A, W, G = _problem(pp, 50, 6, N=6)
     try:
         V = pp.Tensor(ctx, lens, 0).fill_cp(A)
@@ -185,6 +189,8 @@ def test_script_order6_full_size(pp, ctx, roots, monkeypatch):
     for a, b in zip(s.get_factors(), W_ref):
         assert relerr(a, b) < 1e-5, (roots, relerr(a, b))
     assert abs(s.residual() - RS.residual(A, W_ref)) < 1e-4 * RS.norm(A)
+    used = {ln.split("layout=")[1].split()[0] for ln in trace.read_text().splitlines()}
+    assert "VTpad" in used, used   # (the third copy, "Vpad", only if 3 x 62.5 GB fit)
     s.close()
     V.close()
 
