@@ -53,3 +53,4 @@ test_tensor_p_laplacian = G.test_tensor_p_laplacian
 test_tensor_c_collinear = G.test_tensor_c_collinear
 test_tall_unfolding_thin_route_matches_oracle = GT.test_tall_unfolding_thin_route_matches_oracle
 test_tall_unfolding_rank_deficient_falls_back = GT.test_tall_unfolding_rank_deficient_falls_back
+test_chain_order_of_the_first_level_products = GT.test_chain_order_of_the_first_level_products

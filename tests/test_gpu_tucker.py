@@ -285,3 +285,23 @@ def test_tall_unfolding_rank_deficient_falls_back(pp, ctx):
     assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("order", ["asc", "desc"])
+def test_chain_order_of_the_first_level_products(pp, ctx, order, monkeypatch):
+    """the first-level node that keeps the left half removes the right-half modes one by one; the
+    engine starts with the LAST of them when only that makes the tensor scan's columns 128-B
+    aligned (the products commute). Both orders against the oracle's TTMc."""
+    monkeypatch.setenv("PPALS_TUCKER_CHAIN", order)
+    lens, ranks = [6, 5, 4, 7, 5, 6], [2, 3, 2, 3, 2, 2]
+    V = O.fill_uniform(int(np.prod(lens)), 3, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W = [np.linalg.qr(O.fill_uniform(s * r, 40 + i, lo=-1, hi=1).reshape((s, r), order="F"))[0]
+         for i, (s, r) in enumerate(zip(lens, ranks))]
+    for dtype in (1, 0):
+        t = pp.Tensor(ctx, lens, dtype).upload(V)
+        s = pp.Tucker(ctx, t, ranks)
+        s.set_factors(W)
+        for skip in [-1] + list(range(len(lens))):
+            assert relerr(s.ttmc(skip), O.ttmc(V, W, skip)) < (2e-6 if dtype == 0 else 1e-11), skip
+        s.close()
+        t.close()
