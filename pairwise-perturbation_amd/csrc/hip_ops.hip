@@ -112,6 +112,8 @@ class HipOps : public Ops {
     for (auto &es : eig_state_) {
       if (es.Q) hipFree(es.Q);
     }
+    for (auto &sm : eig_small_)
+      if (sm.Q) hipFree(sm.Q);
     hipStreamDestroy(st_);
   }
 
@@ -1010,8 +1012,55 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * r, 256)), dim3(256),
                          sizeof(double) * r * r, st_, GB, J, r, Yr, GU);
   }
+  // Small modes (16 <= J <= 64: the in-LDS Jacobi, 1 ms at J = 50 from a cold start — 15 % of an
+  // order-6 s = 50 HOOI sweep): the Jacobi runs on H = Q^T G Q with Q the slot's previous
+  // eigenvector matrix. G changes little from sweep to sweep, so H is nearly diagonal and the
+  // cyclic Jacobi (quadratically convergent) needs 2-3 sweeps instead of ~8; the result Q Y is
+  // the same eigen-decomposition, with no assumption about gaps. Every 64th call starts cold
+  // (the product Q Y accumulates rounding in its orthogonality).
+  struct SmallEig {
+    int64_t J = 0;
+    double *Q = nullptr;  // J x J, ranked descending
+    bool valid = false;
+    int age = 0;
+  };
+  SmallEig eig_small_[16];
+  void top_eigvecs_small_warm(double *G, int64_t J, int rank, double *U, int slot) {
+    SmallEig &sm = eig_small_[slot];
+    const int Ji = (int)J;
+    const size_t nJJ = (size_t)J * J;
+    if (sm.J != J) {
+      if (sm.Q) hipFree(sm.Q);
+      HIP_CHECK(hipMalloc(&sm.Q, sizeof(double) * nJJ));
+      sm.J = J;
+      sm.valid = false;
+    }
+    const size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64 + 17) + sizeof(int) * 64;
+    if (!sm.valid || ++sm.age >= 64) {
+      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, G, Ji, Ji, sm.Q,
+                         (double *)nullptr);
+      sm.valid = true;
+      sm.age = 0;
+    } else {
+      double *w = (double *)ensure(ws_eig_, ws_eig_sz_, sizeof(double) * 5 * nJJ);
+      double *Qt = w, *C1 = Qt + nJJ, *H = C1 + nJJ, *Y = H + nJJ, *Qn = Y + nJJ;
+      transpose2d(sm.Q, F64, J, J, Qt);
+      gemm_nt(G, J, Qt, J, nullptr, 0, C1, J, Ji, Ji, Ji, 1.0, 0.0);  // G Q
+      hipLaunchKernelGGL(k_tn_small, dim3((Ji * Ji + 15) / 16), dim3(1024), 0, st_, sm.Q, C1, J, Ji, H);
+      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, H, Ji, Ji, Y, (double *)nullptr);
+      hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * J, 256)), dim3(256), sizeof(double) * nJJ, st_,
+                         sm.Q, J, Ji, Y, Qn);
+      HIP_CHECK(hipMemcpyAsync(sm.Q, Qn, sizeof(double) * nJJ, hipMemcpyDeviceToDevice, st_));
+    }
+    HIP_CHECK(hipMemcpyAsync(U, sm.Q, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
+    HIP_CHECK(hipGetLastError());
+  }
   void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int slot) override {
     RoctxRange roctx_("K12 eig (projector route)");
+    if (J >= 16 && J <= 64 && rank <= J && slot >= 0 && slot < 16 && eig_fast_) {
+      top_eigvecs_small_warm(G, J, rank, U, slot);
+      return;
+    }
     if (J <= 64 || rank > 64 || rank >= J || slot < 0 || slot >= 16 || !eig_fast_) {
       top_eigvecs(G, J, rank, U);
       return;
