@@ -234,10 +234,53 @@ class HipOps : public Ops {
     }
     return true;
   }
+  // residual for 32 < R <= 256 on the matrix cores (k_rank_split); false: shape not covered
+  template <typename TV>
+  bool rank_split(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
+                  double *out) {
+    constexpr int VEC = ScanTraits<TV>::VEC;
+    if (!rank_mfma_ || R <= 32 || R > 256 || M % VEC != 0 || M < VEC ||
+        (((uintptr_t)V) & 15) != 0 || K < 1)
+      return false;
+    const int RB = (R + 3) / 4;
+    const int64_t nkb64 = (K + 15) / 16;
+    if (nkb64 > 0x7fffffff) return false;
+    const int nkb = (int)nkb64;
+    double *Ppk = (double *)ensure(ws_pack_, ws_pack_sz_, sizeof(double) * (size_t)nkb * RB * 64);
+    hipLaunchKernelGGL(k_rank_pack, dim3(grid_for((int64_t)nkb * RB * 64, 256)), dim3(256), 0, st_, P,
+                       K, R, RB, nkb, Ppk);
+    const int64_t n_mtiles = (M + 16 * VEC - 1) / (16 * VEC);
+    int nchunk = (int)std::min<int64_t>(nkb, std::max<int64_t>(1, ((int64_t)ncu_ * 8 + n_mtiles - 1) / n_mtiles));
+    int per = (nkb + nchunk - 1) / nchunk;
+    per = std::max(per, std::min(nkb, 8));
+    nchunk = (nkb + per - 1) / per;
+    if (n_mtiles > 0x7fffffff || nchunk > 65535) return false;
+    dim3 grid((unsigned)n_mtiles, (unsigned)nchunk);
+    const int64_t npart = (int64_t)n_mtiles * nchunk;
+    double *part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
+    prof_begin(1, (double)M * K * sizeof(TV));
+    const int rbw = (RB + 3) / 4;
+    if (rbw <= 4)
+      hipLaunchKernelGGL((k_rank_split<TV, 4>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk, R,
+                         RB, per, nkb, part);
+    else if (rbw <= 8)
+      hipLaunchKernelGGL((k_rank_split<TV, 8>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk, R,
+                         RB, per, nkb, part);
+    else
+      hipLaunchKernelGGL((k_rank_split<TV, 16>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk,
+                         R, RB, per, nkb, part);
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, (int)npart, out);
+    HIP_CHECK(hipGetLastError());
+    return true;
+  }
   template <typename TV, int MODE>
   void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                    double *out) {
     if (rank_mfma<TV, MODE>(V, M, K, Q, P, R, out)) return;
+    if constexpr (MODE == 1)
+      if (rank_split<TV>(V, M, K, Q, P, R, out)) return;
     int kch = 32;
     while ((K + kch - 1) / kch > 65535) kch *= 2;
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((K + kch - 1) / kch));

@@ -1159,6 +1159,100 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
   }
 }
 
+// The residual for ranks above 32 (the reference CLI's default rank is s/2): the model tile of a
+// column block needs R/4 contraction steps, too many operand registers for one wave. The four
+// waves of a workgroup take a QUARTER of the rank blocks each on the SAME 16*VEC rows (their share
+// of Q stays in registers: 4 * MAXRBW doubles per row), leave their partial model tiles in LDS
+// (double-buffered: one barrier per column block) and each finishes one of the four column quads
+// of the block — so every tensor element is loaded once, by the wave that subtracts it. The
+// partial tiles are added in wave order: deterministic. MFMA-bound (2 M K R fp64 flops).
+template <typename TV, int MAXRBW>
+__global__ __launch_bounds__(256) void k_rank_split(const TV *__restrict__ V, int64_t M, int64_t K,
+                                                    const double *__restrict__ Q,
+                                                    const double *__restrict__ Ppk, int R, int RB,
+                                                    int kb_per_chunk, int nkb,
+                                                    double *__restrict__ partial) {
+  typedef ScanTraits<TV> TR;
+  typedef typename TR::vec vec;
+  constexpr int VEC = TR::VEC;
+  __shared__ double sd[2][4][VEC][4][64];  // [buffer][wave][jj][column quad][lane]
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j16 = lane & 15;
+  const int64_t m0 = (int64_t)blockIdx.x * (16 * VEC);  // all four waves: the same rows
+  const int64_t m = m0 + (int64_t)VEC * j16;
+  const bool row_ok = m < M;
+  const int64_t m_ld = min(m, M - VEC);
+  const int kb0 = blockIdx.y * kb_per_chunk, kb1 = min(nkb, kb0 + kb_per_chunk);
+  const int rbw = (RB + 3) / 4;  // rank blocks per wave
+  const int rb0 = wave * rbw;
+  double bq[VEC][MAXRBW];
+#pragma unroll
+  for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+    for (int i = 0; i < MAXRBW; i++) {
+      const int rb = rb0 + i, r = 4 * rb + g;
+      bq[jj][i] = (i < rbw && rb < RB && r < R) ? Q[m_ld + jj + M * (int64_t)r] : 0.0;
+    }
+  double acc = 0.0;
+  const TV *__restrict__ vp = V + m_ld;
+  vec cv;
+  double ca[MAXRBW];
+#define PPALS_SPLIT_LOAD(kb_, vv_, aa_)                                                   \
+  {                                                                                       \
+    const int64_t k_ = min((int64_t)(kb_)*16 + 4 * wave + g, K - 1);                      \
+    vv_ = __builtin_nontemporal_load(reinterpret_cast<const vec *>(vp + k_ * M));         \
+    _Pragma("unroll") for (int i = 0; i < MAXRBW; i++) {                                  \
+      const int rb = rb0 + i;                                                             \
+      aa_[i] = (i < rbw && rb < RB) ? Ppk[(((int64_t)(kb_)*RB + rb) * 4 + g) * 16 + j16] : 0.0; \
+    }                                                                                     \
+  }
+  if (kb0 < kb1) PPALS_SPLIT_LOAD(kb0, cv, ca);
+  for (int kb = kb0; kb < kb1; kb++) {
+    vec nv;
+    double na[MAXRBW];
+    const int kn = min(kb + 1, kb1 - 1);
+    PPALS_SPLIT_LOAD(kn, nv, na);
+    f64x4 d[VEC];
+#pragma unroll
+    for (int jj = 0; jj < VEC; jj++) d[jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXRBW; i++)
+      if (i < rbw) {
+#pragma unroll
+        for (int jj = 0; jj < VEC; jj++)
+          d[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], bq[jj][i], d[jj], 0, 0, 0);
+      }
+    const int buf = (kb - kb0) & 1;
+#pragma unroll
+    for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) sd[buf][wave][jj][u][lane] = d[jj][u];
+    __syncthreads();
+    // this wave finishes column quad u = wave: columns 16 kb + 4 wave + g
+    const int64_t k = (int64_t)kb * 16 + 4 * wave + g;
+    double e2 = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < VEC; jj++) {
+      const double model = ((sd[buf][0][jj][wave][lane] + sd[buf][1][jj][wave][lane]) +
+                            sd[buf][2][jj][wave][lane]) + sd[buf][3][jj][wave][lane];
+      const double e = (double)cv[jj] - model;
+      e2 += e * e;
+    }
+    acc += (k < K && row_ok) ? e2 : 0.0;
+    cv = nv;
+#pragma unroll
+    for (int i = 0; i < MAXRBW; i++) ca[i] = na[i];
+  }
+#undef PPALS_SPLIT_LOAD
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // Ppk[((kb*RB + rb)*4 + g)*16 + i] = P[16*kb + i, 4*rb + g]  (zero beyond K / R)
 __global__ void k_rank_pack(const double *__restrict__ P, int64_t K, int R, int RB, int nkb,
                             double *__restrict__ Ppk) {

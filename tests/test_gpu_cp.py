@@ -700,7 +700,11 @@ def test_long_run_factor_parity(pp, ctx, lens, R, dtype):
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R", [([8, 8, 8, 8], 3), ([12, 6, 7, 5], 10), ([20, 14, 9, 11], 20),
                                     ([4, 9, 3, 7], 32), ([68, 4, 5, 3], 1), ([16, 18, 50], 7),
-                                    ([6, 10, 4, 3, 5, 2], 5)])
+                                    ([6, 10, 4, 3, 5, 2], 5),
+                                    # ranks above 32: the rank-split residual (k_rank_split), with
+                                    # 4 / 8 / 16 rank blocks per wave and ragged last blocks
+                                    ([40, 36, 34, 33], 33), ([70, 66, 65], 64), ([120, 101, 103], 100),
+                                    ([140, 9, 130, 11], 130), ([260, 257], 250)])
 def test_rank_stream_on_matrix_cores(pp, ctx, lens, R, dtype):
     """K10 (build_V and the streaming residual / norm) through the fp64-MFMA kernel: row counts
     that are / are not multiples of a workgroup's 256 rows, column counts with a partial last
