@@ -89,6 +89,8 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   }
   ~HipOps() override {
     hipSetDevice(dev_);
@@ -723,8 +725,13 @@ class HipOps : public Ops {
     if (R > 64) {  // S, S^-1 out of global memory (kernels_small.hip.h, "rank above 64")
       double *work = (double *)ensure(ws_big_, ws_big_sz_, sizeof(double) * (size_t)R * R + 64);
       int *status = (int *)(work + (size_t)R * R);
-      hipLaunchKernelGGL(k_gram_system_big, dim3(1), dim3(1024), 0, st_, Gall, N, mode, R, lambda, S,
-                         Sinv, work, status);
+      const size_t lds_gj = sizeof(double) * ((size_t)R * R + 2 * (size_t)R);
+      if (lds_gj <= 150 * 1024)
+        hipLaunchKernelGGL(k_gram_system_lds, dim3(1), dim3(1024), lds_gj, st_, Gall, N, mode, R,
+                           lambda, S, Sinv, status);
+      else
+        hipLaunchKernelGGL(k_gram_system_big, dim3(1), dim3(1024), 0, st_, Gall, N, mode, R, lambda,
+                           S, Sinv, work, status);
       HIP_CHECK(hipGetLastError());
       // a non-positive pivot (S not positive definite: a rank above a mode extent, collinear
       // columns) leaves NaNs in Sinv: take the reference's route instead, the untruncated inverse
@@ -805,6 +812,21 @@ class HipOps : public Ops {
                  int64_t ldd, double ratio) override {
     if (rows <= 0) {  // a rank that owns no rows of this mode (row-block plan): nothing to launch
       HIP_CHECK(hipMemsetAsync(gradsq, 0, sizeof(double), st_));
+      return;
+    }
+    if (R > 64 && ldg == rows && ldn == rows && (!Winit || ratio == 1.0) && rows * (int64_t)R < (1 << 30)) {
+      // both products on the matrix cores (S and S^-1 are symmetric: they ARE their own
+      // transposed operand): grad = W_old S - M, then W = M S^-1 (may alias W_old: stream order)
+      gemm_nt(Wold, ldw, S, R, M, ldm, grad, ldg, (int)rows, R, R, 1.0, -1.0);
+      sumsq(grad, rows * R, gradsq);
+      gemm_nt(M, ldm, Sinv, R, nullptr, 0, Wnew, ldn, (int)rows, R, R, 1.0, 0.0);
+      if (Winit) {  // SVD_solve_mod tail with ratio 1: dW = W - W_init
+        if (ldi != rows || ldd != rows) throw std::runtime_error("ppals: cp_update expects packed factors");
+        double *A[1] = {Wnew}, *B[1] = {const_cast<double *>(Winit)}, *D[1] = {dW};
+        int64_t n[1] = {rows * R};
+        diff_norms(A, B, n, 1, 1, D, 0, (double *)ensure(ws_big2_, ws_big2_sz_, 4 * sizeof(double)));
+      }
+      HIP_CHECK(hipGetLastError());
       return;
     }
     if (R > 64) {
