@@ -457,7 +457,9 @@ class HipOps : public Ops {
     const bool aligned_base = (((uintptr_t)V) & 15) == 0;
     for (int col0 = 0; col0 < R; col0 += 64) {
       const int ncols = std::min(64, R - col0);
-      const int NT = ncols <= 16 ? 1 : (ncols <= 32 ? 2 : 4);
+      // n-tiles of 16 result columns: 3 for 33..48 columns (ranks such as 40, or the second
+      // launch of R = 100 = 64 + 36) instead of padding them to 64 — these scans are MFMA-bound
+      const int NT = ncols <= 16 ? 1 : (ncols <= 32 ? 2 : (ncols <= 48 ? 3 : 4));
       const int64_t nblk64 = (J + 4 * VEC - 1) / (4 * VEC);
       if (nblk64 > 0x7fffffff) throw std::runtime_error("ppals: contraction extent too large");
       const int nblk = (int)nblk64;
@@ -506,14 +508,17 @@ class HipOps : public Ops {
         if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_PREFIX_FAST(1);
           else if (NT == 2) LAUNCH_PREFIX_FAST(2);
+          else if (NT == 3) LAUNCH_PREFIX_FAST(3);
           else LAUNCH_PREFIX_FAST(4);
         } else if (al) {
           if (NT == 1) LAUNCH_PREFIX(1, true);
           else if (NT == 2) LAUNCH_PREFIX(2, true);
+          else if (NT == 3) LAUNCH_PREFIX(3, true);
           else LAUNCH_PREFIX(4, true);
         } else {
           if (NT == 1) LAUNCH_PREFIX(1, false);
           else if (NT == 2) LAUNCH_PREFIX(2, false);
+          else if (NT == 3) LAUNCH_PREFIX(3, false);
           else LAUNCH_PREFIX(4, false);
         }
 #undef LAUNCH_PREFIX
@@ -581,18 +586,22 @@ class HipOps : public Ops {
             !(sizeof(TV) == 8 && nsplit > 1)) {
           if (NT == 1) LAUNCH_SUFFIX_BUF(1);
           else if (NT == 2) LAUNCH_SUFFIX_BUF(2);
+          else if (NT == 3) LAUNCH_SUFFIX_BUF(3);
           else LAUNCH_SUFFIX_BUF(4);
         } else if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_SUFFIX_FAST(1);
           else if (NT == 2) LAUNCH_SUFFIX_FAST(2);
+          else if (NT == 3) LAUNCH_SUFFIX_FAST(3);
           else LAUNCH_SUFFIX_FAST(4);
         } else if (al) {
           if (NT == 1) LAUNCH_SUFFIX(1, true);
           else if (NT == 2) LAUNCH_SUFFIX(2, true);
+          else if (NT == 3) LAUNCH_SUFFIX(3, true);
           else LAUNCH_SUFFIX(4, true);
         } else {
           if (NT == 1) LAUNCH_SUFFIX(1, false);
           else if (NT == 2) LAUNCH_SUFFIX(2, false);
+          else if (NT == 3) LAUNCH_SUFFIX(3, false);
           else LAUNCH_SUFFIX(4, false);
         }
 #undef LAUNCH_SUFFIX
