@@ -236,8 +236,8 @@ class HipOps : public Ops {
     }
     return true;
   }
-  // residual for 32 < R <= 256 on the matrix cores (k_rank_split); false: shape not covered
-  template <typename TV>
+  // generation / residual for 32 < R <= 256 on the matrix cores (k_rank_split); false: not covered
+  template <typename TV, int MODE>
   bool rank_split(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                   double *out) {
     constexpr int VEC = ScanTraits<TV>::VEC;
@@ -259,30 +259,32 @@ class HipOps : public Ops {
     if (n_mtiles > 0x7fffffff || nchunk > 65535) return false;
     dim3 grid((unsigned)n_mtiles, (unsigned)nchunk);
     const int64_t npart = (int64_t)n_mtiles * nchunk;
-    double *part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
+    double *part = MODE == 1 ? (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double)) : nullptr;
     prof_begin(1, (double)M * K * sizeof(TV));
     const int rbw = (RB + 3) / 4;
     if (rbw <= 4)
-      hipLaunchKernelGGL((k_rank_split<TV, 4>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk, R,
+      hipLaunchKernelGGL((k_rank_split<TV, MODE, 4>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
                          RB, per, nkb, part);
     else if (rbw <= 8)
-      hipLaunchKernelGGL((k_rank_split<TV, 8>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk, R,
+      hipLaunchKernelGGL((k_rank_split<TV, MODE, 8>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
                          RB, per, nkb, part);
     else
-      hipLaunchKernelGGL((k_rank_split<TV, 16>), grid, dim3(256), 0, st_, (const TV *)V, M, K, Q, Ppk,
+      hipLaunchKernelGGL((k_rank_split<TV, MODE, 16>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk,
                          R, RB, per, nkb, part);
     prof_end();
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, (int)npart, out);
-    HIP_CHECK(hipGetLastError());
+    if (MODE == 1) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, (int)npart, out);
+      HIP_CHECK(hipGetLastError());
+    }
     return true;
   }
   template <typename TV, int MODE>
   void rank_stream(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                    double *out) {
     if (rank_mfma<TV, MODE>(V, M, K, Q, P, R, out)) return;
-    if constexpr (MODE == 1)
-      if (rank_split<TV>(V, M, K, Q, P, R, out)) return;
+    if constexpr (MODE != 2)
+      if (rank_split<TV, MODE>(V, M, K, Q, P, R, out)) return;
     int kch = 32;
     while ((K + kch - 1) / kch > 65535) kch *= 2;
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((K + kch - 1) / kch));

@@ -1166,8 +1166,9 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
 // (double-buffered: one barrier per column block) and each finishes one of the four column quads
 // of the block — so every tensor element is loaded once, by the wave that subtracts it. The
 // partial tiles are added in wave order: deterministic. MFMA-bound (2 M K R fp64 flops).
-template <typename TV, int MAXRBW>
-__global__ __launch_bounds__(256) void k_rank_split(const TV *__restrict__ V, int64_t M, int64_t K,
+// MODE 1: partial[blk] = the block's share of ||V - model||^2; MODE 0: V = model (tensor generation).
+template <typename TV, int MODE, int MAXRBW>
+__global__ __launch_bounds__(256) void k_rank_split(TV *__restrict__ V, int64_t M, int64_t K,
                                                     const double *__restrict__ Q,
                                                     const double *__restrict__ Ppk, int R, int RB,
                                                     int kb_per_chunk, int nkb,
@@ -1200,8 +1201,10 @@ __global__ __launch_bounds__(256) void k_rank_split(const TV *__restrict__ V, in
   double ca[MAXRBW];
 #define PPALS_SPLIT_LOAD(kb_, vv_, aa_)                                                   \
   {                                                                                       \
-    const int64_t k_ = min((int64_t)(kb_)*16 + 4 * wave + g, K - 1);                      \
-    vv_ = __builtin_nontemporal_load(reinterpret_cast<const vec *>(vp + k_ * M));         \
+    if constexpr (MODE == 1) {                                                            \
+      const int64_t k_ = min((int64_t)(kb_)*16 + 4 * wave + g, K - 1);                    \
+      vv_ = __builtin_nontemporal_load(reinterpret_cast<const vec *>(vp + k_ * M));       \
+    }                                                                                     \
     _Pragma("unroll") for (int i = 0; i < MAXRBW; i++) {                                  \
       const int rb = rb0 + i;                                                             \
       aa_[i] = (i < rbw && rb < RB) ? Ppk[(((int64_t)(kb_)*RB + rb) * 4 + g) * 16 + j16] : 0.0; \
@@ -1232,25 +1235,36 @@ __global__ __launch_bounds__(256) void k_rank_split(const TV *__restrict__ V, in
     // this wave finishes column quad u = wave: columns 16 kb + 4 wave + g
     const int64_t k = (int64_t)kb * 16 + 4 * wave + g;
     double e2 = 0.0;
+    vec o;
 #pragma unroll
     for (int jj = 0; jj < VEC; jj++) {
       const double model = ((sd[buf][0][jj][wave][lane] + sd[buf][1][jj][wave][lane]) +
                             sd[buf][2][jj][wave][lane]) + sd[buf][3][jj][wave][lane];
-      const double e = (double)cv[jj] - model;
-      e2 += e * e;
+      if constexpr (MODE == 1) {
+        const double e = (double)cv[jj] - model;
+        e2 += e * e;
+      } else {
+        o[jj] = (TV)model;
+      }
     }
-    acc += (k < K && row_ok) ? e2 : 0.0;
+    if constexpr (MODE == 1) {
+      acc += (k < K && row_ok) ? e2 : 0.0;
+    } else {
+      if (k < K && row_ok) *reinterpret_cast<vec *>(V + m + k * M) = o;
+    }
     cv = nv;
 #pragma unroll
     for (int i = 0; i < MAXRBW; i++) ca[i] = na[i];
   }
 #undef PPALS_SPLIT_LOAD
+  if constexpr (MODE == 1) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) red[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
 // Ppk[((kb*RB + rb)*4 + g)*16 + i] = P[16*kb + i, 4*rb + g]  (zero beyond K / R)
