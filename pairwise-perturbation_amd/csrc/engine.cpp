@@ -884,7 +884,9 @@ void CpEngine::ms_start_step(int first) {
     static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
     static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
-    if (bytes >= 1.5e9) {
+    // (worth measuring only where the result stream matters: an HBM-bound scan — up to two
+    // n-tiles — that writes at least 1 % of what it reads)
+    if (bytes >= 1.5e9 && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
       const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
       const int reps = large ? 1 : 2;
       const int64_t *cand_mb = large ? cand_large : cand_small;
