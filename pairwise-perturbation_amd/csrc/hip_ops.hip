@@ -861,7 +861,7 @@ class HipOps : public Ops {
   }
   void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) override {
     double *scales = small(MAX_ORDER);
-    hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(64), 0, st_, Gall, N, R, scales);
+    hipLaunchKernelGGL(k_norm_scales, dim3(1), dim3(1024), 0, st_, Gall, N, R, scales);
     HIP_CHECK(hipGetLastError());
     PtrsN w;
     int64_t mx = 1;

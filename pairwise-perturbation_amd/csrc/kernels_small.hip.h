@@ -1117,8 +1117,8 @@ struct PtrsN {
 };
 // ONE wave: scales[i] = (prod_j ||W_j||)^(1/N) / ||W_i||, with ||W_i||^2 = trace(G_i); the Grams
 // are rescaled in place (G_i *= scales[i]^2) so they stay consistent with the scaled factors.
-__global__ __launch_bounds__(64) void k_norm_scales(double *__restrict__ Gall, int N, int R,
-                                                    double *__restrict__ scales) {
+__global__ __launch_bounds__(1024) void k_norm_scales(double *__restrict__ Gall, int N, int R,
+                                                      double *__restrict__ scales) {
   __shared__ double nrm[MAX_ORDER];
   const int lane = threadIdx.x;
   if (lane < N) {
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(64) void k_norm_scales(double *__restrict__ Gall, i
   const double c = pow(prod, 1.0 / N);
   for (int i = 0; i < N; i++) {
     const double f = c / nrm[i];
-    for (int e = lane; e < R * R; e += 64) Gall[(int64_t)i * R * R + e] *= f * f;
+    for (int e = lane; e < R * R; e += blockDim.x) Gall[(int64_t)i * R * R + e] *= f * f;
     if (lane == 0) scales[i] = f;
   }
 }
