@@ -380,6 +380,11 @@ __global__ __launch_bounds__(256) void k_power_finish(const double *__restrict__
   for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = y[i] * inv;
   if (threadIdx.x == 0) *lam = rq;
 }
+// E (J x n, zeroed by the caller): column t = unit vector e_j with j = (t + 1) J / (n + 1)
+__global__ void k_set_unit_cols(double *__restrict__ E, int64_t J, int n) {
+  const int t = threadIdx.x;
+  if (t < n) E[(int64_t)(t + 1) * J / (n + 1) + J * t] = 1.0;
+}
 // X *= 1 / (1.0001 * sqrt(*fro2)): the scaling of the sign iteration by a norm that stays on the
 // device (no read-back between the deflation and the first product)
 __global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double *__restrict__ fro2) {
