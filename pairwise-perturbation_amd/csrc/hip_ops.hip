@@ -84,6 +84,7 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
     if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_SIGMA_SCALE")) eig_sigma_scale_ = atof(v);
     if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
@@ -1171,7 +1172,8 @@ class HipOps : public Ops {
     double *lamD = evW + 64 + 4;
     constexpr size_t kReadback = sizeof(double) * (16 + 64) + sizeof(int) * 8;
     HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
-    const double sigma = 0.5 * (es.lamR + es.lamR1);
+    double sigma = 0.5 * (es.lamR + es.lamR1);
+    if (eig_sigma_scale_ > 0) sigma = eig_sigma_scale_ * es.lamR1;  // tests: a shift that is too low
     // ---- dominant eigenpairs (a relative gap >= 20 above the rest of the wanted ones): refined
     // to machine precision by a few block power steps from the previous basis, then deflated —
     // the sign iteration amplifies rounding by (spectral radius / gap), and a tensor with a mean
@@ -1245,7 +1247,7 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_scale_by_frob, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, (int64_t)nJJ,
                        fro2_d);
     const double ell0 = 0.9 * 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
-    double ell = std::max(ell0, 1e-14);
+    double ell = std::max(ell0, eig_sigma_scale_ > 0 ? 1e-4 : 1e-14);
     int iters = 0;
     const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
     auto ns_step = [&](double mu) {
@@ -1473,6 +1475,7 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  double eig_sigma_scale_ = 0;  // PPALS_EIG_SIGMA_SCALE=f: shift = f * (estimate of the next eigenvalue) (tests)
   int gram_mfma_ = 1;     // PPALS_GRAM_MFMA=0: the fp64 VALU Gram kernel (A/B, tests)
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)

@@ -190,6 +190,9 @@ def test_eigen_step_projector_route_matches_oracle(pp, ctx, lens, ranks, tmp_pat
     W0, c0 = O.hosvd(V, ranks)
     c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
     _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=6, csv=c_ref, resprint=1)
+    # (these unfoldings are tall: without this the factors would come from the small Gram and the
+    # s x s route under test would never run)
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
     results = []
     for fast in ("1", "0"):
         monkeypatch.setenv("PPALS_EIG_FAST", fast)
@@ -305,3 +308,34 @@ def test_chain_order_of_the_first_level_products(pp, ctx, order, monkeypatch):
             assert relerr(s.ttmc(skip), O.ttmc(V, W, skip)) < (2e-6 if dtype == 0 else 1e-11), skip
         s.close()
         t.close()
+
+
+def test_eigen_step_wide_tail(pp, tmp_path, monkeypatch, capfd):
+    """a shift that has slipped below a few more eigenvalues than wanted (forced here:
+    PPALS_EIG_SIGMA_SCALE puts it at 0.4 x the next eigenvalue, under the two that follow in this
+    0.49-per-index spectrum): the projector then covers rank + 2 dimensions, the Rayleigh-Ritz step
+    runs on that many columns and the leading `rank` eigenpairs are still those of the full
+    solver — same iterates as the oracle, and the log shows the wide tail was taken."""
+    lens, ranks = [96, 80, 72], [5, 6, 4]
+    V = _decaying_tensor(lens, [10, 9, 8], 5, 0.001)
+    W0, c0 = O.hosvd(V, ranks)
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=5)
+    monkeypatch.setenv("PPALS_EIG_SIGMA_SCALE", "0.4")
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")   # the s x s route (the unfoldings here are tall)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.run_dt(tol=0.0, maxiter=5)
+    W, core = s.get_factors()
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+        assert relerr(proj(a), proj(b)) < 1e-7, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
+    c2.close()
+    err = capfd.readouterr().err
+    assert "wide tail" in err and "accepted" in err.split("wide tail", 1)[1], err[-2000:]
