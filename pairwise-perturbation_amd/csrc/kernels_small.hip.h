@@ -364,26 +364,33 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
     const int64_t lt = blk % ltiles;
     const int64_t t = (blk / ltiles) % T;
     const int r = (int)(blk / (ltiles * T));
-    const int64_t l = lt * 64 + lane;
+    // fewer than 64 rows (the 25 local rows of a cfg2 shard on 8 GPUs): a wave takes P = 64 / L
+    // consecutive j at a time — lanes (l, p) read L*P contiguous elements — instead of idling
+    // 64 - L lanes; the P partial sums of a row meet in LDS with those of the other waves
+    const int P = L < 64 ? 64 / (int)L : 1;
+    const int lp = L < 64 ? lane / (int)L : 0;
+    const int64_t l = L < 64 ? lane % (int)L : lt * 64 + lane;
     const TX *x = X + l + L * J * (t + T * (int64_t)r);
     const double *b = B + ldb * r;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (l < L) {
-      int64_t j = wave;
-      for (; j + 3 * NW < J; j += 4 * NW) {
+    if (l < L && lp < P) {
+      const int64_t st = (int64_t)NW * P;
+      int64_t j = (int64_t)wave * P + lp;
+      for (; j + 3 * st < J; j += 4 * st) {
         s0 += (double)x[L * j] * b[j];
-        s1 += (double)x[L * (j + NW)] * b[j + NW];
-        s2 += (double)x[L * (j + 2 * NW)] * b[j + 2 * NW];
-        s3 += (double)x[L * (j + 3 * NW)] * b[j + 3 * NW];
+        s1 += (double)x[L * (j + st)] * b[j + st];
+        s2 += (double)x[L * (j + 2 * st)] * b[j + 2 * st];
+        s3 += (double)x[L * (j + 3 * st)] * b[j + 3 * st];
       }
-      for (; j < J; j += NW) s0 += (double)x[L * j] * b[j];
+      for (; j < J; j += st) s0 += (double)x[L * j] * b[j];
     }
     part[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && l < L) {
+    if (wave == 0 && l < L && lp == 0) {
       double s = 0;
 #pragma unroll
-      for (int w = 0; w < NW; w++) s += part[w][lane];
+      for (int w = 0; w < NW; w++)
+        for (int q = 0; q < P; q++) s += part[w][lane + (int)L * q];
       s *= sc;
       double *o = out + l + L * t + rs * r;
       *o = accumulate ? (*o + s) : s;
