@@ -85,6 +85,7 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_SIGMA_SCALE")) eig_sigma_scale_ = atof(v);
+    if (const char *v = getenv("PPALS_EIG_COLD")) eig_cold_ = atoi(v);
     if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
@@ -110,6 +111,7 @@ class HipOps : public Ops {
     if (ws_eig_) hipFree(ws_eig_);
     if (ws_orth_) hipFree(ws_orth_);
     if (ws_pow_) hipFree(ws_pow_);
+    if (ws_cold_) hipFree(ws_cold_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
     for (auto &es : eig_state_) {
@@ -1144,10 +1146,20 @@ class HipOps : public Ops {
     }
     EigState &es = eig_state_[slot];
     if (es.valid && (es.J != J || es.rank != rank)) es.valid = false;
-    if (!es.valid) {
-      eig_bootstrap(es, G, J, rank, U);
+    if (es.valid && projector_step(es, G, J, rank, U, slot, false)) return;
+    // nothing known about this matrix (first call of the slot, a shift that no longer separates
+    // the wanted eigenvalues): a few steps of block subspace iteration place the shift, the same
+    // projector step — checked against machine precision, not against an estimated gap — delivers
+    // the eigenpairs; the full solver remains the fallback of the fallback
+    if (eig_cold_ && cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true))
       return;
-    }
+    es.valid = false;
+    eig_bootstrap(es, G, J, rank, U);
+  }
+  // One projector step from the state of the slot; false: not accepted (the caller falls back).
+  // strict: the state is a rough estimate (cold start) — accept only residuals at the rounding
+  // floor eps * lambda_1, whatever the estimated gap says.
+  bool projector_step(EigState &es, double *G, int64_t J, int rank, double *U, int slot, bool strict) {
     // The whole step is enqueued without a read-back: what the host needs in order to schedule it
     // (where the gap lies, the scale of the shifted matrix) it knows from the previous call of the
     // slot, and everything that decides whether the result is accepted (||X^2 - I||, trace(P),
@@ -1156,7 +1168,7 @@ class HipOps : public Ops {
     const int Ji = (int)J;
     const size_t nJJ = (size_t)J * J, nJR = (size_t)J * rank;
     // (column buffers with room for kWide extra columns: the "wide tail" below)
-    constexpr int kWide = 8;
+    constexpr int kWide = 16;
     const size_t nJW = (size_t)J * (rank + kWide);
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
                                  sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 256));
@@ -1238,15 +1250,14 @@ class HipOps : public Ops {
       HIP_CHECK(hipMemcpyAsync(&fro2, fro2_d, sizeof(double), hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
       rho = 1.0001 * std::sqrt(fro2);
-      if (!(rho > 0) || !std::isfinite(rho)) {
-        es.valid = false;
-        eig_bootstrap(es, G, J, rank, U);
-        return;
-      }
+      if (!(rho > 0) || !std::isfinite(rho)) return false;
     }
     hipLaunchKernelGGL(k_scale_by_frob, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, (int64_t)nJJ,
                        fro2_d);
-    const double ell0 = 0.9 * 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
+    // (strict = cold start: the distance of the shift to the nearest eigenvalue is unknown — the
+    // Ritz values around it are rough — so a small lower bound is assumed: a few iterations more)
+    double ell0 = 0.9 * 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
+    if (strict) ell0 = std::min(ell0, 2e-5);
     double ell = std::max(ell0, eig_sigma_scale_ > 0 ? 1e-4 : 1e-14);
     int iters = 0;
     const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
@@ -1315,7 +1326,9 @@ class HipOps : public Ops {
       const bool converged = hc[0] <= 1e-20 * (double)J;
       // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
       // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
-      const double res_tol = std::max(1e-9 * gap, 1e-14 * es.evh[0]) * std::sqrt((double)rank);
+      const double res_tol = (strict ? 1e-13 * std::max(es.evh[0], evn[0])
+                                     : std::max(1e-9 * gap, 1e-14 * es.evh[0])) *
+                             std::sqrt((double)rank);
       const bool good = converged && std::fabs(cnt - rank) < 1e-6 && hs[0] == 0 && hs[2] != 1 && hs[3] == 0 &&
                         res <= res_tol && std::isfinite(rho_now);
       if (eig_debug_)
@@ -1324,17 +1337,18 @@ class HipOps : public Ops {
                         "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
                 slot, (long long)J, rank, es.lamR, es.lamR1, m, rho, rho_now, ell0, iters, hc[0], cnt,
                 res, gap, hs[0], hs[1], hs[2], hs[3],
-                good ? "accepted" : (converged ? "full solver" : "more steps"), es.fast, es.full);
+                good ? "accepted" : (converged ? "not accepted as it is" : "more steps"), es.fast, es.full);
       if (good) {
         for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
         const double shift = evn[rank - 1] - es.lamR;
         es.lamR = evn[rank - 1];
         es.lamR1 = std::min(std::max(0.0, es.lamR1 + shift), es.lamR);
         es.rho_frob = rho_now;
+        if (strict) es.lamR1 = std::min(es.lamR1, es.lamR * (1 - 1e-6));  // (a rough estimate)
         if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;  // next call: full solver
         HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
         es.fast++;
-        return;
+        return true;
       }
       const int cwide = (int)std::lround(cnt);
       if (converged && std::fabs(cnt - cwide) < 1e-6 && cwide > rank && cwide <= rank + kWide &&
@@ -1363,18 +1377,77 @@ class HipOps : public Ops {
           es.rho_frob = rho_now;
           HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
           es.fast++;
-          return;
+          return true;
         }
         break;
       }
-      if (converged || attempt >= 2) break;
-      ns_step(1.0);  // the gap was narrower than estimated: two more steps, then the tail again
+      if (converged || attempt >= (strict ? 4 : 2)) break;
+      ns_step(1.0);  // the gap was narrower than estimated: a few more steps, then the tail again
       ns_step(1.0);
+      if (strict) {
+        ns_step(1.0);
+        ns_step(1.0);
+      }
       HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), st_));  // (the Cholesky QR of the tail)
     }
-    // sigma no longer separates `rank` eigenvalues, a lost direction, no convergence: full solver
-    es.valid = false;
-    eig_bootstrap(es, G, J, rank, U);
+    // sigma does not separate `rank` eigenvalues, a lost direction, no convergence
+    return false;
+  }
+  // Cold start of a slot: q steps of block subspace iteration from a pseudo-random block of
+  // rank + 16 columns, Rayleigh-Ritz — rough Ritz pairs (lower bounds of the eigenvalues). They
+  // become the slot's state with a deliberately LOW estimate of the eigenvalue below the cut, so
+  // that the shift of the projector step has at least `rank` eigenvalues above it; a few more are
+  // what its wide tail is for. false: the Ritz values do not resolve the neighbourhood of the cut
+  // (a flat spectrum) or the block lost rank — the caller goes to the full solver.
+  bool cold_ritz_state(EigState &es, double *G, int64_t J, int rank, int slot) {
+    const int b = std::min(64, rank + 16);
+    if (b >= J || rank + 4 >= b) return false;
+    const int Ji = (int)J;
+    const size_t nJB = (size_t)J * b;
+    double *w = (double *)ensure(ws_cold_, ws_cold_sz_, sizeof(double) * (5 * nJB + 3 * 64 * 64 + 128));
+    double *Z = w, *Z2 = Z + nJB, *Zt = Z2 + nJB, *GB = Zt + nJB, *Uo = GB + nJB;
+    double *C = Uo + nJB, *H = C + 64 * 64, *Yr = H + 64 * 64, *ev = Yr + 64 * 64;
+    int *status = (int *)(ev + 64);
+    HIP_CHECK(hipMemsetAsync(status, 0, 4 * sizeof(int), st_));
+    hipLaunchKernelGGL(k_fill_hash, dim3(grid_for((int64_t)nJB, 256)), dim3(256), 0, st_, Z, (int64_t)nJB,
+                       (uint64_t)(0x5eed + slot));
+    double *cur = Z, *oth = Z2;
+    for (int it = 0; it < 4; it++) {
+      transpose2d(cur, F64, J, b, Zt);
+      gemm_nt(G, J, Zt, b, nullptr, 0, oth, J, Ji, b, Ji, 1.0, 0.0);  // G * block
+      double *res = chol_qr2(oth, cur, J, b, C, status);             // two passes: ends in `oth`
+      if (res != oth) return false;
+      std::swap(cur, oth);
+    }
+    rayleigh_ritz(G, cur, J, b, Zt, GB, H, Yr, Uo, ev, nullptr);
+    double th[64];
+    int hs[4];
+    HIP_CHECK(hipMemcpyAsync(th, ev, sizeof(double) * b, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(hs, status, sizeof(int) * 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipGetLastError());
+    const int below = std::min(b - 1, rank + 4);  // index of the estimate placed under the cut
+    const bool ok = hs[0] != 1 && hs[1] == 0 && th[rank - 1] > 0 && th[below] >= 0 &&
+                    th[rank - 1] > th[below] * 1.02;
+    if (eig_debug_)
+      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: cold start, Ritz values %.4e .. %.4e | %.4e "
+                      "(index %d) -> %s\n", slot, (long long)J, rank, th[0], th[rank - 1], th[below],
+              below, ok ? "projector step" : "full solver");
+    if (!ok) return false;
+    if (!es.Q || es.J != J || es.rank != rank) {
+      if (es.Q) hipFree(es.Q);
+      HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+    }
+    es.J = J;
+    es.rank = rank;
+    HIP_CHECK(hipMemcpyAsync(es.Q, Uo, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
+    for (int d = 0; d < rank; d++) es.evh[d] = th[d];
+    es.lamR = th[rank - 1];
+    es.lamR1 = th[below];
+    es.rho = th[0];
+    es.rho_frob = 0;
+    es.valid = true;
+    return true;
   }
   double frob_shifted(const double *G, int64_t J, double sigma) {
     const int g = grid_for(J * J, 256, 1024);
@@ -1475,6 +1548,9 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
+  void *ws_cold_ = nullptr;
+  size_t ws_cold_sz_ = 0;
   double eig_sigma_scale_ = 0;  // PPALS_EIG_SIGMA_SCALE=f: shift = f * (estimate of the next eigenvalue) (tests)
   int gram_mfma_ = 1;     // PPALS_GRAM_MFMA=0: the fp64 VALU Gram kernel (A/B, tests)
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)

@@ -380,6 +380,12 @@ __global__ __launch_bounds__(256) void k_power_finish(const double *__restrict__
   for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = y[i] * inv;
   if (threadIdx.x == 0) *lam = rq;
 }
+// x[e] = a reproducible pseudo-random value in (-1, 1) (the start block of a cold subspace iteration)
+__global__ void k_fill_hash(double *__restrict__ x, int64_t n, uint64_t seed) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    x[e] = 2.0 * u01(seed, (uint64_t)e) - 1.0;
+}
 // E (J x n, zeroed by the caller): column t = unit vector e_j with j = (t + 1) J / (n + 1)
 __global__ void k_set_unit_cols(double *__restrict__ E, int64_t J, int n) {
   const int t = threadIdx.x;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(64) void k_chol_rinv(double *__restrict__ C, int r,
   double pmin = dmax;  // smallest pivot: dmax / pmin <= cond(C)
   for (int k = 0; k < r; k++) {
     const double d = L[k + r * k];
-    if (!(d > 1e-12 * dmax)) {
+    if (!(d > 1e-14 * dmax)) {
       bad = true;
       break;
     }

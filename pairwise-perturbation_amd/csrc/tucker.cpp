@@ -409,7 +409,9 @@ void TuckerEngine::hosvd() {
       ops_.unfold_gram(V_.data, V_.dtype, L, V_.glens[i], T, G_);
       if (dist_) comm_.allreduce_sum(G_, V_.glens[i] * V_.glens[i]);
     }
-    ops_.top_eigvecs(G_, V_.glens[i], r_[i], W_[i]);
+    // (slots 8.. : a cold start of their own — the Gram of the full unfolding has little to do
+    // with the one the first HOOI sweep will see in slot i)
+    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], MAX_ORDER + i);
   }
   compute_core_full();
   ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
