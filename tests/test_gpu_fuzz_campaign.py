@@ -124,8 +124,13 @@ def test_cp_pp_driver(pp, ctx, c, monkeypatch, tmp_path):
 @pytest.mark.parametrize("c", [x for x in _cases(max(2, NCASES // 3), SEED + 2) if len(x["lens"]) <= 5],
                          ids=lambda c: "-".join(map(str, c["lens"])))
 def test_tucker_sweeps(pp, ctx, c, monkeypatch, tmp_path):
-    lens = c["lens"]
+    lens = list(c["lens"])
     rng = np.random.default_rng(c["seed"])
+    if c["seed"] % 3 == 0 and len(lens) <= 4 and int(np.prod(lens)) < 4e5:
+        # one mode above 64: the projector route of the eigen-step, with its cold start from Ritz
+        # values and its wide tail, instead of the in-LDS Jacobi
+        k = int(np.argmax(lens))
+        lens[k] = 70 + c["seed"] % 90
     ranks = [int(rng.integers(1, max(2, min(s, 6)))) for s in lens]
     for i, r in enumerate(ranks):   # a rank above the product of the others is ill-posed
         ranks[i] = min(r, int(np.prod([q for j, q in enumerate(ranks) if j != i])))
