@@ -926,6 +926,25 @@ class HipOps : public Ops {
   void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) override {
     RoctxRange roctx_("K12/K13 unfold gram");
     const int64_t C = L * T;
+    if (gram_mfma_ && dt == F64 && J >= 64 && J <= 8192 && C >= 16 && C <= 4096 &&
+        (double)J * (double)C * 8.0 <= 64e6) {
+      // the Gram of a HOOI leaf (a few hundred rows and columns): the latency-bound symmetric
+      // product of the eigen-step (one 16 x 16 tile per workgroup, 8 waves split the columns) on
+      // the unfolding with the mode in front — 8 us instead of 31 at cfg5
+      const double *A = (const double *)X;
+      if (L > 1) {
+        double *Ym = (double *)ensure(ws_big2_, ws_big2_sz_, sizeof(double) * (size_t)J * C);
+        transpose_batched(X, F64, L, J, T, Ym);
+        A = Ym;
+      }
+      const int nt = (int)((J + 15) / 16);
+      prof_begin(1, (double)C * J * 8.0);
+      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(512), 0, st_, A, J,
+                         A, J, (const double *)nullptr, (int64_t)0, G, J, (int)J, (int)C, 1.0, 0.0);
+      prof_end();
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     const int tiles = (int)((J + 31) / 32);
     int nsplit = 1;
     const int64_t want = (int64_t)ncu_ * 4;
