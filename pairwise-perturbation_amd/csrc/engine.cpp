@@ -287,11 +287,23 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   ensure_transposed();
   if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
     // placement of the first-level intermediate, measured per root with the factors at hand
-    // (zeros: the timing does not depend on the values); nothing is kept but the offsets
+    // (zeros: the timing does not depend on the values); nothing is kept but the offsets.
+    // The block is sized ONCE, for the largest root set, before the first measurement: growing it
+    // later would move every root's result and void what was measured (unequal mode extents,
+    // [s/P, s, s, s] shards). Tuning happens here and nowhere else — never inside a timed sweep.
+    size_t xmax = 0;
     for (int r = 0; r < N_; r++) {
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
+      xmax = std::max(xmax, ms_X_bytes(r, ms_k_));
+    }
+    ms_X_base_ = big_alloc(xmax + ms_X_slack());
+    ms_X_cap_ = xmax + ms_X_slack();
+    ms_tuning_now_ = true;
+    for (int r = 0; r < N_; r++) {
+      if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;
       ms_start_step(r);
     }
+    ms_tuning_now_ = false;
     ms_invalidate();
     ms_X_.valid = false;
   }
@@ -421,6 +433,20 @@ void CpEngine::ensure_transposed() {
   for (int m = mid + 1; m < N_; m++) t.order.push_back(m);
   for (int m = 0; m <= mid; m++) t.order.push_back(m);
   choose_pad(t, std::min(N_ - 2, N_ - 1 - mid));  // the block must lie inside the right half
+  // An optional copy is taken only if what the session must still allocate fits behind it: the
+  // first-level intermediate (+ placement slack), the level-1 scratch of the PP build of the same
+  // size, tree nodes / pair operators (a few per cent of that) and a margin. (A Tucker session on
+  // the same tensor, or a second CP session, may still find the device full: big_alloc then gives
+  // the optional copies back.)
+  int64_t min_ext = ext(0);
+  for (int m = 1; m < N_; m++) min_ext = std::min(min_ext, ext(m));
+  const size_t xbytes_max = (size_t)(V_.nloc / std::max<int64_t>(1, min_ext)) * R_ * esz;
+  const size_t reserve = 3 * xbytes_max + ms_X_slack() + ((size_t)1 << 30);
+  auto fits = [&](size_t bytes) {
+    const size_t avail = ops_.mem_available();
+    return avail == (size_t)-1 || avail >= bytes + reserve;
+  };
+  if (!fits(bytes_of(t))) return;
   t.ptr = ops_.try_alloc(bytes_of(t));
   if (!t.ptr) return;
   t.owned = true;
@@ -430,7 +456,7 @@ void CpEngine::ensure_transposed() {
   Layout a;
   for (int m = 0; m < N_; m++) a.order.push_back(m);
   choose_pad(a, N_ - 2);
-  if (a.q > 0) {
+  if (a.q > 0 && fits(bytes_of(a))) {
     a.ptr = ops_.try_alloc(bytes_of(a));
     if (a.ptr) {
       a.owned = true;
@@ -833,6 +859,34 @@ size_t CpEngine::ms_X_slack() const {
   return bytes >= 1.5e9 ? ((size_t)64 << 20) + 4096 : 0;
 }
 
+// bytes of the first-level intermediate of the root set first .. first+k-1 (layout-independent)
+size_t CpEngine::ms_X_bytes(int first, int k) const {
+  int64_t J = 1;
+  for (int q = 0; q < k; q++) J *= ext((first + q) % N_);
+  return (size_t)(V_.nloc / J) * R_ * dtype_size(V_.dtype);
+}
+
+// Allocation of one of the session's large buffers. The optional resident layouts (the padded
+// third copy, then the second copy) were taken while the device still had room; when a MANDATORY
+// buffer does not fit any more they are given back, one at a time, and the allocation is retried —
+// the scans then read the layouts that are left (plan_scan), slower but correct. Callers must not
+// hold a ScanPlan across this call.
+void *CpEngine::big_alloc(size_t bytes) {
+  for (;;) {
+    void *p = ops_.try_alloc(bytes);
+    if (p) return p;
+    if (lay_.size() > 1 && lay_.back().owned) {
+      ops_.sync();
+      ops_.free(lay_.back().ptr);
+      lay_.pop_back();
+      if (lay_.size() == 1) vt_state_ = -1;
+      for (auto &n : nodes_) n.valid = false;
+      continue;
+    }
+    return ops_.alloc(bytes);  // throws with the back end's message
+  }
+}
+
 // new step: X = V contracted with the k root modes first, ..., first + k - 1 (cyclic) in ONE
 // tensor scan on whichever resident layout stores them next to each other and behind at least one
 // other mode; X is kept in the tensor's own precision
@@ -842,6 +896,19 @@ void CpEngine::ms_start_step(int first) {
   ms_order_.clear();
   for (int q = k; q < N_; q++) ms_order_.push_back((first + q) % N_);
   for (auto &n : ms_nodes_) n.t.valid = false;
+  // X at this root's offset inside the over-allocated block (see engine.h, ms_X_off_); sized
+  // before the scan is planned (big_alloc may give a resident layout back)
+  const size_t xbytes = ms_X_bytes(first, k);
+  const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;
+  if (ms_X_cap_ < xbytes + slack) {
+    ops_.free(ms_X_base_);
+    ms_X_base_ = nullptr;
+    ms_X_cap_ = 0;
+    ms_X_base_ = big_alloc(xbytes + slack);
+    ms_X_cap_ = xbytes + slack;
+    // (the offsets measured at session set-up stay valid — they are bounded by the slack — but
+    // nothing is re-measured here: this may be a timed sweep)
+  }
   ScanPlan pl;
   if (!plan_scan(first, k, false, pl)) {
     // a root set that wraps around the last mode is adjacent only in the second layout; without
@@ -862,21 +929,14 @@ void CpEngine::ms_start_step(int first) {
   }
   ms_X_.dt = V_.dtype;
   ms_X_.contracted = mask;
-  // X at this root's offset inside the over-allocated block (see engine.h, ms_X_off_)
-  const size_t xbytes = (size_t)L * T * R_ * dtype_size(ms_X_.dt);
-  const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;
-  if (ms_X_cap_ < xbytes + slack) {
-    ops_.free(ms_X_base_);
-    ms_X_base_ = ops_.alloc(xbytes + slack);
-    ms_X_cap_ = xbytes + slack;
-    for (int q = 0; q < MAX_ORDER; q++) ms_tuned_[q] = false;
-  }
+  if ((size_t)L * T * R_ * dtype_size(ms_X_.dt) != xbytes)
+    throw std::runtime_error("ppals: internal error (first-level intermediate size)");
   auto launch_scan = [&](int64_t off) {
     ms_X_.buf = (char *)ms_X_base_ + off;
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
   };
-  if (slack > 0 && !ms_tuned_[first]) {
+  if (slack > 0 && !ms_tuned_[first] && ms_tuning_now_) {
     // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
     // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
     ms_tuned_[first] = true;
@@ -1248,7 +1308,7 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
     // (at order 3 a level-1 result already IS a pair operator: those stay fp64 like all the others)
     op.dt = (pp_fast_ && N_ > 3) ? V_.dtype : F64;
     if (pp_fast_ && N_ > 3 && schedule_ == 1 && ms_k_ == 1 && ms_root_ == mode && ms_X_.valid &&
-        ms_X_.dt == op.dt) {
+        ms_X_.dt == op.dt && !pp_no_borrow_) {
       // The exact sweep that ended just now left its first-level intermediate X = V x_mode W_mode
       // in the multi-sweep cache, and W_mode has not changed since (a step never updates its own
       // root; Normalize is the pending scalar): that IS this level-1 operator. One of the three
@@ -1258,7 +1318,13 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
       op.scale = ms_scale_of(ms_X_);
       op.modes = ms_X_.modes;
     } else {
-      op.buf = pp_buffer(seq, dtype_size(op.dt) * (size_t)op.elems * R_);
+      op.buf = pp_buffer(seq, dtype_size(op.dt) * (size_t)(V_.nloc / ext(mode)) * R_);
+      // (planned again: the allocation may have given a resident layout back)
+      if (!plan_scan(mode, 1, !(pp_fast_ && N_ >= 3), pl))
+        throw std::runtime_error("ppals: internal error (single mode not adjacent)");
+      L = pl.Lc;
+      T = pl.T;
+      op.modes = pl.kept;
       ops_.scan_contract(pl.lay->ptr, V_.dtype, pl.L, ext(mode), T, &f, 1, R_, op.buf, op.dt, L,
                          op.elems, pl.pad);
     }
@@ -1289,11 +1355,31 @@ void CpEngine::pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, do
     ops_.mttv(T.buf, F64, ext(T.modes[0]), ext(cmode), 1, &f, 1, R_, out, out_rows, 1, nullptr);
 }
 void CpEngine::pp_clear() { pp_.clear(); }  // the buffers stay in the pool
+// Buffer of the operator `seq` from the grow-only pool. What the approximate sweeps read — the pair
+// operators (N-2 modes contracted) and the full MTTKRPs — has a buffer of its own per key.
+// Everything above them in the recursion of Build_mttkrp_map is scaffolding, read only while the
+// operators below it are built; pp_build_all visits the keys in an order in which all users of a
+// prefix are consecutive, so ONE buffer per level serves every scaffold of that level (order 4:
+// one s^3 R level-1 tensor instead of three; order 6, s = 50, R = 6: 7.5 GB instead of 37.5 GB).
+// A scaffold that takes the level's buffer over evicts the previous holder from the cache.
 void *CpEngine::pp_buffer(const std::string &seq, size_t bytes) {
-  PPBuf &b = pp_pool_[seq];
+  const bool scaffold = (int)seq.size() < N_ - 2;
+  const std::string key = scaffold ? "#" + std::to_string(seq.size()) : seq;
+  if (scaffold) {
+    for (auto it = pp_.begin(); it != pp_.end();) {
+      if (it->first.size() == seq.size() && it->second.owned) {
+        it = pp_.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  PPBuf &b = pp_pool_[key];
   if (b.cap < bytes) {
     ops_.free(b.buf);
-    b.buf = ops_.alloc(bytes);
+    b.buf = nullptr;
+    b.cap = 0;
+    b.buf = big_alloc(bytes);
     b.cap = bytes;
   }
   return b.buf;
@@ -1320,6 +1406,18 @@ void CpEngine::pp_build_all() {
       ++it;
     }
   }
+  // ... and its buffers go back to the device when they are large (PPALS_PP_SCRATCH_KEEP bytes,
+  // default 2 GiB: below that, keeping one per level saves the hipMalloc / hipFree of every phase)
+  size_t keep = (size_t)2 << 30;
+  if (const char *e = std::getenv("PPALS_PP_SCRATCH_KEEP")) keep = (size_t)std::atoll(e);
+  for (auto it = pp_pool_.begin(); it != pp_pool_.end();) {
+    if (it->first[0] == '#' && it->second.cap > keep) {
+      ops_.free(it->second.buf);
+      it = pp_pool_.erase(it);
+    } else {
+      ++it;
+    }
+  }
 }
 int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   for (size_t k = 0; k < contracted.size(); k++) {
@@ -1328,6 +1426,9 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   }
   if (contracted.empty() || (int)contracted.size() >= N_) return -1;
   pp_clear();
+  // (never the borrowed multi-sweep intermediate here: it carries a Normalize factor that only the
+  // contractions below it apply — this entry point hands the operator itself to the caller)
+  pp_no_borrow_ = true;
   const PPOp *op = &pp_get(contracted);
   const bool saved = pp_fast_;
   if (op->dt != F64 || !std::is_sorted(op->modes.begin(), op->modes.end())) {
@@ -1340,6 +1441,7 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   int64_t n = op->elems * R_;
   pp_clear();
   pp_fast_ = saved;
+  pp_no_borrow_ = false;
   return n;
 }
 

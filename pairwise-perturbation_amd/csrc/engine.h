@@ -113,8 +113,9 @@ class CpEngine {
     bool owned = true;       // false: borrowed from the multi-sweep cache (never freed here)
     const double *scale = nullptr;  // pending Normalize factor of a borrowed tensor (device scalar)
   };
-  // grow-only pool of the PP operator buffers, by key: a PP phase re-uses the buffers of the
-  // previous one instead of allocating / freeing ~1 GB of operators around every phase
+  // grow-only pool of the PP operator buffers: a PP phase re-uses the buffers of the previous one
+  // instead of allocating / freeing ~1 GB of operators around every phase. Keyed by operator for
+  // what the approximate sweeps read, by LEVEL ("#1", "#2", ...) for the scaffolding above it
   struct PPBuf {
     void *buf = nullptr;
     size_t cap = 0;
@@ -166,6 +167,9 @@ class CpEngine {
   bool ms_tuned_[MAX_ORDER] = {false};
   bool ms_tune_enabled_ = true;
   size_t ms_X_slack() const;
+  size_t ms_X_bytes(int first, int k) const;
+  bool ms_tuning_now_ = false;  // placement is measured at session set-up only
+  void *big_alloc(size_t bytes);  // gives optional resident layouts back when the device is full
   std::vector<MsNode> ms_nodes_;
   std::vector<int> ms_order_;  // the N-k modes of the step in update order
   std::vector<int> ms_leaf_;   // node index of each list position
@@ -185,6 +189,7 @@ class CpEngine {
   // out (+)= T contracted over `cmode` with f; T is a pair operator (two modes, any storage order)
   void pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, double *out, int64_t out_rows);
   bool pp_fast_ = true;  // both resident layouts + typed level-1 operators (PPALS_PP_FAST=0: off)
+  bool pp_no_borrow_ = false;  // pp_operator(): never hand out the (scaled) multi-sweep intermediate
   void pp_clear();
   void pp_build_all();
   void sweep_pp(double lambda, double ratio);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "hip_ops.h"
@@ -114,11 +115,10 @@ class HipOps : public Ops {
     if (ws_cold_) hipFree(ws_cold_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
-    for (auto &es : eig_state_) {
-      if (es.Q) hipFree(es.Q);
-    }
-    for (auto &sm : eig_small_)
-      if (sm.Q) hipFree(sm.Q);
+    for (auto &kv : eig_state_)
+      if (kv.second.Q) hipFree(kv.second.Q);
+    for (auto &kv : eig_small_)
+      if (kv.second.Q) hipFree(kv.second.Q);
     hipStreamDestroy(st_);
   }
 
@@ -392,6 +392,15 @@ class HipOps : public Ops {
       return nullptr;
     }
     return p;
+  }
+  size_t mem_available() override {
+    size_t fr = 0, tot = 0;
+    hipSetDevice(dev_);
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+      (void)hipGetLastError();
+      return (size_t)-1;
+    }
+    return fr;
   }
   void unpack_shards(const void *stage, int dt, int64_t s0, int64_t rest, int64_t blk, int P,
                      int64_t chunk_bytes, void *full) override {
@@ -1122,7 +1131,7 @@ class HipOps : public Ops {
     bool valid = false;
     int age = 0;
   };
-  SmallEig eig_small_[16];
+  std::map<int, SmallEig> eig_small_;  // by slot (session base + mode, see eig_session_new)
   void top_eigvecs_small_warm(double *G, int64_t J, int rank, double *U, int slot) {
     SmallEig &sm = eig_small_[slot];
     const int Ji = (int)J;
@@ -1155,11 +1164,11 @@ class HipOps : public Ops {
   }
   void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int slot) override {
     RoctxRange roctx_("K12 eig (projector route)");
-    if (J >= 16 && J <= 64 && rank <= J && slot >= 0 && slot < 16 && eig_fast_) {
+    if (J >= 16 && J <= 64 && rank <= J && slot >= 0 && eig_fast_) {
       top_eigvecs_small_warm(G, J, rank, U, slot);
       return;
     }
-    if (J <= 64 || rank > 64 || rank >= J || slot < 0 || slot >= 16 || !eig_fast_) {
+    if (J <= 64 || rank > 64 || rank >= J || slot < 0 || !eig_fast_) {
       top_eigvecs(G, J, rank, U);
       return;
     }
@@ -1173,7 +1182,34 @@ class HipOps : public Ops {
     if (eig_cold_ && cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true))
       return;
     es.valid = false;
+    if (eig_debug_)
+      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: full solver (dsyevd)\n", slot, (long long)J, rank);
     eig_bootstrap(es, G, J, rank, U);
+  }
+  // Warm-start state belongs to the SESSION that made it: a session draws a block of 64 slots
+  // here and gives it back when it ends, so sessions that alternate on one context (or the thin
+  // c x c route and its s x s fallback inside one factor update, which use different slots of the
+  // block) never see each other's bases, gaps or eigenvalue scales.
+  int eig_session_new() override {
+    eig_next_base_ += 64;
+    return eig_next_base_;
+  }
+  void eig_session_free(int base) override {
+    hipStreamSynchronize(st_);
+    for (auto it = eig_state_.begin(); it != eig_state_.end();)
+      if (it->first >= base && it->first < base + 64) {
+        if (it->second.Q) hipFree(it->second.Q);
+        it = eig_state_.erase(it);
+      } else {
+        ++it;
+      }
+    for (auto it = eig_small_.begin(); it != eig_small_.end();)
+      if (it->first >= base && it->first < base + 64) {
+        if (it->second.Q) hipFree(it->second.Q);
+        it = eig_small_.erase(it);
+      } else {
+        ++it;
+      }
   }
   // One projector step from the state of the slot; false: not accepted (the caller falls back).
   // strict: the state is a rough estimate (cold start) — accept only residuals at the rounding
@@ -1295,7 +1331,6 @@ class HipOps : public Ops {
       ell = 0.5 * mu * ell * (3.0 - mu * mu * ell * ell);
     }
     for (int k = 0; k < 2; k++) ns_step(1.0);
-    const double gap = es.lamR - es.lamR1;
     for (int attempt = 0;; attempt++) {
       // ---- check of the sign iteration: ||X^2 - I||_F^2 and trace(X) (-> chk[0], chk[1])
       hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
@@ -1345,8 +1380,11 @@ class HipOps : public Ops {
       const bool converged = hc[0] <= 1e-20 * (double)J;
       // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
       // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
-      const double res_tol = (strict ? 1e-13 * std::max(es.evh[0], evn[0])
-                                     : std::max(1e-9 * gap, 1e-14 * es.evh[0])) *
+      // (from THIS step's quantities only: trace(P) == rank says that exactly `rank` eigenvalues
+      // lie above this step's shift, so the gap below the rank-th one is at least its distance to
+      // the shift; the slot's previous gap / eigenvalue scale only scheduled the iteration)
+      const double gap_now = std::max(0.0, evn[rank - 1] - sigma);
+      const double res_tol = (strict ? 1e-13 * evn[0] : std::max(1e-9 * gap_now, 1e-14 * evn[0])) *
                              std::sqrt((double)rank);
       const bool good = converged && std::fabs(cnt - rank) < 1e-6 && hs[0] == 0 && hs[2] != 1 && hs[3] == 0 &&
                         res <= res_tol && std::isfinite(rho_now);
@@ -1355,7 +1393,7 @@ class HipOps : public Ops {
                         "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
                         "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
                 slot, (long long)J, rank, es.lamR, es.lamR1, m, rho, rho_now, ell0, iters, hc[0], cnt,
-                res, gap, hs[0], hs[1], hs[2], hs[3],
+                res, gap_now, hs[0], hs[1], hs[2], hs[3],
                 good ? "accepted" : (converged ? "not accepted as it is" : "more steps"), es.fast, es.full);
       if (good) {
         for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
@@ -1575,7 +1613,8 @@ class HipOps : public Ops {
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)
-  EigState eig_state_[16];
+  std::map<int, EigState> eig_state_;  // by slot
+  int eig_next_base_ = 0;
   void *eig_host_ = nullptr;  // pinned: the read-back of a projector step
   void *ws_eig_ = nullptr, *ws_orth_ = nullptr, *ws_pow_ = nullptr, *ws_part2_ = nullptr;
   size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;

@@ -115,6 +115,8 @@ class Ops {
                              int P, int64_t chunk_bytes, void *full) = 0;
   // alloc that returns nullptr instead of throwing when the device is out of memory
   virtual void *try_alloc(size_t bytes) { return alloc(bytes); }
+  // free device memory in bytes, (size_t)-1: unknown / unlimited
+  virtual size_t mem_available() { return (size_t)-1; }
 
   // ---- Khatri-Rao product, plain: out[j + J*c] = prod_f W_f[j_f + ld_f*(col0+c)], fp64 ----
   virtual void krp(double *out, const FactorRef *f, int nf, int col0, int ncols) = 0;
@@ -254,6 +256,10 @@ class Ops {
   virtual void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int /*slot*/) {
     top_eigvecs(G, J, rank, U);
   }
+  // A session's block of 64 warm-start slots [base, base + 64) (what a back end remembers under a
+  // slot dies with the session that drew the block)
+  virtual int eig_session_new() { return 0; }
+  virtual void eig_session_free(int /*base*/) {}
   // U (rows x r, column-major, ld = rows) -> orthonormal columns spanning the same nested
   // subspaces (column k stays in span(U[:, :k+1]) with a positive component on the old column k:
   // a QR factorisation's Q). Returns false, leaving U unspecified, when U is numerically rank

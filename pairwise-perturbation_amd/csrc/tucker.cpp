@@ -31,6 +31,7 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   P_ = comm.size();
   dist_ = P_ > 1 || (force_comm_path() && !comm.is_self());
   rank_ = comm.rank();
+  eig_base_ = ops_.eig_session_new();  // this session's warm-start slots: base + {i, 8 + i, 16 + i}
   int64_t maxs = 0;
   for (int i = 0; i < N_; i++) {
     if (ranks[i] <= 0 || ranks[i] > V_.glens[i])
@@ -87,6 +88,10 @@ void TuckerEngine::check_tensor_generation() {
 TuckerEngine::~TuckerEngine() {
   try {
     ops_.sync();
+  } catch (...) {
+  }
+  try {
+    ops_.eig_session_free(eig_base_);
   } catch (...) {
   }
   for (auto p : W_) ops_.free(p);
@@ -411,7 +416,7 @@ void TuckerEngine::hosvd() {
     }
     // (slots 8.. : a cold start of their own — the Gram of the full unfolding has little to do
     // with the one the first HOOI sweep will see in slot i)
-    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], MAX_ORDER + i);
+    ops_.top_eigvecs_warm(G_, V_.glens[i], r_[i], W_[i], eig_base_ + MAX_ORDER + i);
   }
   compute_core_full();
   ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);
@@ -442,12 +447,13 @@ void TuckerEngine::factor_update(int i, const double *Y, int64_t L, int64_t T) {
     }
     double *Vr = thin_ + s * c;
     ops_.unfold_gram(Ym, F64, s, c, 1, G_);  // c x c (c < s: fits G_)
-    ops_.top_eigvecs_warm(G_, c, r_[i], Vr, i);
+    // (a slot of its own: the c x c problem and the s x s fallback below are different sequences)
+    ops_.top_eigvecs_warm(G_, c, r_[i], Vr, eig_base_ + 2 * MAX_ORDER + i);
     ops_.ttm_keep(Ym, F64, s, c, 1, Vr, c, r_[i], W_[i]);
     if (ops_.orthonormalize(W_[i], s, r_[i])) return;
   }
   ops_.unfold_gram(Y, F64, L, s, T, G_);
-  ops_.top_eigvecs_warm(G_, s, r_[i], W_[i], i);
+  ops_.top_eigvecs_warm(G_, s, r_[i], W_[i], eig_base_ + i);
 }
 
 void TuckerEngine::sweep_dt() { sweep_body(nullptr); }

@@ -26,6 +26,8 @@ test_pp_operators = G.test_pp_operators
 test_gram_system = G.test_gram_system
 test_jacobi_fallback_path = G.test_jacobi_fallback_path
 test_dt_sweeps_match_oracle = G.test_dt_sweeps_match_oracle
+test_normalize_and_owed_scale = G.test_normalize_and_owed_scale
+test_pp_operator_after_msdt_sweeps = G.test_pp_operator_after_msdt_sweeps
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
 test_driver_pp_partupdate_matches_oracle = G.test_driver_pp_partupdate_matches_oracle

@@ -191,7 +191,98 @@ def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule):
         assert relerr(a, b) < ftol, relerr(a, b)
     gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
     assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
+    # grad_W[i] = -M + W_i S (als_CP.cxx:296) element by element, against the scale that formed
+    # it: -M and W_i S cancel to ~||grad|| << ||M|| near a solution, so the bar is relative to ||M||
+    for i, (a, b) in enumerate(zip(G_got, G_ref)):
+        scale = np.linalg.norm(W_ref[i] @ O.gram_hadamard(W_ref, i)) + np.linalg.norm(b)
+        assert np.linalg.norm(a - b) < 50 * ftol * scale, (i, np.linalg.norm(a - b), scale)
     assert abs(s.residual() - O.residual(V, W_ref)) < 1e-4 * np.linalg.norm(V) * (1 if dtype == 0 else 1e-4)
+
+
+def _scalar_multiple(a, b, tol):
+    """a == c * b for ONE scalar c > 0 (returned)"""
+    c = np.vdot(b, a) / np.vdot(b, b)
+    assert c > 0 and relerr(a, c * b) < tol, (c, relerr(a, c * b))
+    return c
+
+
+@pytest.mark.parametrize("roots", [1, 2])
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", [([12, 10, 9, 11], 4), ([14, 9, 11], 3), ([6, 5, 4, 5, 4, 3], 2),
+                                    ([9, 7, 8, 6, 5], 2)])
+def test_normalize_and_owed_scale(pp, ctx, lens, R, dtype, roots, monkeypatch):
+    """K7 in isolation (Normalize, common.cxx:644-689, and the engine's bookkeeping around it).
+    (1) One sweep WITH Normalize against one sweep of the class API, which has none
+    (src/CP.cxx:171): every factor is ONE positive scalar times the un-normalised factor, the
+    scalars multiply to 1 (the model tensor is unchanged), all ||W_i||_F come out equal, and the
+    cached Grams were rescaled with them (gram_system afterwards == Hadamard of the returned
+    factors' Grams). (2) The multi-sweep schedule does not rescale its cached tensors but carries
+    the factor OWED to each (X_r and the tree nodes built before the Normalize) into the next
+    contraction that reads it: after exactly two sweeps the gradient of every mode — whose MTTKRP
+    went through an owed scalar for the modes served by the carried-over step — matches the
+    oracle's element by element; a wrong or missing factor shows up as an O(1) error in exactly
+    those modes."""
+    N = len(lens)
+    if roots > N - 2:
+        pytest.skip("root set too large for this order")
+    monkeypatch.setenv("PPALS_MSDT_ROOTS", str(roots))
+    V, W = problem(lens, R, 5, "r")
+    G = O.init_factors(lens, R, 99)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    ktol = 20 * KTOL[dtype]
+    for schedule in ("msdt", "dt"):
+        s = pp.CP(ctx, t, R)
+        s.set_schedule(schedule)
+        s.set_factors(W, G)
+        s.sweeps_dt(1)
+        W1 = s.get_factors()
+        _, sw, _, W_nn, _ = O.cpd_als(V, W, G, 0, tol=0.0, maxsweep=0, resprint=10 ** 9)
+        assert sw == 1.0
+        cs = [_scalar_multiple(a, b, ktol) for a, b in zip(W1, W_nn)]
+        assert abs(np.prod(cs) - 1.0) < ktol
+        norms = [np.linalg.norm(a) for a in W1]
+        assert max(norms) - min(norms) < 1e-12 * max(norms)
+        for a, b in zip(W1, O.normalize(W_nn)):
+            assert relerr(a, b) < ktol
+        for i in range(N):
+            S, _ = s.gram_system(i, 0.0)
+            assert relerr(S, O.gram_hadamard(W1, i)) < 1e-12, (schedule, i)
+        s.sweeps_dt(1)
+        W2, G2 = s.get_factors(with_grad=True)
+        _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=1, resprint=10 ** 9)
+        for i in range(N):
+            assert relerr(W2[i], W_ref[i]) < 50 * ktol, (schedule, i, relerr(W2[i], W_ref[i]))
+            scale = np.linalg.norm(W_ref[i] @ O.gram_hadamard(W_ref, i)) + np.linalg.norm(G_ref[i])
+            assert np.linalg.norm(G2[i] - G_ref[i]) < 50 * ktol * scale, (schedule, i)
+        s.close()
+    t.close()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("lens,R", [([6, 7, 5, 8], 3), ([9, 8, 7, 6, 5], 2)])
+def test_pp_operator_after_msdt_sweeps(pp, ctx, lens, R, dtype, monkeypatch):
+    """ppals_pp_operator between sweeps: inside a run the PP build borrows the multi-sweep
+    intermediate X_r (with the Normalize factor it is owed) as one of its level-1 operators; the
+    kernel-level entry point must hand out the operator itself — V contracted with the CURRENT
+    factors — whatever the sweep schedule left in its caches (Build_mttkrp_map, als_CP.cxx:352-409)"""
+    monkeypatch.setenv("PPALS_MSDT_ROOTS", "1")
+    V, W = problem(lens, R, 6, "r")
+    G = O.init_factors(lens, R, 99)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    N = len(lens)
+    for schedule in ("msdt", "dt"):
+        s = pp.CP(ctx, t, R)
+        s.set_schedule(schedule)
+        s.set_factors(W, G)
+        for nsweeps in (1, 3):
+            s.sweeps_dt(nsweeps)
+            Wc = s.get_factors()
+            for key in [chr(97 + m) for m in range(N)] + ["ab", "".join(chr(97 + m) for m in range(1, N))]:
+                got = s.pp_operator(key)
+                want = O.pp_operator(V, Wc, key).ravel(order="F")
+                assert relerr(got, want) < 5 * KTOL[dtype], (schedule, nsweeps, key, relerr(got, want))
+        s.close()
+    t.close()
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
