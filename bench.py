@@ -138,6 +138,148 @@ def cpu_baseline(lens, R, budget_s=25.0):
     }
 
 
+def _csv_rows(path):
+    rows = []
+    for ln in open(path).read().splitlines()[1:]:
+        if ln.strip():
+            rows.append([float(x) for x in ln.split(",")])
+    return rows
+
+
+def _bench_lines(path):
+    out = {}
+    for ln in open(path).read().splitlines():
+        if "," in ln and ln.strip().startswith("["):
+            k, v = ln.split(",")[:2]
+            try:
+                out.setdefault(k.strip(), []).append(float(v))
+            except ValueError:
+                pass
+    return out
+
+
+def _median(x):
+    x = sorted(x)
+    return x[len(x) // 2] if x else None
+
+
+def cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir):
+    """BASELINE configs[2]: `-pp 1` against `-pp 0` on the resident cfg2 tensor, measured the way
+    the reference measures it — the [dtime] column of alsCP_DT / alsCP_PP (print blocks excluded,
+    als_CP.cxx:167,189-190) and the [DTtime] / [PPfirst] / [PPsecond] lines of their `bench` mode
+    (als_CP.cxx:204-208,736-747; pp_bench.cxx:295-314: every repetition from the same factors)."""
+    cp = ppals.CP(ctx, V, R)
+    kw = dict(tol=1e-10 * vnorm, maxiter=300, resprint=10)
+    dt_csv, pp_csv, pp1_csv, b_csv = (os.path.join(tmpdir, n) for n in
+                                      ("dt.csv", "pp.csv", "pp1.csv", "bench.csv"))
+    cp.set_factors(W0, G0)
+    cp.run_dt(csv=dt_csv, **kw)
+    cp.set_factors(W0, G0)
+    cp.run_pp(csv=pp_csv, tol_init=0.01, **kw)
+    dt, pp = _csv_rows(dt_csv), _csv_rows(pp_csv)
+    floor = 1.02 * max(min(r[5] for r in dt), min(r[5] for r in pp))
+
+    def first_at(rows):
+        for r in rows:
+            if r[5] <= floor:
+                return {"iter": int(r[1]), "dtime_s": r[6]}
+        return None
+    # per-sweep split by [pp_update]: the same run with a row per iteration (each row costs a
+    # stream sync, so these are upper bounds of the in-flight sweep times)
+    cp.set_factors(W0, G0)
+    cp.run_pp(csv=pp1_csv, tol_init=0.01, tol=1e-10 * vnorm, maxiter=300, resprint=1)
+    r1 = _csv_rows(pp1_csv)
+    split = {"dt": [], "pp": [], "pp_init": []}
+    # A row is printed BEFORE the sweep of its iteration, so the interval to the next row is the
+    # sweep of the row's own kind. The exact phase returns without counting its last sweep
+    # (als_CP.cxx:594-605) and the PP phase prints a row on entry (als_CP.cxx:697): (k,0) -> (k,1)
+    # is that exact sweep, (k,1) -> (k+1,1) the operator build (als_CP.cxx:667-695) + one PP sweep.
+    for k in range(1, len(r1)):
+        a, b = r1[k - 1], r1[k]
+        kind = "dt" if a[4] == 0 else ("pp_init" if (k >= 2 and r1[k - 2][4] == 0) else "pp")
+        split[kind].append(b[6] - a[6])
+    with open(b_csv, "w") as f:
+        f.write("[timetype],[dtime]\n")
+    reps = 5
+    for _ in range(reps):
+        cp.set_factors(W0, G0)
+        cp.run_dt(tol=1e-10 * vnorm, maxiter=1, resprint=1, bench=1, csv=b_csv, csv_append=1)
+    for _ in range(reps):
+        cp.set_factors(W0, G0)
+        cp.run_pp(tol=1e-10 * vnorm, tol_init=0.01, maxiter=1, resprint=1, bench=1, csv=b_csv,
+                  csv_append=1)
+    bl = _bench_lines(b_csv)
+    cp.close()
+    return {
+        "config": "BASELINE configs[2]: CP order-4 s=200 R=10 -tensor r, -pp 1 -pp_res_tol 0.01 vs "
+                  "-pp 0, 300 iterations each, -resprint 10, fp32 tensor storage",
+        "dt_total_dtime_s": dt[-1][6], "pp_total_dtime_s": pp[-1][6],
+        "pp_rows_flagged_pp_update": sum(1 for r in pp if r[4] == 1), "rows": len(pp),
+        "diffV_floor": floor, "dt_first_at_floor": first_at(dt), "pp_first_at_floor": first_at(pp),
+        "final_gradnorm": {"dt": dt[-1][2], "pp": pp[-1][2]},
+        "sweeps_per_s_by_pp_update": {
+            k: (len(v) / sum(v) if v and sum(v) > 0 else None) for k, v in split.items()},
+        "sweeps_counted_by_pp_update": {k: len(v) for k, v in split.items()},
+        "bench_mode_ms": {"[DTtime]": 1e3 * _median(bl.get("[DTtime]", [])),
+                          "[PPfirst]": 1e3 * _median(bl.get("[PPfirst]", [])),
+                          "[PPsecond]": 1e3 * _median(bl.get("[PPsecond]", [])), "repetitions": reps,
+                          "note": "medians; every line a cold, synchronised measurement from the "
+                                  "same factors, as pp_bench.cxx:299-314"},
+    }
+
+
+def cfg5_tucker_record(ppals, ctx, tmpdir):
+    """BASELINE configs[4]: Tucker order-3 s=400 core 20^3 on `-tensor r2` (test_ALS.cxx:272), HOSVD
+    initialisation + 40 HOOI sweeps of alsTucker_DT (als_Tucker.cxx:240-424), fp32 storage."""
+    lens, ranks = [400, 400, 400], [20, 20, 20]
+    V = ppals.Tensor(ctx, lens, ppals.F32).fill_uniform(7)
+    tk = ppals.Tucker(ctx, V, ranks)
+    tk.hosvd()                       # warm-up of the one-off paths (workspaces, solver handle)
+    ctx.sync()
+    t0 = time.perf_counter()
+    tk.hosvd()
+    ctx.sync()
+    hosvd_ms = 1e3 * (time.perf_counter() - t0)
+    csv = os.path.join(tmpdir, "tucker.csv")
+    tk.run_dt(tol=0.0, maxiter=40, resprint=10, csv=csv)
+    rows = _csv_rows(csv)
+    # steady state: sweeps 10..40 of the driver's own [dtime] column
+    r10 = [r for r in rows if r[1] == 10][0]
+    steady_ms = 1e3 * (rows[-1][6] - r10[6]) / (rows[-1][1] - r10[1])
+    # kernel split of a sweep, HIP events on the engine's stream (untimed pass)
+    n = 10
+    ctx.profile_reset()
+    ctx.profile_enable(2)
+    tk.sweeps_dt(n)
+    ctx.sync()
+    ctx.profile_enable(0)
+    ls, scan_ms, scan_bytes = ctx.profile_read(0)
+    lg, gram_ms, _ = ctx.profile_read(1)
+    rec = {
+        "config": "BASELINE configs[4]: Tucker order-3 s=400 core 20x20x20, -tensor r2, hosvd + "
+                  "alsTucker_DT 40 sweeps, fp32 tensor storage, 1 GPU",
+        "hosvd_ms": hosvd_ms, "ms_per_hooi_sweep": steady_ms,
+        "ms_per_hooi_sweep_incl_first_10": 1e3 * rows[-1][6] / rows[-1][1],
+        "total_dtime_s_40_sweeps": rows[-1][6],
+        "final_diffnorm": rows[-1][2], "final_diffV": rows[-1][5],
+        "scan_ms_per_sweep": scan_ms / n, "scan_launches_per_sweep": ls / n,
+        "gram_ms_per_sweep": gram_ms / n,
+        "eigen_step_us": 1e3 * max(steady_ms - scan_ms / n - gram_ms / n, 0.0) / 3.0,
+        "eigen_step_note": "(sweep - tensor scans - Grams) / 3 modes: the spectral-projector step "
+                           "incl. its launches' gaps",
+    }
+    if ls > 0 and scan_ms > 0:
+        ach = scan_bytes / (scan_ms * 1e-3) / 1e9
+        rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "launches": ls,
+                           "avg_launch_ms": scan_ms / ls,
+                           "algorithmic_bytes_per_launch": scan_bytes / ls,
+                           "kernel": "tensor scans of the TTMc chain (K11)"}
+    tk.close()
+    V.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +291,8 @@ def main():
     ap.add_argument("--schedule", default=None, choices=["dt", "msdt"],
                     help="sweep schedule (default: the engine's, msdt); same ALS iterates either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-records", action="store_true",
+                    help="skip the cfg3 (PP) / cfg4 (s=400) / cfg5 (Tucker) sub_records at N = 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,6 +304,13 @@ def main():
     import numpy as np
     import torch  # first: libppals.so then shares torch's libamdhip64 / librccl
     import ppals
+    config_records = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_config_records
+                      and args.workload == "cp4_s200_r10" and args.dtype == "f32"
+                      and not args.schedule)
+    if config_records:
+        # the Tucker record's HOSVD uses rocSOLVER: its libraries must enter the process before the
+        # HIP runtime is up (include/ppals.h, ppals_preload_eigensolver)
+        ppals.preload_eigensolver()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
@@ -185,6 +336,7 @@ def main():
         dist.broadcast(uid, 0)
         ctx.init_comm(rank, world, bytes(uid.cpu().numpy().tobytes()))
 
+    nranks_seen = ctx.nranks   # read back from ppals_ctx_nranks: 1 without a communicator
     Wtrue = ppals.init_factors(lens, R, 1000)
     W0 = ppals.init_factors(lens, R, 2000)
     G0 = ppals.init_factors(lens, R, 3000)
@@ -195,10 +347,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def measure(cp, steps, warmup):
+    def measure(cp, steps, warmup, W=None, G=None):
         """W untimed sweeps, then EXACTLY `steps` timed ones between barrier + synchronize on both
         sides (max over ranks); HIP events on the engine's stream around the tensor scans only"""
-        cp.set_factors(W0, G0)
+        cp.set_factors(W if W is not None else W0, G if G is not None else G0)
         cp.sweeps_dt(warmup)
         barrier()
         ctx.profile_reset()
@@ -279,6 +431,13 @@ def main():
         else:
             os.environ["PPALS_COMM_SMALL_BYTES"] = old
     cp.close()
+    if config_records:
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmpdir:
+            try:
+                sub["cfg3_pp"] = cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir)
+            except Exception as e:  # reported, never required
+                sub["cfg3_pp"] = {"error": str(e)}
     V.close()
     if world == 1 and args.dtype == "f32" and not args.schedule and args.workload == "cp4_s200_r10":
         V64 = ppals.Tensor(ctx, lens, ppals.F64).fill_cp(Wtrue)
@@ -290,6 +449,34 @@ def main():
         sub[f"{cp64.schedule}_schedule_f64"] = r
         cp64.close()
         V64.close()
+
+    if config_records:
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmpdir:
+            for name, fn in (("cfg5_tucker", lambda: cfg5_tucker_record(ppals, ctx, tmpdir)),):
+                try:
+                    sub[name] = fn()
+                except Exception as e:  # reported, never required
+                    sub[name] = {"error": str(e)}
+        # configs[3] on ONE GPU (the 8-GPU curve is the driver's --gpus runs of this script)
+        try:
+            lens4, R4 = WORKLOADS["cp4_s400_r20"]
+            V4 = ppals.Tensor(ctx, lens4, ppals.F32).fill_cp(ppals.init_factors(lens4, R4, 1000))
+            cp4 = ppals.CP(ctx, V4, R4)
+            r = measure(cp4, 5, 2, ppals.init_factors(lens4, R4, 2000),
+                        ppals.init_factors(lens4, R4, 3000))
+            r["config"] = ("BASELINE configs[3] on 1 GPU: CP order-4 s=400 R=20 -tensor r, 102 GB "
+                           "fp32 + the second resident layout")
+            r["dtype"] = "f32"
+            r["sweep_flops"] = sweep_flops(lens4, R4, cp4.schedule)
+            r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
+            if "roofline" in r:
+                r["roofline"]["kernel"] = "k_scan_suffix_fast<float,2,1> (two n-tiles)"
+            sub["cfg4_1gpu"] = r
+            cp4.close()
+            V4.close()
+        except Exception as e:
+            sub["cfg4_1gpu"] = {"error": str(e)}
 
     if rank == 0:
         ms_per_step = head["ms_per_step"]
@@ -320,6 +507,7 @@ def main():
                                 "= the reduce-scatter / all-gather plan") if use_comm else "none"},
             "mttkrp_tflops": flops * sweeps_s / 1e12,
             "sweep_flops": flops,
+            "rccl_ranks": nranks_seen,
             "final_gradnorm": gradnorm,
             "final_rel_residual": resid / vnorm,
         }
@@ -341,7 +529,10 @@ def main():
         if "roofline" in head:
             rl = dict(head["roofline"])
             rl.update({
-                "traffic": traffic, "traffic_source": traffic_src,
+                # `traffic` is null unless PMC counters were read in THIS run (they cannot be, from
+                # inside the process); `traffic_replayed` is the committed figure of the separate
+                # rocprofv3 --pmc passes of this same command
+                "traffic": None, "traffic_replayed": traffic, "traffic_source": traffic_src,
                 "kernel": ("k_scan_suffix_buf" if (R <= 16 or esz == 8) else "k_scan_suffix_fast")
                           + " (tensor scan: one mode contracted per launch under msdt, a mode half "
                             "under dt; _buf = persistent buffer-load form, one n-tile or fp64 storage; "

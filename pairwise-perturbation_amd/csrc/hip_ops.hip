@@ -92,6 +92,11 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_block_orth,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_tail,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   }
@@ -1018,6 +1023,7 @@ class HipOps : public Ops {
     bool valid = false;
     double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, largest eigenvalue
     double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
+    double head = 4.0;    // head room of the spectral-bound scale (projector_step, fused form)
     double *Q = nullptr;                  // previous basis (J x rank)
     double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
     int fast = 0, full = 0;
@@ -1025,8 +1031,15 @@ class HipOps : public Ops {
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
-    hipLaunchKernelGGL(k_dgemm_nt, grid, dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C, ldc, M, N, K,
-                       alpha, beta);
+    hipLaunchKernelGGL(k_dgemm_nx<false>, grid, dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C, ldc, M,
+                       N, K, alpha, beta);
+  }
+  // the same with the second operand as it is (K x N, column-major): thin tails, no transposition
+  void gemm_nn(const double *A, int64_t lda, const double *B, int64_t ldb, const double *D,
+               int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
+    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
+    hipLaunchKernelGGL(k_dgemm_nx<true>, grid, dim3(256), 0, st_, A, lda, B, ldb, D, ldd, C, ldc, M, N,
+                       K, alpha, beta);
   }
   // full solver + what the next call of the slot needs (rank-th and next eigenvalue, the basis)
   void eig_bootstrap(EigState &es, double *G, int64_t J, int rank, double *U) {
@@ -1055,6 +1068,7 @@ class HipOps : public Ops {
     es.rank = rank;
     HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
     es.rho_frob = 0;  // the next projector step reads its norm once
+    es.head = 4.0;
     es.valid = es.lamR > 0 && es.lamR1 >= 0 && es.lamR > es.lamR1 * (1 + 1e-9);
   }
   // Z (J x r) -> orthonormal columns, Cholesky QR twice (status 2 of a pass = "far from
@@ -1175,12 +1189,25 @@ class HipOps : public Ops {
     EigState &es = eig_state_[slot];
     if (es.valid && (es.J != J || es.rank != rank)) es.valid = false;
     if (es.valid && projector_step(es, G, J, rank, U, slot, false)) return;
+    if (es.valid && eig_fused_) {  // the spectral bound may have been outrun: once more on the measured norm
+      eig_frob_once_ = true;
+      const bool ok = projector_step(es, G, J, rank, U, slot, false);
+      eig_frob_once_ = false;
+      if (ok) {
+        es.head = 8.0;
+        return;
+      }
+    }
     // nothing known about this matrix (first call of the slot, a shift that no longer separates
     // the wanted eigenvalues): a few steps of block subspace iteration place the shift, the same
     // projector step — checked against machine precision, not against an estimated gap — delivers
     // the eigenpairs; the full solver remains the fallback of the fallback
-    if (eig_cold_ && cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true))
-      return;
+    if (eig_cold_) {
+      if (cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true)) return;
+      // a flat spectrum around the cut (the Gram of a noise tensor: the HOSVD initialisation), where
+      // Ritz values cannot place the shift: place it by COUNTING eigenvalues with the sign iteration
+      if (eig_fused_ && cold_ok_ && cold_bisect(es, G, J, rank, U, slot)) return;
+    }
     es.valid = false;
     if (eig_debug_)
       fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: full solver (dsyevd)\n", slot, (long long)J, rank);
@@ -1253,6 +1280,20 @@ class HipOps : public Ops {
         ratio = es.evh[d] / es.evh[d - 1];
       }
     double tau = 0;
+    // Fused form of a warm step (PPALS_EIG_FUSED=0: the round-2 launch sequence, kept for A/B and as
+    // the route of block deflation / cold starts): the scale of the iteration comes from what the
+    // slot knows about the spectrum instead of a Frobenius norm measured on the device (G is a Gram
+    // matrix: every eigenvalue of G - sigma I lies in [-sigma, lambda_max - sigma], so
+    // max(sigma, lambda_next - sigma) bounds the spectral radius of the deflated, shifted matrix —
+    // an order of magnitude below its Frobenius norm for a flat bulk of a few hundred eigenvalues,
+    // i.e. 2-3 iterations fewer). Head room (EigState::head): 25 % in steady state, the square of
+    // the growth the slot's leading eigenvalue showed over its last step otherwise, 4 x right after a
+    // cold start (the first HOOI sweeps move the spectrum by factors); beyond it the iteration still
+    // converges up to sqrt(3) x, after which an eigenvalue is folded to the wrong side, the count
+    // comes out short and the step is repeated on the measured Frobenius norm (top_eigvecs_warm).
+    const bool fused_scale = eig_fused_ && !strict && m <= 1 && eig_sigma_scale_ <= 0 && !eig_frob_once_;
+    const double *pow_y = nullptr, *pow_p = nullptr;
+    int pow_n = 0;
     if (m == 1) {
       // one dominant eigenpair (a tensor with a mean component): power steps on one vector. The
       // previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
@@ -1270,8 +1311,12 @@ class HipOps : public Ops {
         src = ybuf[it & 1];
         pin = pbuf[it & 1];
       }
-      hipLaunchKernelGGL(k_power_finish, dim3(1), dim3(256), 0, st_, src, J, pin, nb, QD, lamD);
+      pow_y = src;
+      pow_p = pin;
+      pow_n = nb;
       tau = es.lamR * 1.5 + 1e-300;
+      if (!fused_scale)
+        hipLaunchKernelGGL(k_power_finish, dim3(1), dim3(256), 0, st_, src, J, pin, nb, QD, lamD);
     } else if (m > 0) {
       const int nsteps = std::min(14, std::max(3, (int)std::ceil(std::log(1e-18) / std::log(ratio))));
       HIP_CHECK(hipMemcpyAsync(QD, es.Q, sizeof(double) * J * m, hipMemcpyDeviceToDevice, st_));
@@ -1296,19 +1341,27 @@ class HipOps : public Ops {
     const int gdef = grid_for(nJJ, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * (gdef + 1));
     double *fro2_d = chk + 8;
-    hipLaunchKernelGGL(k_deflate_shift, dim3(gdef), dim3(256), 0, st_, G, J, QD, m, lamD, tau, sigma,
-                       X, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, gdef, fro2_d);
     double rho = es.rho_frob;
-    if (!(rho > 0)) {  // first projector step of the slot: read the norm
-      double fro2 = 0;
-      HIP_CHECK(hipMemcpyAsync(&fro2, fro2_d, sizeof(double), hipMemcpyDeviceToHost, st_));
-      HIP_CHECK(hipStreamSynchronize(st_));
-      rho = 1.0001 * std::sqrt(fro2);
+    if (fused_scale) {
+      const double next = m < rank ? es.evh[m] : 0.0;  // largest eigenvalue that is not deflated
+      rho = es.head * std::max(sigma, next - sigma);
       if (!(rho > 0) || !std::isfinite(rho)) return false;
+      hipLaunchKernelGGL(k_ns_prepare, dim3(gdef), dim3(256), 0, st_, G, J, pow_y, pow_p, pow_n, m, tau,
+                         sigma, 1.0 / rho, X, QD, lamD);
+    } else {
+      hipLaunchKernelGGL(k_deflate_shift, dim3(gdef), dim3(256), 0, st_, G, J, QD, m, lamD, tau, sigma,
+                         X, part);
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, gdef, fro2_d);
+      if (!(rho > 0)) {  // first projector step of the slot: read the norm
+        double fro2 = 0;
+        HIP_CHECK(hipMemcpyAsync(&fro2, fro2_d, sizeof(double), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        rho = 1.0001 * std::sqrt(fro2);
+        if (!(rho > 0) || !std::isfinite(rho)) return false;
+      }
+      hipLaunchKernelGGL(k_scale_by_frob, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, (int64_t)nJJ,
+                         fro2_d);
     }
-    hipLaunchKernelGGL(k_scale_by_frob, dim3(grid_for(nJJ, 256)), dim3(256), 0, st_, X, (int64_t)nJJ,
-                       fro2_d);
     // (strict = cold start: the distance of the shift to the nearest eigenvalue is unknown — the
     // Ritz values around it are rough — so a small lower bound is assumed: a few iterations more)
     double ell0 = 0.9 * 0.5 * std::min(es.lamR - sigma, sigma - es.lamR1) / rho;
@@ -1316,12 +1369,19 @@ class HipOps : public Ops {
     double ell = std::max(ell0, eig_sigma_scale_ > 0 ? 1e-4 : 1e-14);
     int iters = 0;
     const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
-    auto ns_step = [&](double mu) {
+    // fused tail: the check sums ride on the LAST step's two products (per-tile partial sums of
+    // ||X_prev^2 - I||_F^2 and of trace(X_new), added up by the tail's last kernel)
+    const bool fused_tail = eig_fused_ && m <= 1 &&
+                            sizeof(double) * ((size_t)J * (rank + kWide) + 2 * (size_t)(rank + kWide) * (rank + kWide) + 64) <=
+                                (size_t)150 * 1024;
+    double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
+    double *ptr_ = pe2 + ntri;
+    auto ns_step = [&](double mu, bool last = false) {
       // Y = X^2, X <- X (a I + b X^2): symmetric products, stored symmetric bit for bit
       hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
-                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
+                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
       hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, Y, J, X, J, Xn, J, Ji, Ji,
-                         -0.5 * mu * mu * mu, 1.5 * mu);
+                         -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
       std::swap(X, Xn);
       iters++;
     };
@@ -1330,14 +1390,15 @@ class HipOps : public Ops {
       ns_step(mu);
       ell = 0.5 * mu * ell * (3.0 - mu * mu * ell * ell);
     }
-    for (int k = 0; k < 2; k++) ns_step(1.0);
+    ns_step(1.0);
+    ns_step(1.0, fused_tail);
     for (int attempt = 0;; attempt++) {
       // ---- check of the sign iteration: ||X^2 - I||_F^2 and trace(X) (-> chk[0], chk[1])
-      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
-                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
-      {
-        const int gc = grid_for(nJJ, 256, 256);
-        double *pc = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * gc + 2));
+      if (!fused_tail) {
+        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
+                           (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
+        const int gc = 256;
+        double *pc = ptr_ + ntri;
         hipLaunchKernelGGL(k_sign_check, dim3(gc), dim3(256), 0, st_, Y, X, J, pc);
         hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, st_, pc, gc, chk);
       }
@@ -1350,6 +1411,23 @@ class HipOps : public Ops {
       // QR, Rayleigh-Ritz on cols x cols; the leading `rank` eigenvectors land in Uout (ld J), their
       // residual in chk[4], all `cols` eigenvalues in evW; then the one read-back of the step
       auto tail = [&](int cols, const double *Omega, double *Uout, int npass) {
+        if (fused_tail) {
+          // Z = (Omega + X Omega) / 2 | orthonormal basis of [Q_D | rest] in ONE workgroup, the block
+          // in LDS | G B | Rayleigh-Ritz, back-products, residual and the check sums in ONE workgroup
+          gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
+          const size_t lds_o = sizeof(double) * ((size_t)J * cols + 2 * (size_t)cols * cols + 64);
+          hipLaunchKernelGGL(k_block_orth, dim3(1), dim3(1024), lds_o, st_, Z, J, cols, QD, m, npass, Z2,
+                             status);
+          gemm_nn(G, J, Z2, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);
+          const size_t lds_r = sizeof(double) * (2 * (size_t)cols * (cols + 1) + 64 + 17) + sizeof(int) * 128;
+          hipLaunchKernelGGL(k_rr_tail, dim3(1), dim3(1024), lds_r, st_, Z2, GZ, J, cols, rank, pe2, ptr_,
+                             (int)ntri, Uout, evW, chk);
+          if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
+          HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
+          HIP_CHECK(hipStreamSynchronize(st_));
+          HIP_CHECK(hipGetLastError());
+          return;
+        }
         transpose2d(Omega, F64, J, cols, Ot);  // Omega^T (cols x J): coalesced B operand
         gemm_nt(X, J, Ot, cols, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
         if (m > 0) {
@@ -1372,12 +1450,16 @@ class HipOps : public Ops {
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipGetLastError());
       };
-      tail(rank, es.Q, U, 1);
+      // (fused tail: the second Cholesky-QR pass costs ~3 us inside the one-workgroup kernel, so it
+      // always runs and a basis that moved far from the previous one is no reason to reject)
+      tail(rank, es.Q, U, fused_tail ? 2 : 1);
       const double *hc = (const double *)eig_host_, *evn = hc + 16;
       const int *hs = (const int *)(evn + 64);
       const double cnt = 0.5 * (hc[1] + (double)J), res = std::sqrt(hc[4]);
-      const double rho_now = 1.0001 * std::sqrt(hc[8]);
-      const bool converged = hc[0] <= 1e-20 * (double)J;
+      const double rho_now = fused_scale ? rho : 1.0001 * std::sqrt(hc[8]);
+      // (fused tail: hc[0] is ||E||_F^2 of the iterate BEFORE the last step, E = X^2 - I; the step
+      // squares it — E_new = (3 E^2 + E^3) / 4 — so ||E_new||_F <= ||E||_F^2 = hc[0])
+      const bool converged = fused_tail ? hc[0] <= 1e-10 * std::sqrt((double)J) : hc[0] <= 1e-20 * (double)J;
       // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
       // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
       // (from THIS step's quantities only: trace(P) == rank says that exactly `rank` eigenvalues
@@ -1386,7 +1468,8 @@ class HipOps : public Ops {
       const double gap_now = std::max(0.0, evn[rank - 1] - sigma);
       const double res_tol = (strict ? 1e-13 * evn[0] : std::max(1e-9 * gap_now, 1e-14 * evn[0])) *
                              std::sqrt((double)rank);
-      const bool good = converged && std::fabs(cnt - rank) < 1e-6 && hs[0] == 0 && hs[2] != 1 && hs[3] == 0 &&
+      const bool chol_ok = fused_tail ? (hs[0] != 1 && hs[1] == 0) : hs[0] == 0;
+      const bool good = converged && std::fabs(cnt - rank) < 1e-6 && chol_ok && hs[2] != 1 && hs[3] == 0 &&
                         res <= res_tol && std::isfinite(rho_now);
       if (eig_debug_)
         fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
@@ -1396,6 +1479,11 @@ class HipOps : public Ops {
                 res, gap_now, hs[0], hs[1], hs[2], hs[3],
                 good ? "accepted" : (converged ? "not accepted as it is" : "more steps"), es.fast, es.full);
       if (good) {
+        {
+          const int mi = std::min(m, rank - 1);
+          const double growth = es.evh[mi] > 0 ? evn[mi] / es.evh[mi] : 2.0;
+          es.head = std::min(8.0, std::max(1.25, 1.25 * growth * growth));
+        }
         for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
         const double shift = evn[rank - 1] - es.lamR;
         es.lamR = evn[rank - 1];
@@ -1428,6 +1516,7 @@ class HipOps : public Ops {
                   cwide, resw, hs[0], hs[1], goodw ? "accepted" : "full solver");
         if (goodw) {
           HIP_CHECK(hipMemcpyAsync(U, Uw, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
+          es.head = 4.0;  // (the estimates were off by several eigenvalues: the spectrum is moving)
           for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
           es.lamR = evn[rank - 1];
           es.lamR1 = std::max(0.0, evn[rank]);
@@ -1439,12 +1528,13 @@ class HipOps : public Ops {
         break;
       }
       if (converged || attempt >= (strict ? 4 : 2)) break;
-      ns_step(1.0);  // the gap was narrower than estimated: a few more steps, then the tail again
-      ns_step(1.0);
+      // the gap was narrower than estimated: a few more steps, then the tail again
       if (strict) {
         ns_step(1.0);
         ns_step(1.0);
       }
+      ns_step(1.0);
+      ns_step(1.0, fused_tail);
       HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), st_));  // (the Cholesky QR of the tail)
     }
     // sigma does not separate `rank` eigenvalues, a lost direction, no convergence
@@ -1457,6 +1547,7 @@ class HipOps : public Ops {
   // what its wide tail is for. false: the Ritz values do not resolve the neighbourhood of the cut
   // (a flat spectrum) or the block lost rank — the caller goes to the full solver.
   bool cold_ritz_state(EigState &es, double *G, int64_t J, int rank, int slot) {
+    cold_ok_ = false;
     const int b = std::min(64, rank + 16);
     if (b >= J || rank + 4 >= b) return false;
     const int Ji = (int)J;
@@ -1484,8 +1575,13 @@ class HipOps : public Ops {
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipGetLastError());
     const int below = std::min(b - 1, rank + 4);  // index of the estimate placed under the cut
-    const bool ok = hs[0] != 1 && hs[1] == 0 && th[rank - 1] > 0 && th[below] >= 0 &&
-                    th[rank - 1] > th[below] * 1.02;
+    const bool sane = hs[0] != 1 && hs[1] == 0 && th[rank - 1] > 0 && th[below] >= 0;
+    const bool ok = sane && th[rank - 1] > th[below] * 1.02;
+    // (kept for cold_bisect: the Ritz block is a generic basis, its Ritz values are lower bounds)
+    cold_ok_ = sane;
+    cold_b_ = b;
+    cold_Uo_ = Uo;
+    for (int d = 0; d < b; d++) cold_th_[d] = th[d];
     if (eig_debug_)
       fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: cold start, Ritz values %.4e .. %.4e | %.4e "
                       "(index %d) -> %s\n", slot, (long long)J, rank, th[0], th[rank - 1], th[below],
@@ -1503,9 +1599,212 @@ class HipOps : public Ops {
     es.lamR1 = th[below];
     es.rho = th[0];
     es.rho_frob = 0;
+    es.head = 4.0;
     es.valid = true;
     return true;
   }
+
+  // Cold start by eigenvalue counting. trace(sign(G - sigma I)) says how many eigenvalues lie above
+  // sigma — exactly, whatever the spectrum looks like — so the shift is placed by a few trials of
+  // the sign iteration instead of by Ritz values: a bracket [lo, hi] with count(lo) >= rank (the
+  // rank-th Ritz value is a lower bound of the rank-th eigenvalue) and count(hi) < rank, then
+  // interpolation on count^(2/3) (the edge law of a bulk spectrum) until rank <= count <=
+  // rank + kWide. The projector of that trial is exact for an invariant subspace of `count`
+  // dimensions; Rayleigh-Ritz on P applied to the Ritz block delivers its eigenpairs one by one and
+  // the leading `rank` are the answer (the same tail as a warm step's "wide tail"). A trial costs
+  // ~0.25 ms (28 products of J^3), the full solver 9 ms at J = 400. One dominant eigenpair (a mean
+  // component) is refined by power steps and deflated; anything this cannot handle returns false.
+  bool cold_bisect(EigState &es, double *G, int64_t J, int rank, double *U, int slot) {
+    constexpr int kWide = 16;
+    const int Ji = (int)J, b = cold_b_;
+    const size_t nJJ = (size_t)J * J, nJR = (size_t)J * rank, nJW = (size_t)J * (rank + kWide);
+    if (rank + kWide > b || rank + kWide >= Ji) return false;
+    if (sizeof(double) * ((size_t)J * (rank + kWide) + 2 * (size_t)(rank + kWide) * (rank + kWide) + 64) >
+        (size_t)150 * 1024)
+      return false;
+    const double *th = cold_th_;
+    int m = 0;
+    for (int d = 1; d < rank; d++)
+      if (th[d] > 0 && th[d - 1] / th[d] >= 20.0) m = d;
+    if (m > 1) return false;
+    const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
+    double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
+                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 256));
+    double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
+    double *Z = Y + nJJ, *Z2 = Z + nJW, *GZ = Z2 + nJW, *QD = GZ + nJW, *y0 = QD + nJW, *y1 = y0 + nJW,
+           *Uw = y1 + nJW;
+    double *chk = Y + nJJ + 10 * nJW + 3 * 64 * 64, *evW = chk + 16;
+    int *status = (int *)(evW + 64);
+    double *lamD = evW + 64 + 4;
+    constexpr size_t kReadback = sizeof(double) * (16 + 64) + sizeof(int) * 8;
+    double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
+    double *ptr_ = pe2 + ntri;
+    if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
+    // the Ritz block lives in ws_cold_, which nothing below touches
+    const double *Om = cold_Uo_;
+    const double *pow_y = nullptr, *pow_p = nullptr;
+    int pow_n = 0;
+    if (m == 1) {
+      const int nb = (int)((J + 7) / 8);
+      double *pw = (double *)ensure(ws_pow_, ws_pow_sz_, sizeof(double) * 4 * (size_t)nb);
+      double *pbuf[2] = {pw, pw + 2 * (size_t)nb};
+      double *ybuf[2] = {y0, y1};
+      const double *src = Om, *pin = nullptr;
+      for (int it = 0; it < 4; it++) {
+        hipLaunchKernelGGL(k_power_mv, dim3(nb), dim3(256), 0, st_, G, J, src, pin, nb, ybuf[it & 1],
+                           pbuf[it & 1]);
+        src = ybuf[it & 1];
+        pin = pbuf[it & 1];
+      }
+      pow_y = src;
+      pow_p = pin;
+      pow_n = nb;
+    }
+    const double next_ub = 1.5 * th[m];  // generous bound of the largest eigenvalue left in place
+    int trials = 0, products = 0;
+    // one trial: X = sign((G - deflation - sigma I) / rho), returns count and convergence
+    auto trial = [&](double sigma, double *count, bool *conv) {
+      const double rho = 1.25 * std::max(sigma, next_ub - sigma);
+      const int gdef = grid_for(nJJ, 256, 1024);
+      hipLaunchKernelGGL(k_ns_prepare, dim3(gdef), dim3(256), 0, st_, G, J, pow_y, pow_p, pow_n, m,
+                         2.0 * sigma, sigma, 1.0 / rho, X, QD, lamD);
+      auto ns_step = [&](double mu, bool last) {
+        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
+                           (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
+        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, Y, J, X, J, Xn, J, Ji,
+                           Ji, -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
+        std::swap(X, Xn);
+        products += 2;
+      };
+      double ell = 1e-5;  // assumed distance of the shift to the nearest eigenvalue (scaled)
+      int it = 0;
+      while (1.0 - ell > 1e-3 && it++ < 80) {
+        const double mu = std::sqrt(3.0 / (1.0 + ell + ell * ell));
+        ns_step(mu, false);
+        ell = 0.5 * mu * ell * (3.0 - mu * mu * ell * ell);
+      }
+      ns_step(1.0, false);
+      for (int attempt = 0;; attempt++) {
+        ns_step(1.0, true);
+        hipLaunchKernelGGL(k_chk_sums, dim3(1), dim3(256), 0, st_, pe2, ptr_, (int)ntri, chk);
+        HIP_CHECK(hipMemcpyAsync(eig_host_, chk, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        const double *hc = (const double *)eig_host_;
+        *conv = hc[0] <= 1e-10 * std::sqrt((double)J);
+        *count = 0.5 * (hc[1] + (double)J);
+        if (*conv || attempt >= 3) break;
+        ns_step(1.0, false);  // the shift sits closer to an eigenvalue than assumed: more steps
+        ns_step(1.0, false);
+        ns_step(1.0, false);
+      }
+      trials++;
+      if (eig_debug_)
+        fprintf(stderr, "[ppals eig] slot %d   count trial %d: sigma %.8e -> count %.4f (%s)\n", slot,
+                trials, sigma, *count, *conv ? "converged" : "NOT converged");
+    };
+    double lo = th[rank - 1], hi = 1.08 * th[m], c_lo = -1, c_hi = -1;
+    double cnt = 0;
+    bool conv = false;
+    // upper end of the bracket: fewer than `rank` eigenvalues above it
+    for (int k = 0; k < 6; k++) {
+      trial(hi, &cnt, &conv);
+      if (conv && std::lround(cnt) < rank) {
+        c_hi = (double)std::lround(cnt);
+        break;
+      }
+      if (conv && std::lround(cnt) <= rank + kWide) break;  // landed inside the window already
+      if (conv) lo = hi, c_lo = (double)std::lround(cnt);
+      hi *= conv ? 1.08 : 1.0003;
+    }
+    double sigma = hi;
+    auto in_window = [&]() { return conv && std::lround(cnt) >= rank && std::lround(cnt) <= rank + kWide; };
+    if (!in_window()) {
+      if (c_hi < 0) return false;
+      if (c_lo < 0) {  // count at the Ritz lower bound
+        trial(lo, &cnt, &conv);
+        if (!conv) {
+          lo *= 0.9997;
+          trial(lo, &cnt, &conv);
+        }
+        if (!conv) return false;
+        c_lo = (double)std::lround(cnt);
+        sigma = lo;
+      }
+      const double target = rank + kWide / 2;
+      for (int k = 0; k < 12 && !in_window(); k++) {
+        if (c_lo < rank) return false;  // the Ritz value was no lower bound: give up
+        // N(sigma)^(2/3) is close to linear below a spectral edge; plain bisection every third trial
+        const double tl = std::pow(c_lo, 2.0 / 3.0), thh = std::pow(std::max(c_hi, 0.0), 2.0 / 3.0),
+                     tt = std::pow(target, 2.0 / 3.0);
+        double f = (k % 3 == 2) ? 0.5 : (tl - tt) / std::max(tl - thh, 1e-300);
+        f = std::min(0.95, std::max(0.05, f));
+        sigma = lo + f * (hi - lo);
+        trial(sigma, &cnt, &conv);
+        if (!conv) {  // on top of an eigenvalue: nudge
+          sigma = lo + std::min(0.97, f + 0.02) * (hi - lo);
+          trial(sigma, &cnt, &conv);
+          if (!conv) return false;
+        }
+        const long c = std::lround(cnt);
+        if (c > rank + kWide) {
+          lo = sigma;
+          c_lo = (double)c;
+        } else if (c < rank) {
+          hi = sigma;
+          c_hi = (double)c;
+        }
+      }
+      if (!in_window()) return false;
+    }
+    const int cols = (int)std::lround(cnt);
+    if (std::fabs(cnt - cols) > 1e-6) return false;
+    // ---- the tail on `cols` columns: P applied to the Ritz block (a generic basis), two Cholesky-QR
+    // passes, Rayleigh-Ritz; the deflated eigenvector takes the place of the first column
+    HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
+    gemm_nn(X, J, Om, J, Om, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
+    const size_t lds_o = sizeof(double) * ((size_t)J * cols + 2 * (size_t)cols * cols + 64);
+    hipLaunchKernelGGL(k_block_orth, dim3(1), dim3(1024), lds_o, st_, Z, J, cols, QD, m, 2, Z2, status);
+    gemm_nn(G, J, Z2, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);
+    const size_t lds_r = sizeof(double) * (2 * (size_t)cols * (cols + 1) + 64 + 17) + sizeof(int) * 128;
+    hipLaunchKernelGGL(k_rr_tail, dim3(1), dim3(1024), lds_r, st_, Z2, GZ, J, cols, rank, pe2, ptr_,
+                       (int)ntri, Uw, evW, chk);
+    HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipGetLastError());
+    const double *hc = (const double *)eig_host_, *evn = hc + 16;
+    const int *hs = (const int *)(evn + 64);
+    const double res = std::sqrt(hc[4]);
+    const double res_tol = 1e-13 * evn[0] * std::sqrt((double)rank);
+    const bool good = hs[0] != 1 && hs[1] == 0 && res <= res_tol && std::isfinite(res) &&
+                      (cols == rank || evn[rank - 1] > evn[rank] * (1 + 1e-12));
+    if (eig_debug_)
+      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: cold start by counting, %d trials (%d products), "
+                      "sigma %.8e count %d, residual %.3e (tol %.3e) chol %d%d -> %s\n",
+              slot, (long long)J, rank, trials, products, sigma, cols, res, res_tol, hs[0], hs[1],
+              good ? "accepted" : "full solver");
+    if (!good) return false;
+    HIP_CHECK(hipMemcpyAsync(U, Uw, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
+    if (!es.Q || es.J != J || es.rank != rank) {
+      if (es.Q) hipFree(es.Q);
+      HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+    }
+    es.J = J;
+    es.rank = rank;
+    HIP_CHECK(hipMemcpyAsync(es.Q, Uw, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
+    for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
+    es.lamR = evn[rank - 1];
+    es.lamR1 = cols > rank ? std::max(0.0, evn[rank]) : std::min(sigma, es.lamR * (1 - 1e-6));
+    es.rho = evn[0];
+    es.rho_frob = 0;
+    es.head = 4.0;
+    es.valid = es.lamR > es.lamR1 * (1 + 1e-9);
+    es.fast++;
+    return true;
+  }
+  bool cold_ok_ = false;
+  int cold_b_ = 0;
+  const double *cold_Uo_ = nullptr;
+  double cold_th_[64] = {0};
   double frob_shifted(const double *G, int64_t J, double sigma) {
     const int g = grid_for(J * J, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * (g + 1));
@@ -1605,6 +1904,8 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  bool eig_frob_once_ = false;
+  int eig_fused_ = 1;  // PPALS_EIG_FUSED=0: the multi-launch tail and the Frobenius scale (A/B, tests)
   int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
   void *ws_cold_ = nullptr;
   size_t ws_cold_sz_ = 0;

@@ -28,7 +28,11 @@ namespace ppals {
 // L2-resident and a launch is pure latency, so ONE 16 x 16 output tile is spread over a whole
 // workgroup — its 4 waves split K, each keeps UN steps (2*UN loads per lane) in flight, and the
 // four partial tiles meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, int64_t lda,
+// BN = true: the second operand is handed over as B itself (K x N, column-major, ldb) — for the
+// thin operands of the eigen-step's tail (a few dozen columns, L2-resident) this saves the
+// transposition launch; the lanes of a column group then read 16 different lines instead of one.
+template <bool BN>
+__global__ __launch_bounds__(256) void k_dgemm_nx(const double *__restrict__ A, int64_t lda,
                                                   const double *__restrict__ Bt, int64_t ldb,
                                                   const double *__restrict__ D, int64_t ldd,
                                                   double *__restrict__ C, int64_t ldc, int M, int N,
@@ -41,7 +45,8 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, 
   // clamped operand rows: lanes past the edge re-read the last row, their results are not stored
   const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, N - 1);
   const double *__restrict__ ap = A + ia;
-  const double *__restrict__ bp = Bt + jb;
+  const double *__restrict__ bp = BN ? Bt + (int64_t)ldb * jb : Bt + jb;
+  const int64_t bstep = BN ? 1 : ldb;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   const int ksteps = (K + 3) / 4;
   const int spw = (ksteps + 3) / 4;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double *__restrict__ A, 
       const int k = (s0 + u) * 4 + g;
       const bool ok = (s0 + u) < s_end && k < K;  // beyond the range: multiply by zero
       const int kc = ok ? k : 0;
-      const double a = ap[(int64_t)lda * kc], b = bp[(int64_t)ldb * kc];
+      const double a = ap[(int64_t)lda * kc], b = bp[bstep * kc];
       av[u] = ok ? a : 0.0;
       bv[u] = ok ? b : 0.0;
     }
@@ -92,7 +97,12 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
                                                       const double *__restrict__ Bt, int64_t ldb,
                                                       const double *__restrict__ D, int64_t ldd,
                                                       double *__restrict__ C, int64_t ldc, int M,
-                                                      int K, double alpha, double beta) {
+                                                      int K, double alpha, double beta,
+                                                      int chk_mode = 0,
+                                                      double *__restrict__ chk_part = nullptr) {
+  // chk_mode 1: chk_part[blockIdx.x] = this tile's share of ||C - I||_F^2 (off-diagonal tiles count
+  // twice: both triangles); 2: its share of trace(C). The convergence check of the sign iteration
+  // rides on the products it has to do anyway — no extra product, no reduction launch.
   constexpr int UN = 13;
   __shared__ double part[NW - 1][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
   __syncthreads();
   if (wave > 0) return;
   const int j = j0 + l16;
+  double chk = 0.0;
   if (j < M) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -146,8 +157,18 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
         if (D) v += beta * D[i + ldd * (int64_t)j];
         C[i + ldc * (int64_t)j] = v;
         if (i != j) C[j + ldc * (int64_t)i] = v;
+        if (chk_mode == 1) {
+          const double d = v - (i == j ? 1.0 : 0.0);
+          chk += (i == j ? 1.0 : 2.0) * d * d;
+        } else if (chk_mode == 2 && i == j) {
+          chk += v;
+        }
       }
     }
+  }
+  if (chk_mode) {  // (wave 0 only is left: a wave-level sum in a fixed order)
+    chk = wave_sum(chk);
+    if (lane == 0) chk_part[blockIdx.x] = chk;
   }
 }
 
@@ -223,6 +244,45 @@ __global__ void k_shift_scale(const double *__restrict__ G, int64_t J, double si
 // X = G - sum_{d < m} (lam[d] - tau) q_d q_d^T - sigma I   (deflation of the dominant eigenpairs:
 // their eigenvalues are moved down to tau, everything else is untouched), partial[blk] = the
 // block's share of ||X||_F^2. Q: J x m column-major.
+// The same with the scale of the sign iteration applied at once, X = (G - deflation - sigma I) *
+// inv_rho, and the dominant eigenpair taken straight from the power iteration's last product:
+// q = y / ||y||, lambda = the Rayleigh quotient left in the partial sums `pp` (np pairs: ||y||^2
+// share, q_in^T y share). Workgroup 0 also writes q (J) and lambda for the tail. m is 0 or 1.
+__global__ __launch_bounds__(256) void k_ns_prepare(const double *__restrict__ G, int64_t J,
+                                                    const double *__restrict__ y,
+                                                    const double *__restrict__ pp, int np, int m,
+                                                    double tau, double sigma, double inv_rho,
+                                                    double *__restrict__ X,
+                                                    double *__restrict__ q_out,
+                                                    double *__restrict__ lam_out) {
+  __shared__ double lds[17];
+  double inv = 0, lam = 0;
+  if (m > 0) {
+    double n2 = 0, rq = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+      n2 += pp[2 * i];
+      rq += pp[2 * i + 1];
+    }
+    n2 = block_sum(n2, lds);
+    rq = block_sum(rq, lds);
+    inv = 1.0 / sqrt(n2);
+    lam = rq;
+    if (blockIdx.x == 0) {
+      for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = y[i] * inv;
+      if (threadIdx.x == 0) *lam_out = lam;
+    }
+  }
+  const double w = (lam - tau) * inv * inv;
+  const int64_t total = J * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % J, j = e / J;
+    double v = G[e] - (i == j ? sigma : 0.0);
+    if (m > 0) v -= w * y[i] * y[j];
+    X[e] = v * inv_rho;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_deflate_shift(const double *__restrict__ G, int64_t J,
                                                        const double *__restrict__ Q, int m,
                                                        const double *__restrict__ lam, double tau,
@@ -524,6 +584,229 @@ __global__ void k_half_sum(const double *__restrict__ a, const double *__restric
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (int64_t)gridDim.x * blockDim.x)
     out[e] = 0.5 * (a[e] + b[e]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tail of a projector step in TWO single-workgroup launches (was ~17: projections, Gram,
+// Cholesky, triangular product, transposition, H = B^T G B, Jacobi, two back-products, residual,
+// reductions of the check sums). Everything here is a few hundred rows by a few dozen columns.
+//
+// k_block_orth: Z (J x cols, global) -> B (J x cols, global) with orthonormal columns spanning the
+// same space: [optional] the m leading columns are REPLACED by QD (J x m, orthonormal: the deflated
+// eigenvectors from the power iteration) and the others are cleared of them (twice); then Cholesky
+// QR, `npass` passes (2 unless Z is known to be nearly orthonormal). Z lives in LDS as it goes
+// (J * cols * 8 bytes of dynamic LDS + 2 cols^2 + 64). status[0..npass): as k_chol_rinv.
+__global__ __launch_bounds__(1024) void k_block_orth(const double *__restrict__ Z, int64_t J, int cols,
+                                                     const double *__restrict__ QD, int m, int npass,
+                                                     double *__restrict__ B, int *__restrict__ status) {
+  extern __shared__ double lds[];
+  double *Zs = lds;                           // J x cols, column-major
+  double *Cm = Zs + (size_t)J * cols;         // cols x cols
+  double *Ri = Cm + cols * cols;              // cols x cols
+  double *red = Ri + cols * cols;             // 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int Ji = (int)J;
+  for (int e = tid; e < Ji * cols; e += blockDim.x) {
+    const int c = e / Ji;
+    Zs[e] = (c < m) ? QD[e] : Z[e];
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 2 && m > 0; pass++) {
+    // t[d][c] = q_d^T z_c, then z_c -= sum_d q_d t[d][c]   (c >= m)
+    for (int e = wave; e < m * (cols - m); e += nw) {
+      const int d = e % m, c = m + e / m;
+      double s = 0;
+      for (int i = lane; i < Ji; i += 64) s += Zs[i + Ji * d] * Zs[i + Ji * c];
+      s = wave_sum(s);
+      if (lane == 0) Cm[d + m * (c - m)] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < Ji * (cols - m); e += blockDim.x) {
+      const int i = e % Ji, c = m + e / Ji;
+      double a = 0;
+      for (int d = 0; d < m; d++) a += Zs[i + Ji * d] * Cm[d + m * (c - m)];
+      Zs[i + Ji * c] -= a;
+    }
+    __syncthreads();
+  }
+  for (int pass = 0; pass < npass; pass++) {
+    // C = Z^T Z (upper triangle computed, mirrored)
+    const int ntri = cols * (cols + 1) / 2;
+    for (int e = wave; e < ntri; e += nw) {
+      int p = 0, rem = e;
+      while (rem >= cols - p) {
+        rem -= cols - p;
+        p++;
+      }
+      const int q = p + rem;
+      double s = 0;
+      for (int i = lane; i < Ji; i += 64) s += Zs[i + Ji * p] * Zs[i + Ji * q];
+      s = wave_sum(s);
+      if (lane == 0) {
+        Cm[p + cols * q] = s;
+        Cm[q + cols * p] = s;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {  // Cholesky C = L L^T in place (lower), Ri = L^{-T}: one wave, as k_chol_rinv
+      const int r = cols;
+      double *L = Cm, *X = Ri;
+      for (int e = lane; e < r * r; e += 64) X[e] = 0.0;
+      wave_sync();
+      double dmax = 0;
+      for (int k = 0; k < r; k++) dmax = fmax(dmax, L[k + r * k]);
+      bool bad = false;
+      double pmin = dmax;
+      for (int k = 0; k < r; k++) {
+        const double d = L[k + r * k];
+        if (!(d > 1e-14 * dmax)) {
+          bad = true;
+          break;
+        }
+        pmin = fmin(pmin, d);
+        const double sk = sqrt(d);
+        wave_sync();
+        for (int i = k + lane; i < r; i += 64) L[i + r * k] = (i == k) ? sk : L[i + r * k] / sk;
+        wave_sync();
+        for (int e = lane; e < (r - k - 1) * (r - k - 1); e += 64) {
+          const int i = k + 1 + e % (r - k - 1), j = k + 1 + e / (r - k - 1);
+          if (i >= j) L[i + r * j] -= L[i + r * k] * L[j + r * k];
+        }
+        wave_sync();
+      }
+      if (lane == 0) status[pass] = bad ? 1 : (dmax > 4.0 * pmin ? 2 : 0);
+      if (lane == 0) red[0] = bad ? 1.0 : 0.0;
+      if (!bad) {
+        for (int c = lane; c < r; c += 64) {  // X = L^{-1}, one column per lane
+          for (int i = c; i < r; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; k++) s -= L[i + r * k] * X[k + r * c];
+            X[i + r * c] = s / L[i + r * i];
+          }
+        }
+      }
+      wave_sync();
+    }
+    __syncthreads();
+    if (red[0] != 0.0) break;  // rank deficient: the caller falls back (status says so)
+    // Z <- Z * L^{-T}: column q of the result = sum_{p <= q} z_p * Linv[q][p] needs the OLD columns
+    // p <= q only, so the columns are replaced from the last one down, every thread its own rows
+    for (int i = tid; i < Ji; i += blockDim.x) {
+      for (int q = cols - 1; q >= 0; q--) {
+        double a = 0;
+        for (int p = 0; p <= q; p++) a += Zs[i + Ji * p] * Ri[q + cols * p];
+        Zs[i + Ji * q] = a;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < Ji * cols; e += blockDim.x) B[e] = Zs[e];
+}
+
+// out[0] = sum a[0..n), out[1] = sum b[0..n)  (the check sums of a counting trial)
+__global__ __launch_bounds__(256) void k_chk_sums(const double *__restrict__ a,
+                                                  const double *__restrict__ b, int n,
+                                                  double *__restrict__ out) {
+  __shared__ double lds[17];
+  double x = 0, y = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    x += a[i];
+    y += b[i];
+  }
+  x = block_sum(x, lds);
+  y = block_sum(y, lds);
+  if (threadIdx.x == 0) {
+    out[0] = x;
+    out[1] = y;
+  }
+}
+
+// k_rr_tail: Rayleigh-Ritz of G on the orthonormal basis B (J x cols) given GB = G B: H = B^T GB
+// (cols x cols), its eigen-decomposition by the in-LDS Jacobi, eigenvalues sorted descending ->
+// evW[0..cols), U = B Y[:, :rank] and the residual ||G U - U diag(ev)||_F^2 of the leading `rank`
+// pairs -> chk[4]; on the way the partial check sums the sign iteration's last two products left
+// (np each) are added up: chk[0] = ||X_prev^2 - I||_F^2, chk[1] = trace(X).
+// dynamic LDS: A[cols][cols+1] | Q[cols][cols+1] | cs[64] | pq[64 ints] | red[17] | ord[64 ints]
+__global__ __launch_bounds__(1024) void k_rr_tail(const double *__restrict__ Bm,
+                                                  const double *__restrict__ GB, int64_t J, int cols,
+                                                  int rank, const double *__restrict__ part_e2,
+                                                  const double *__restrict__ part_tr, int np,
+                                                  double *__restrict__ U, double *__restrict__ evW,
+                                                  double *__restrict__ chk) {
+  extern __shared__ double lds[];
+  const int ldA = cols + 1;
+  double *A = lds;
+  double *Q = A + cols * ldA;
+  double *cs = Q + cols * ldA;
+  int *pq = (int *)(cs + 64);
+  double *red = (double *)(pq + 64);
+  int *ord = (int *)(red + 17);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int Ji = (int)J;
+  // H = B^T (G B), symmetrised from its upper triangle
+  const int ntri = cols * (cols + 1) / 2;
+  for (int e = wave; e < ntri; e += nw) {
+    int p = 0, rem = e;
+    while (rem >= cols - p) {
+      rem -= cols - p;
+      p++;
+    }
+    const int q = p + rem;
+    const double *a = Bm + J * p, *b = GB + J * q;
+    double s = 0;
+    for (int i = lane; i < Ji; i += 64) s += a[i] * b[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+      A[p * ldA + q] = s;
+      A[q * ldA + p] = s;
+    }
+  }
+  __syncthreads();
+  if (cols <= 32) {  // one wave: wave-level barriers only (rounds of <= 16 rotations x 32 rows)
+    if (wave == 0) jacobi_eig_t<64>(A, Q, cs, pq, cols, nullptr);
+    __syncthreads();
+  } else {
+    jacobi_eig_t<1024>(A, Q, cs, pq, cols, red);
+  }
+  if (tid < cols) {
+    const double wk = A[tid * ldA + tid];
+    int pos = 0;
+    for (int j = 0; j < cols; j++) {
+      const double wj = A[j * ldA + j];
+      if (wj > wk || (wj == wk && j < tid)) pos++;
+    }
+    ord[pos] = tid;
+    evW[pos] = wk;
+  }
+  __syncthreads();
+  // U = B Y, residual of the leading pairs: r_i,k = (GB Y)_ik - U_ik * ev_k
+  double res = 0;
+  for (int e = tid; e < Ji * rank; e += blockDim.x) {
+    const int i = e % Ji, k = e / Ji;
+    const int col = ord[k];
+    double u = 0, gu = 0;
+    for (int p = 0; p < cols; p++) {
+      const double y = Q[p * ldA + col];
+      u += Bm[i + J * p] * y;
+      gu += GB[i + J * p] * y;
+    }
+    U[e] = u;
+    const double d = gu - u * A[col * ldA + col];
+    res += d * d;
+  }
+  res = block_sum(res, red);
+  double e2 = 0, tr = 0;
+  for (int i = tid; i < np; i += blockDim.x) {
+    e2 += part_e2[i];
+    tr += part_tr[i];
+  }
+  e2 = block_sum(e2, red);
+  tr = block_sum(tr, red);
+  if (tid == 0) {
+    chk[0] = e2;
+    chk[1] = tr;
+    chk[4] = res;
+  }
 }
 
 }  // namespace ppals

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <set>
 #include <string>
 
 #include "../../include/ppals.h"
@@ -21,6 +22,13 @@ struct ppals_ctx {
   Comm *comm = nullptr;
   SelfComm self;
   Comm &c() { return comm ? *comm : self; }
+  // Live children. A caller should destroy sessions, then tensors, then the context; a garbage-
+  // collected binding (or an exception on the way out) may not. ppals_ctx_destroy therefore tears
+  // down whatever is still alive itself and leaves the orphaned handles DEAD (eng / data null):
+  // destroying them later is a no-op, using them an error — never a use-after-free of the device.
+  std::set<ppals_cp *> cps;
+  std::set<ppals_tucker *> tks;
+  std::set<ppals_tensor *> tensors;
 };
 struct ppals_tensor {
   ppals_ctx *ctx;
@@ -76,6 +84,24 @@ int ppals_ctx_create(ppals_ctx **out, int device) {
 }
 void ppals_ctx_destroy(ppals_ctx *ctx) {
   if (!ctx) return;
+  for (ppals_cp *s : ctx->cps) {
+    delete s->eng;
+    s->eng = nullptr;
+    s->ctx = nullptr;
+  }
+  for (ppals_tucker *s : ctx->tks) {
+    delete s->eng;
+    s->eng = nullptr;
+    s->ctx = nullptr;
+  }
+  for (ppals_tensor *t : ctx->tensors) {
+    try {
+      ctx->ops->free(t->d.data);
+    } catch (...) {
+    }
+    t->d.data = nullptr;
+    t->ctx = nullptr;
+  }
   delete ctx->comm;
   delete ctx->ops;
   delete ctx;
@@ -144,26 +170,30 @@ int ppals_tensor_create(ppals_ctx *ctx, int order, const int64_t *global_lens, i
     return PPALS_ERR_ARG;
   }
   t->d.generation = &t->generation;
+  ctx->tensors.insert(t.get());
   *out = t.release();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 void ppals_tensor_destroy(ppals_tensor *t) {
   if (!t) return;
-  try {
-    t->ctx->ops->free(t->d.data);
-  } catch (...) {
+  if (t->ctx) {
+    try {
+      t->ctx->ops->free(t->d.data);
+    } catch (...) {
+    }
+    t->ctx->tensors.erase(t);
   }
   delete t;
 }
 int ppals_tensor_local_rows(const ppals_tensor *t, int64_t *lo, int64_t *n) {
-  if (!t) return fail(PPALS_ERR_ARG, "NULL tensor");
+  if (!t || !t->ctx) return fail(PPALS_ERR_ARG, "NULL tensor");
   if (lo) *lo = t->d.row0;
   if (n) *n = t->d.llens[0];
   return PPALS_OK;
 }
 int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat) {
-  if (!t || !Wtrue_flat || R <= 0) return fail(PPALS_ERR_ARG, "bad argument");
+  if (!t || !t->ctx || !Wtrue_flat || R <= 0) return fail(PPALS_ERR_ARG, "bad argument");
   API_BEGIN
   t->generation++;
   tensor_fill_cp(*t->ctx->ops, t->d, R, Wtrue_flat);
@@ -171,7 +201,7 @@ int ppals_tensor_fill_cp(ppals_tensor *t, int R, const double *Wtrue_flat) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double hi) {
-  if (!t) return fail(PPALS_ERR_ARG, "NULL tensor");
+  if (!t || !t->ctx) return fail(PPALS_ERR_ARG, "NULL tensor");
   API_BEGIN
   t->generation++;
   tensor_fill_uniform(*t->ctx->ops, t->d, seed, lo, hi);
@@ -179,7 +209,7 @@ int ppals_tensor_fill_uniform(ppals_tensor *t, uint64_t seed, double lo, double 
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s) {
-  if (!t || ndigits < 2 || ndigits % 2 || s < 1) return fail(PPALS_ERR_ARG, "bad argument");
+  if (!t || !t->ctx || ndigits < 2 || ndigits % 2 || s < 1) return fail(PPALS_ERR_ARG, "bad argument");
   API_BEGIN
   double total = 1, want = 1;
   for (int i = 0; i < t->d.order; i++) total *= (double)t->d.glens[i];
@@ -192,7 +222,7 @@ int ppals_tensor_fill_laplacian(ppals_tensor *t, int ndigits, int s) {
 }
 int ppals_tensor_fill_collinear(ppals_tensor *t, int R, double col_min, double col_max,
                                 double ratio_noise, uint64_t seed) {
-  if (!t || R <= 0) return fail(PPALS_ERR_ARG, "bad argument (rank must be positive)");
+  if (!t || !t->ctx || R <= 0) return fail(PPALS_ERR_ARG, "bad argument (rank must be positive)");
   API_BEGIN
   t->generation++;
   tensor_fill_collinear(*t->ctx->ops, t->ctx->c(), t->d, R, col_min, col_max, ratio_noise, seed);
@@ -208,7 +238,7 @@ int ppals_collinear_factors(int order, const int64_t *lens, int R, double col_mi
   API_END(PPALS_ERR_ARG)
 }
 int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
-  if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!t || !t->ctx || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   t->generation++;
   tensor_upload(*t->ctx->ops, t->d, host_full);
@@ -216,14 +246,14 @@ int ppals_tensor_upload(ppals_tensor *t, const double *host_full) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tensor_download(ppals_tensor *t, double *host_full) {
-  if (!t || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!t || !t->ctx || !host_full) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   tensor_download(*t->ctx->ops, t->d, host_full);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tensor_norm(ppals_tensor *t, double *out) {
-  if (!t || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!t || !t->ctx || !out) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   *out = tensor_norm(*t->ctx->ops, t->ctx->c(), t->d);
   return PPALS_OK;
@@ -253,6 +283,7 @@ int ppals_cp_create(ppals_ctx *ctx, ppals_tensor *V, int R, ppals_cp **out) {
   std::unique_ptr<ppals_cp> s(new ppals_cp);
   s->ctx = ctx;
   s->eng = new CpEngine(*ctx->ops, ctx->c(), V->d, R);
+  ctx->cps.insert(s.get());
   *out = s.release();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -260,24 +291,25 @@ int ppals_cp_create(ppals_ctx *ctx, ppals_tensor *V, int R, ppals_cp **out) {
 void ppals_cp_destroy(ppals_cp *s) {
   if (!s) return;
   delete s->eng;
+  if (s->ctx) s->ctx->cps.erase(s);
   delete s;
 }
 int ppals_cp_set_factors(ppals_cp *s, const double *Wflat, const double *gradWflat) {
-  if (!s || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->set_factors(Wflat, gradWflat);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->get_factors(Wflat, gradWflat);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_set_schedule(ppals_cp *s, int schedule) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL session");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL session");
   if (schedule != PPALS_SCHEDULE_DT && schedule != PPALS_SCHEDULE_MSDT)
     return fail(PPALS_ERR_ARG, "schedule must be PPALS_SCHEDULE_DT or PPALS_SCHEDULE_MSDT");
   API_BEGIN
@@ -287,28 +319,28 @@ int ppals_cp_set_schedule(ppals_cp *s, int schedule) {
 }
 int ppals_cp_get_schedule(const ppals_cp *s) { return s ? s->eng->schedule() : PPALS_ERR_ARG; }
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   for (int i = 0; i < n; i++) s->eng->sweep_dt(lambda);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_gradnorm(ppals_cp *s, double *out) {
-  if (!s || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !out) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   *out = s->eng->gradnorm();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_residual(ppals_cp *s, double *out) {
-  if (!s || !out) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !out) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   *out = s->eng->residual();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tree_node(ppals_cp *s, const char *key, double *out, int64_t *n) {
-  if (!s || !key) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !key) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   int64_t c = s->eng->tree_node(key, out);
   if (c < 0) return fail(PPALS_ERR_ARG, "ppals_tree_node: not a node of the dimension tree");
@@ -317,7 +349,7 @@ int ppals_tree_node(ppals_cp *s, const char *key, double *out, int64_t *n) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_mttkrp(ppals_cp *s, int mode, double *M) {
-  if (!s || !M) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !M) return fail(PPALS_ERR_ARG, "NULL argument");
   if (mode < 0 || mode >= s->eng->order()) return fail(PPALS_ERR_ARG, "mode out of range");
   API_BEGIN
   s->eng->mttkrp(mode, M);
@@ -325,7 +357,7 @@ int ppals_mttkrp(ppals_cp *s, int mode, double *M) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_pp_operator(ppals_cp *s, const char *contracted, double *out, int64_t *n) {
-  if (!s || !contracted) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !contracted) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   int64_t c = s->eng->pp_operator(contracted, out);
   if (c < 0) return fail(PPALS_ERR_ARG, "ppals_pp_operator: bad mode string");
@@ -334,7 +366,7 @@ int ppals_pp_operator(ppals_cp *s, const char *contracted, double *out, int64_t 
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_gram_system(ppals_cp *s, int mode, double lambda, double *S, double *Sinv) {
-  if (!s || !S || !Sinv) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !S || !Sinv) return fail(PPALS_ERR_ARG, "NULL argument");
   if (mode < 0 || mode >= s->eng->order()) return fail(PPALS_ERR_ARG, "mode out of range");
   API_BEGIN
   s->eng->gram_system(mode, lambda, S, Sinv);
@@ -359,26 +391,26 @@ static CpOpts to_opts(const ppals_cp_opts *o) {
   return c;
 }
 int ppals_cp_dt(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_dt(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_pp(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_pp(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
 
 int ppals_cp_pp_partupdate(ppals_cp *s, const ppals_cp_opts *o, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_pp_partupdate(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sweeps, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   if (optimizer < PPALS_OPT_SIMPLE || optimizer > PPALS_OPT_MSDT)
     return fail(PPALS_ERR_ARG, "optimizer must be PPALS_OPT_SIMPLE, PPALS_OPT_DT or PPALS_OPT_MSDT");
   API_BEGIN
@@ -393,6 +425,7 @@ int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals
   std::unique_ptr<ppals_tucker> s(new ppals_tucker);
   s->ctx = ctx;
   s->eng = new TuckerEngine(*ctx->ops, ctx->c(), V->d, ranks);
+  ctx->tks.insert(s.get());
   *out = s.release();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
@@ -400,38 +433,39 @@ int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals
 void ppals_tucker_destroy(ppals_tucker *s) {
   if (!s) return;
   delete s->eng;
+  if (s->ctx) s->ctx->tks.erase(s);
   delete s;
 }
 int ppals_tucker_set_factors(ppals_tucker *s, const double *Wflat) {
-  if (!s || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !Wflat) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->set_factors(Wflat);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_set_core(ppals_tucker *s, const double *core) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->set_core(core);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_get_factors(ppals_tucker *s, double *Wflat, double *core) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->get_factors(Wflat, core);
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_hosvd(ppals_tucker *s) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   s->eng->hosvd();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_ttmc(ppals_tucker *s, int skip, double *Y, int64_t *n) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   int64_t c = s->eng->ttmc(skip, Y);
   if (n) *n = c;
@@ -439,21 +473,21 @@ int ppals_tucker_ttmc(ppals_tucker *s, int skip, double *Y, int64_t *n) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_sweeps_dt(ppals_tucker *s, int n) {
-  if (!s) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   for (int i = 0; i < n; i++) s->eng->sweep_dt();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
 int ppals_tucker_dt(ppals_tucker *s, const ppals_cp_opts *o, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_dt(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)
 }
 
 int ppals_tucker_pp(ppals_tucker *s, const ppals_cp_opts *o, int *iters) {
-  if (!s || !o) return fail(PPALS_ERR_ARG, "NULL argument");
+  if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   return s->eng->run_pp(to_opts(o), iters);
   API_END(PPALS_ERR_HIP)

@@ -55,6 +55,13 @@ def main():
     def relerr(a, b):
         return np.linalg.norm(a - b) / np.linalg.norm(b)
 
+    if os.environ.get("PPALS_RANK_MODE") == "rs_plan":
+        rs_plan_cases(pp, ctx, rank, world, calls, relerr)
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"rank {rank}: OK", calls)
+        return
+
     cases = [([10, 7, 6, 5], 3, 1), ([9, 8, 7, 6], 4, 0), ([11, 6, 5], 2, 1),
              ([8, 4, 5, 4, 3, 3], 2, 1)]
     # the degenerate partition (row blocks of ceil(s0/P) leave the last rank empty) is refused on
@@ -217,6 +224,55 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: OK", calls)
+
+
+def rs_plan_cases(pp, ctx, rank, world, calls, relerr):
+    """the plan north_star names — reduce-scatter of the s x R partial MTTKRP rows, row-block solve,
+    all-gather of the new rows — for EVERY mode of cfg-shaped problems (cubic, s divisible by the
+    world size: BASELINE configs[3] has s = 400 on 8 GPUs), at any world size up to 8; both sweep
+    schedules, the PP driver, and the collective counts a sweep must issue."""
+    os.environ["PPALS_COMM_SMALL_BYTES"] = "0"   # no message is "small": never the all-reduce plan
+    for lens, R, dtype in [([2 * world] * 4, 3, 1), ([world, 2 * world, world + 3], 2, 1),
+                           ([2 * world] * 4, 4, 0)]:
+        N = len(lens)
+        Wt = O.init_factors(lens, R, 1234)
+        V = O.build_V(Wt)
+        W = O.init_factors(lens, R, 4321)
+        G = O.init_factors(lens, R, 99)
+        t = pp.Tensor(ctx, lens, dtype).upload(V)
+        lo, n = t.local_rows()
+        assert n == lens[0] // world and lo == rank * n     # equal shards
+        K = 3
+        _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+        for schedule in ("msdt", "dt"):
+            s = pp.CP(ctx, t, R)
+            s.set_schedule(schedule)
+            s.set_factors(W, G)
+            before = dict(calls)
+            s.sweeps_dt(K)
+            # per sweep: a reduce-scatter for every mode but the partitioned one (its rows are
+            # complete on their owner) and an all-gather for every mode
+            assert calls["rs"] - before["rs"] == K * (N - 1), (calls, before)
+            assert calls["ag"] - before["ag"] == K * N, (calls, before)
+            W_got, G_got = s.get_factors(with_grad=True)
+            for a, b in zip(W_got, W_ref):
+                assert relerr(a, b) < (1e-8 if dtype == 1 else 1e-5), (schedule, relerr(a, b))
+            for a, b in zip(G_got, G_ref):
+                assert np.linalg.norm(a - b) < (1e-7 if dtype == 1 else 1e-3) * (1 + np.linalg.norm(b))
+            s.close()
+        if dtype == 1:
+            Vn = np.linalg.norm(V)
+            kw = dict(tol=1e-6 * Vn, tol_init=0.1, maxiter=20, resprint=1000)
+            _, it_ref, W_pp_ref, _ = O.als_cp_pp(V, W, G, **kw)
+            s = pp.CP(ctx, t, R)
+            s.set_factors(W, G)
+            _, it = s.run_pp(**kw)
+            assert it == it_ref
+            for a, b in zip(s.get_factors(), W_pp_ref):
+                assert relerr(a, b) < 1e-6, relerr(a, b)
+            s.close()
+        t.close()
+    assert calls["rs"] > 0 and calls["ag"] > 0
 
 
 if __name__ == "__main__":

@@ -56,3 +56,27 @@ test_tensor_c_collinear = G.test_tensor_c_collinear
 test_tall_unfolding_thin_route_matches_oracle = GT.test_tall_unfolding_thin_route_matches_oracle
 test_tall_unfolding_rank_deficient_falls_back = GT.test_tall_unfolding_rank_deficient_falls_back
 test_chain_order_of_the_first_level_products = GT.test_chain_order_of_the_first_level_products
+
+
+def test_context_destroyed_before_its_children(pp):
+    """a garbage-collected binding (or an exception on the way out) may destroy the context while
+    sessions / tensors are still alive: ppals_ctx_destroy tears them down itself and leaves DEAD
+    handles — destroying them later is a no-op, using them an error, never a use-after-free"""
+    import ctypes as C
+    c = pp.Context(0)
+    t = pp.Tensor(c, [6, 5, 4], 1).fill_uniform(3)
+    s = pp.CP(c, t, 2)
+    k = pp.Tucker(c, t, [2, 2, 2])
+    s.set_factors(pp.init_factors([6, 5, 4], 2, 1))
+    s.sweeps_dt(1)
+    pp.lib().ppals_ctx_destroy(c._h)   # behind the binding's back: children still alive
+    c._h = C.c_void_p()
+    with pytest.raises(pp.PpalsError):
+        s.sweeps_dt(1)
+    with pytest.raises(pp.PpalsError):
+        k.hosvd()
+    with pytest.raises(pp.PpalsError):
+        t.norm()
+    k.close()
+    s.close()
+    t.close()

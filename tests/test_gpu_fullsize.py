@@ -352,7 +352,8 @@ def test_cfg5_tucker_full_size_r2(pp, cfg5_r2, dtype, env, tmp_path, monkeypatch
         # projector step), all the others warm projector steps; none may end in the full solver
         acc = [ln for ln in lines if "-> accepted" in ln]
         assert len(acc) >= 18, "\n".join(lines[-40:])
-        assert sum("cold start" in ln and "projector step" in ln for ln in lines) == 3, "\n".join(lines)
+        ncold = sum("cold start" in ln and "projector step" in ln for ln in lines)
+        assert 3 <= ncold <= 6, "\n".join(lines)   # (a second one while the first sweeps move the spectrum)
         assert not any("full solver" in ln for ln in lines), "\n".join(lines)
     elif env.get("PPALS_EIG_FAST") == "0":
         assert not lines, lines[:3]

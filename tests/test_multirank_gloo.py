@@ -47,3 +47,34 @@ def test_sharded_engine_matches_oracle(world, padded):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
         assert "OK" in out
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_reduce_scatter_plan_every_mode(world):
+    """the reduce-scatter / all-gather plan forced for every mode (PPALS_COMM_SMALL_BYTES=0) on
+    cfg-shaped problems — equal shards, s divisible by the world size — at world 8 (what the
+    driver's 8-GPU run of configs[3] uses when the messages are not small), see
+    hostsim_rank.rs_plan_cases"""
+    import hostsim_util
+    hostsim_util.load()
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", PPALS_ORACLE_THREADS="1",
+                   PPALS_RANK_MODE="rs_plan")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "hostsim_rank.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert "OK" in out
