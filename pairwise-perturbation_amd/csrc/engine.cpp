@@ -270,6 +270,10 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (N_ < 3) schedule_ = 0;
   if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("PPALS_PLACE_TUNE")) ms_tune_enabled_ = std::atoi(e) != 0;
+  // (off unless asked for: on this stack the replay costs more than the nine launches it replaces,
+  // DESIGN.md section 8)
+  pp_graph_enabled_ = false;
+  if (const char *e = std::getenv("PPALS_GRAPH")) pp_graph_enabled_ = std::atoi(e) != 0;
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
     ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
@@ -335,6 +339,7 @@ CpEngine::~CpEngine() {
   for (auto p : dM_) ops_.free(p);
   for (auto p : Mm_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
+  pp_graph_drop();
   pp_clear();
   for (auto &kv : pp_pool_) ops_.free(kv.second.buf);
   ops_.free(pp_norms_);
@@ -1086,14 +1091,20 @@ void CpEngine::sweep_dt(double lambda) {
     return;
   }
   for (auto &n : nodes_) n.valid = false;  // mttkrp_map.clear(), als_CP.cxx:215
+  bool norm_fused = false;
   for (int i = 0; i < N_; i++) {
     compute_node(leaf_[i]);
     const Node &lf = nodes_[leaf_[i]];
+    if (i == N_ - 1 && !dist_) {  // Normalize at the tail of the sweep's last update launch
+      int64_t rows[MAX_ORDER];
+      for (int q = 0; q < N_; q++) rows[q] = V_.glens[q];
+      norm_fused = ops_.arm_normalize(W_.data(), rows, N_, R_, G_, i, nullptr);
+    }
     mode_update(i, lf.buf, ext(i), lambda, false, 1.0);
     // every cached node that does NOT contain mode i stays valid; nodes containing mode i were
     // built from W_j, j != i only, so they stay valid too until the cache is cleared.
   }
-  normalize();
+  if (!norm_fused) normalize();
   grad_from_sweep_ = true;
 }
 
@@ -1448,13 +1459,76 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
 // one approximate sweep: als_CP.cxx:754-825. Per mode: ONE launch for M = M_i^0 + the N-1
 // first-order corrections, ONE for the whole mode update (which also leaves ||dW_i||^2); the
 // Normalize launch leaves ||W_i||^2: the restart test of the next iteration costs no launch.
+std::vector<const void *> CpEngine::pp_graph_signature() const {
+  std::vector<const void *> sig;
+  for (const auto &kv : pp_) sig.push_back(kv.second.buf);
+  for (int i = 0; i < N_; i++) {
+    sig.push_back(W_[i]);
+    sig.push_back(gradW_[i]);
+    sig.push_back(Winit_[i]);
+    sig.push_back(dW_[i]);
+  }
+  sig.push_back(Mbuf_);
+  sig.push_back(pp_norms_);
+  sig.push_back(G_);
+  return sig;
+}
+void CpEngine::pp_graph_drop() {
+  if (pp_graph_) ops_.graph_destroy(pp_graph_);
+  pp_graph_ = nullptr;
+  pp_graph_sig_.clear();
+}
+// called when the operators of a PP phase have been built (part of the phase's set-up time, like
+// the operators themselves: [PPfirst] of the reference's timer)
+void CpEngine::pp_graph_prepare(double lambda, double ratio) {
+  if (!pp_graph_enabled_ || dist_) return;
+  if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+  if (!pp_norms_) {
+    pp_norms_ = (double *)ops_.alloc(sizeof(double) * 2 * MAX_ORDER);
+    ops_.zero(pp_norms_, sizeof(double) * 2 * MAX_ORDER);
+  }
+  const auto sig = pp_graph_signature();
+  if (pp_graph_ && sig == pp_graph_sig_ && lambda == pp_graph_lambda_ && ratio == pp_graph_ratio_)
+    return;  // the recording of an earlier phase names the same buffers: still good
+  pp_graph_drop();
+  if (!ops_.graph_capture_begin()) return;
+  bool ok = true;
+  try {
+    sweep_pp_body(lambda, ratio);
+  } catch (...) {
+    ok = false;  // something inside wanted to allocate or synchronise: no graph for this session
+  }
+  void *g = ops_.graph_capture_end();
+  if (!ok || !g) {
+    if (g) ops_.graph_destroy(g);
+    pp_graph_enabled_ = false;
+    return;
+  }
+  pp_graph_ = g;
+  pp_graph_sig_ = sig;
+  pp_graph_lambda_ = lambda;
+  pp_graph_ratio_ = ratio;
+}
+
 void CpEngine::sweep_pp(double lambda, double ratio) {
+  if (pp_graph_ && lambda == pp_graph_lambda_ && ratio == pp_graph_ratio_ &&
+      pp_graph_signature() == pp_graph_sig_) {
+    ms_invalidate();
+    ops_.graph_launch(pp_graph_);
+    grad_from_sweep_ = true;
+    return;
+  }
+  sweep_pp_body(lambda, ratio);
+}
+
+void CpEngine::sweep_pp_body(double lambda, double ratio) {
   ms_invalidate();  // PP moves the factors without touching the multi-sweep cache
   if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
   if (!pp_norms_) {
     pp_norms_ = (double *)ops_.alloc(sizeof(double) * 2 * MAX_ORDER);
     ops_.zero(pp_norms_, sizeof(double) * 2 * MAX_ORDER);
   }
+  bool norm_fused = false;
   for (int i = 0; i < N_; i++) {
     const int64_t si = ext(i);
     const PPOp &M0 = pp_get(all_but(N_, i));
@@ -1472,12 +1546,22 @@ void CpEngine::sweep_pp(double lambda, double ratio) {
       terms[nt].lddw = f.ld;
       nt++;
     }
+    // (S and S^-1 of this mode depend on the other modes' Grams only: a back end may prepare
+    // them on the side of the correction's launch)
+    ops_.arm_gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
     ops_.pp_correct((const double *)M0.buf, si, R_, terms, nt, Mbuf_);
+    if (i == N_ - 1 && !dist_) {  // Normalize at the tail of the sweep's last update launch
+      int64_t rows[MAX_ORDER];
+      for (int q = 0; q < N_; q++) rows[q] = V_.glens[q];
+      norm_fused = ops_.arm_normalize(W_.data(), rows, N_, R_, G_, i, pp_norms_ + 1);
+    }
     mode_update(i, Mbuf_, si, lambda, true, ratio);
   }
-  pp_norms_live_ = !dist_;
-  normalize();
-  pp_norms_live_ = false;
+  if (!norm_fused) {
+    pp_norms_live_ = !dist_;
+    normalize();
+    pp_norms_live_ = false;
+  }
   grad_from_sweep_ = true;
 }
 
@@ -1625,6 +1709,7 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
         ops_.zero(dW_[j], n);
       }
       pp_build_all();
+      pp_graph_prepare(o.lambda, o.ratio_step);
     }
     if (iter % o.resprint == 0 || iter == o.maxiter || iter == init_iter) {
       if (!o.bench) {

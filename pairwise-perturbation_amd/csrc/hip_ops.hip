@@ -75,12 +75,18 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_top_eig_small,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true>,
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<false, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_UPDATE_STAGE")) stage_update_ = atoi(v);
+    if (const char *v = getenv("PPALS_GRAPH")) graphs_ = atoi(v);
+    if (const char *v = getenv("PPALS_UPDATE_FUSE_NORM")) update_fuse_norm_ = atoi(v);
+    if (const char *v = getenv("PPALS_UPDATE_MFMA")) update_mfma_ = atoi(v);
+    if (const char *v = getenv("PPALS_UPDATE_PRESOLVE")) update_presolve_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
     if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
@@ -90,12 +96,13 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
     if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
+    if (const char *v = getenv("PPALS_GRAM_SYRK")) gram_syrk_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_block_orth,
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_m,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_tail,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_apply,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -120,8 +127,10 @@ class HipOps : public Ops {
     if (ws_cold_) hipFree(ws_cold_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
-    for (auto &kv : eig_state_)
+    for (auto &kv : eig_state_) {
       if (kv.second.Q) hipFree(kv.second.Q);
+      if (kv.second.Qn) hipFree(kv.second.Qn);
+    }
     for (auto &kv : eig_small_)
       if (kv.second.Q) hipFree(kv.second.Q);
     hipStreamDestroy(st_);
@@ -750,6 +759,12 @@ class HipOps : public Ops {
   }
   void gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
                    double *Sinv) override {
+    if (sys_ready_ && sys_.Gall == Gall && sys_.mode == mode && sys_.S == S && sys_.Sinv == Sinv &&
+        sys_.lambda == lambda && sys_R_ == R) {  // prepared on the side of the last contraction
+      sys_ready_ = false;
+      return;
+    }
+    sys_ready_ = false;
     if (R > 64) {  // S, S^-1 out of global memory (kernels_small.hip.h, "rank above 64")
       double *work = (double *)ensure(ws_big_, ws_big_sz_, sizeof(double) * (size_t)R * R + 64);
       int *status = (int *)(work + (size_t)R * R);
@@ -805,15 +820,71 @@ class HipOps : public Ops {
     size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
                  sizeof(int) * 64;
     const size_t stage = 2 * sizeof(double) * (size_t)rows * R;
-    if (stage_update_ && lds + stage <= 150 * 1024)
-      hipLaunchKernelGGL(k_cp_mode_update<true>, dim3(1), dim3(1024), lds + stage, st_, Gall, N, mode,
-                         R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd,
-                         ratio, S, Sinv, dwsq);
-    else
-      hipLaunchKernelGGL(k_cp_mode_update<false>, dim3(1), dim3(1024), lds, st_, Gall, N, mode, R,
-                         lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio,
-                         S, Sinv, dwsq);
+    // S / S^-1 prepared by the contraction launched before (arm_gram_system + pp_correct)?
+    const int presolved = (sys_ready_ && sys_.Gall == Gall && sys_.mode == mode && sys_.S == S &&
+                           sys_.Sinv == Sinv && S && sys_.lambda == lambda) ? 1 : 0;
+    sys_ready_ = false;
+    sys_armed_ = false;
+    NormArgs nrm;
+    if (norm_armed_) {
+      if (!(norm_.on && norm_mode_ == mode && norm_G_ == Gall && ldw == rows))
+        throw std::logic_error("ppals: armed Normalize does not match the mode update that followed");
+      nrm = norm_;
+      nrm.scales = small(MAX_ORDER);
+      norm_armed_ = false;
+    }
+    if (stage_update_ && lds + stage <= 150 * 1024) {
+      if (update_mfma_)
+        hipLaunchKernelGGL((k_cp_mode_update<true, true>), dim3(1), dim3(1024), lds + stage, st_, Gall, N,
+                           mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
+                           ldd, ratio, S, Sinv, dwsq, presolved, nrm);
+      else
+        hipLaunchKernelGGL((k_cp_mode_update<true, false>), dim3(1), dim3(1024), lds + stage, st_, Gall,
+                           N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
+                           ldd, ratio, S, Sinv, dwsq, presolved, nrm);
+    } else {
+      hipLaunchKernelGGL((k_cp_mode_update<false, false>), dim3(1), dim3(1024), lds, st_, Gall, N, mode,
+                         R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio,
+                         S, Sinv, dwsq, presolved);
+    }
     HIP_CHECK(hipGetLastError());
+  }
+  bool arm_normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall, int mode,
+                     double *wsq) override {
+    norm_armed_ = false;
+    if (!update_fuse_norm_ || R > 64 || force_jacobi_ || !stage_update_ || N > MAX_ORDER) return false;
+    int64_t tot = 0;
+    for (int i = 0; i < N; i++) tot += rows[i] * R;
+    const size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
+                       sizeof(int) * 64;
+    if (tot > 65536 || lds + 2 * sizeof(double) * (size_t)rows[mode] * R > 150 * 1024) return false;
+    norm_ = NormArgs();
+    norm_.on = 1;
+    for (int i = 0; i < N; i++) {
+      norm_.w.p[i] = W[i];
+      norm_.w.n[i] = rows[i] * R;
+    }
+    norm_.wsq = wsq;
+    norm_mode_ = mode;
+    norm_G_ = Gall;
+    (void)small(MAX_ORDER);  // (allocated now: no workspace growth inside the armed launch)
+    norm_armed_ = true;
+    return true;
+  }
+  void arm_gram_system(const double *Gall, int N, int mode, int R, double lambda, double *S,
+                       double *Sinv) override {
+    sys_ready_ = false;
+    sys_armed_ = false;
+    if (!update_presolve_ || force_jacobi_ || R > 32 || !S || !Sinv) return;
+    sys_.Gall = Gall;
+    sys_.N = N;
+    sys_.mode = mode;
+    sys_.lambda = lambda;
+    sys_.S = S;
+    sys_.Sinv = Sinv;
+    sys_.force_jacobi = 0;
+    sys_R_ = R;
+    sys_armed_ = true;
   }
   void pp_correct(const double *M0, int64_t rows, int R, const PPTerm *terms, int nterms,
                   double *M) override {
@@ -829,10 +900,19 @@ class HipOps : public Ops {
       tm.keep_first[t] = terms[t].keep_first;
     }
     dim3 grid((unsigned)((rows + 15) / 16), (unsigned)R);
+    SysArgs sys;
+    size_t lds = 0;
+    if (sys_armed_ && sys_R_ == R) {  // one more column of blocks: its first block prepares S, S^-1
+      sys = sys_;
+      grid.x += 1;
+      lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
+    }
     prof_begin(1, 0.0);
-    hipLaunchKernelGGL(k_pp_correct, grid, dim3(256), 0, st_, M0, rows, R, tm, M);
+    hipLaunchKernelGGL(k_pp_correct, grid, dim3(256), lds, st_, M0, rows, R, tm, M, sys);
     prof_end();
     HIP_CHECK(hipGetLastError());
+    if (sys.Gall) sys_ready_ = true;
+    sys_armed_ = false;
   }
   void cp_update(const double *M, int64_t ldm, const double *Wold, int64_t ldw, double *Wnew,
                  int64_t ldn, double *grad, int64_t ldg, int64_t rows, int R, const double *S,
@@ -959,6 +1039,29 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       return;
     }
+    if (gram_mfma_ && gram_syrk_ && dt == F32 && J >= 64 && C >= 4096 &&
+        ((L == 1 && J % 4 == 0) || (L > 1 && L % 4 == 0))) {
+      // K13 at size (the HOSVD Grams of the full tensor): the tiled SYRK, upper triangle only
+      const int nt = (int)((J + 63) / 64);
+      const int ntri = nt * (nt + 1) / 2;
+      int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)ncu_ * 3 + ntri - 1) / ntri),
+                                          std::max<int64_t>(1, C / 1024));
+      nsplit = std::min(nsplit, 512);
+      int64_t per = ((C + nsplit - 1) / nsplit + 31) / 32 * 32;
+      nsplit = (int)((C + per - 1) / per);
+      double *dst = nsplit > 1 ? (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * J * J) : G;
+      prof_begin(1, (double)C * J * dtype_size(dt));
+      hipLaunchKernelGGL(k_unfold_syrk_f32, dim3((unsigned)ntri, 1, (unsigned)nsplit), dim3(256), 0, st_,
+                         (const float *)X, L, J, T, per, dst);
+      prof_end();
+      HIP_CHECK(hipGetLastError());
+      if (nsplit > 1) {
+        hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(J * J, 256)), dim3(256), 0, st_, dst, nsplit,
+                           J * J, J * J, 1, G, (int64_t)1, (int64_t)0, 0, (int64_t)0, (int64_t)0);
+        HIP_CHECK(hipGetLastError());
+      }
+      return;
+    }
     const int tiles = (int)((J + 31) / 32);
     int nsplit = 1;
     const int64_t want = (int64_t)ncu_ * 4;
@@ -999,9 +1102,7 @@ class HipOps : public Ops {
   void top_eigvecs(double *G, int64_t J, int rank, double *U) override {
     RoctxRange roctx_("K12 eig (full solver)");
     if (J <= 64) {  // small modes: in-LDS Jacobi, one block
-      size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64 + 17) + sizeof(int) * 64;
-      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, G, (int)J, rank, U,
-                         (double *)nullptr);
+      launch_top_eig_small(G, (int)J, rank, U, nullptr);
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -1025,6 +1126,7 @@ class HipOps : public Ops {
     double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
     double head = 4.0;    // head room of the spectral-bound scale (projector_step, fused form)
     double *Q = nullptr;                  // previous basis (J x rank)
+    double *Qn = nullptr;                 // spare buffer of the same size (the step's result lands here)
     double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
     int fast = 0, full = 0;
   };
@@ -1033,6 +1135,14 @@ class HipOps : public Ops {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(k_dgemm_nx<false>, grid, dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C, ldc, M,
                        N, K, alpha, beta);
+  }
+  // in-LDS eigen-decomposition of a small symmetric matrix (J <= 64) by one workgroup: a thread
+  // per element when there are that many (two barriers per Jacobi round whatever the size)
+  void launch_top_eig_small(const double *G, int J, int rank, double *U, double *evals) {
+    // (a thread per element up to 15 waves, plus the wave that prepares the next round's angles)
+    const int nthr = std::min(1024, std::max(192, (J * J + 63) / 64 * 64) + 64);
+    hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(nthr), top_eig_small_lds(J), st_, G, J, rank, U,
+                       evals);
   }
   // the same with the second operand as it is (K x N, column-major): thin tails, no transposition
   void gemm_nn(const double *A, int64_t lda, const double *B, int64_t ldb, const double *D,
@@ -1062,7 +1172,9 @@ class HipOps : public Ops {
     es.rho = lam[rank];
     if (!es.Q || es.J != J || es.rank != rank) {
       if (es.Q) hipFree(es.Q);
+      if (es.Qn) hipFree(es.Qn);
       HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+      HIP_CHECK(hipMalloc(&es.Qn, sizeof(double) * J * rank));
     }
     es.J = J;
     es.rank = rank;
@@ -1125,8 +1237,7 @@ class HipOps : public Ops {
     transpose2d(B, F64, J, r, Bt);
     gemm_nt(G, J, Bt, r, nullptr, 0, GB, J, (int)J, r, (int)J, 1.0, 0.0);
     hipLaunchKernelGGL(k_tn_small, dim3((r * r + 15) / 16), dim3(1024), 0, st_, B, GB, J, r, H);
-    size_t lds = sizeof(double) * (2 * (size_t)r * (r + 1) + 64 + 17) + sizeof(int) * 64;
-    hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, H, r, r, Yr, ev);
+    launch_top_eig_small(H, r, r, Yr, ev);
     hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * r, 256)), dim3(256),
                        sizeof(double) * r * r, st_, B, J, r, Yr, U);
     if (GU)
@@ -1156,10 +1267,8 @@ class HipOps : public Ops {
       sm.J = J;
       sm.valid = false;
     }
-    const size_t lds = sizeof(double) * (2 * (size_t)J * (J + 1) + 64 + 17) + sizeof(int) * 64;
     if (!sm.valid || ++sm.age >= 64) {
-      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, G, Ji, Ji, sm.Q,
-                         (double *)nullptr);
+      launch_top_eig_small(G, Ji, Ji, sm.Q, nullptr);
       sm.valid = true;
       sm.age = 0;
     } else {
@@ -1168,7 +1277,7 @@ class HipOps : public Ops {
       transpose2d(sm.Q, F64, J, J, Qt);
       gemm_nt(G, J, Qt, J, nullptr, 0, C1, J, Ji, Ji, Ji, 1.0, 0.0);  // G Q
       hipLaunchKernelGGL(k_tn_small, dim3((Ji * Ji + 15) / 16), dim3(1024), 0, st_, sm.Q, C1, J, Ji, H);
-      hipLaunchKernelGGL(k_top_eig_small, dim3(1), dim3(256), lds, st_, H, Ji, Ji, Y, (double *)nullptr);
+      launch_top_eig_small(H, Ji, Ji, Y, nullptr);
       hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * J, 256)), dim3(256), sizeof(double) * nJJ, st_,
                          sm.Q, J, Ji, Y, Qn);
       HIP_CHECK(hipMemcpyAsync(sm.Q, Qn, sizeof(double) * nJJ, hipMemcpyDeviceToDevice, st_));
@@ -1226,6 +1335,7 @@ class HipOps : public Ops {
     for (auto it = eig_state_.begin(); it != eig_state_.end();)
       if (it->first >= base && it->first < base + 64) {
         if (it->second.Q) hipFree(it->second.Q);
+        if (it->second.Qn) hipFree(it->second.Qn);
         it = eig_state_.erase(it);
       } else {
         ++it;
@@ -1237,6 +1347,46 @@ class HipOps : public Ops {
       } else {
         ++it;
       }
+  }
+
+  // The tail of a projector step in six launches, none of them a lone workgroup with the rows in
+  // The tail of a projector step in seven launches, everything that touches the J rows multi-
+  // workgroup: Z = (Omega + X Omega) / 2 | C = Z^T Z and t = Q_D^T Z | M with [Q_D | Z] M
+  // orthonormal (one workgroup, cols x cols) | B = [Q_D | Z] M | G B | H = B^T G B | every
+  // workgroup diagonalises H itself (block Jacobi in LDS) and forms its rows of U = B Y and of the
+  // residual. `rounds` = 2 repeats the Gram / Cholesky / product on B (a basis far from
+  // orthonormal: cold starts, wide tails).
+  static constexpr int kTailBlocks = 64;
+  void fused_tail_launches(const double *G, const double *X, int64_t J, int cols, int rank,
+                           const double *Omega, const double *QD, int m, double *Z, double *Z2,
+                           double *GZ, double *C, double *H, double *Uout, double *evW, double *chk,
+                           int *status, const double *pe2, const double *ptr_, int np, int rounds = 1,
+                           double *Uout2 = nullptr) {
+    const int Ji = (int)J;
+    gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
+    const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
+    const int rows_per = (int)((J + nblk - 1) / nblk);
+    double *src = Z, *dst = Z2;
+    for (int rd = 0; rd < rounds; rd++) {
+      const int mm = rd == 0 ? m : 0;  // (the deflated columns are in place after the first round)
+      hipLaunchKernelGGL(k_tn_two, dim3((cols * cols + mm * cols + 15) / 16), dim3(1024), 0, st_, src, QD,
+                         J, cols, mm, C);
+      const int nn = cols - mm;
+      const size_t lds_c = sizeof(double) * (4 * (size_t)nn * nn + (size_t)std::max(mm, 1) * cols + 8);
+      // (M goes into H's area, which is free until the Gram of G B)
+      hipLaunchKernelGGL(k_chol_m, dim3(1), dim3(1024), lds_c, st_, src, QD, J, cols, mm, C, H, status + rd);
+      gemm_nn(src, J, H, cols, nullptr, 0, dst, J, Ji, cols, cols, 1.0, 0.0);
+      std::swap(src, dst);
+    }
+    double *B = src;  // (rounds == 1: Z2, rounds == 2: Z)
+    double *GB = GZ;
+    gemm_nn(G, J, B, J, nullptr, 0, GB, J, Ji, cols, Ji, 1.0, 0.0);
+    hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H);
+    double *resp = chk + 16 + 64 + 4 + 64;
+    // (two elements of H per thread + the wave that prepares the next Jacobi round's angles)
+    const int nthr_rr = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
+    hipLaunchKernelGGL(k_rr_apply, dim3(nblk), dim3(nthr_rr), top_eig_small_lds(cols) + sizeof(int) * 64, st_, B,
+                       GB, J, cols, rank, H, rows_per, pe2, ptr_, np, Uout, Uout2, evW, chk, resp);
   }
   // One projector step from the state of the slot; false: not accepted (the caller falls back).
   // strict: the state is a rough estimate (cold start) — accept only residuals at the rounding
@@ -1253,7 +1403,7 @@ class HipOps : public Ops {
     constexpr int kWide = 16;
     const size_t nJW = (size_t)J * (rank + kWide);
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
-                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 256));
+                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 512));
     double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
     double *Ot = Y + nJJ, *Z = Ot + nJW, *Z2 = Z + nJW, *GZ = Z2 + nJW, *Ut = GZ + nJW,
            *GU = Ut + nJW, *QD = GU + nJW, *QD2 = QD + nJW, *Om = QD2 + nJW, *Uw = Om + nJW;
@@ -1264,7 +1414,7 @@ class HipOps : public Ops {
            *evW = chk + 16;
     int *status = (int *)(evW + 64);
     double *lamD = evW + 64 + 4;
-    constexpr size_t kReadback = sizeof(double) * (16 + 64) + sizeof(int) * 8;
+    constexpr size_t kReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
     HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
     double sigma = 0.5 * (es.lamR + es.lamR1);
     if (eig_sigma_scale_ > 0) sigma = eig_sigma_scale_ * es.lamR1;  // tests: a shift that is too low
@@ -1298,7 +1448,8 @@ class HipOps : public Ops {
       // one dominant eigenpair (a tensor with a mean component): power steps on one vector. The
       // previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
       // Rayleigh quotient left by the last step is that of its input: second order in its error.
-      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-15) / std::log(ratio)))) + 1;
+      // (k steps leave an error of 1e-2 * ratio^k in the vector and its square in the quotient)
+      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-14) / std::log(ratio))));
       const int nb = (int)((J + 7) / 8);
       double *pw = (double *)ensure(ws_pow_, ws_pow_sz_, sizeof(double) * 4 * (size_t)nb);
       double *pbuf[2] = {pw, pw + 2 * (size_t)nb};
@@ -1371,9 +1522,7 @@ class HipOps : public Ops {
     const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
     // fused tail: the check sums ride on the LAST step's two products (per-tile partial sums of
     // ||X_prev^2 - I||_F^2 and of trace(X_new), added up by the tail's last kernel)
-    const bool fused_tail = eig_fused_ && m <= 1 &&
-                            sizeof(double) * ((size_t)J * (rank + kWide) + 2 * (size_t)(rank + kWide) * (rank + kWide) + 64) <=
-                                (size_t)150 * 1024;
+    const bool fused_tail = eig_fused_ && m <= 1 && rank + kWide <= 64;
     double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
     double *ptr_ = pe2 + ntri;
     auto ns_step = [&](double mu, bool last = false) {
@@ -1412,20 +1561,20 @@ class HipOps : public Ops {
       // residual in chk[4], all `cols` eigenvalues in evW; then the one read-back of the step
       auto tail = [&](int cols, const double *Omega, double *Uout, int npass) {
         if (fused_tail) {
-          // Z = (Omega + X Omega) / 2 | orthonormal basis of [Q_D | rest] in ONE workgroup, the block
-          // in LDS | G B | Rayleigh-Ritz, back-products, residual and the check sums in ONE workgroup
-          gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
-          const size_t lds_o = sizeof(double) * ((size_t)J * cols + 2 * (size_t)cols * cols + 64);
-          hipLaunchKernelGGL(k_block_orth, dim3(1), dim3(1024), lds_o, st_, Z, J, cols, QD, m, npass, Z2,
-                             status);
-          gemm_nn(G, J, Z2, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);
-          const size_t lds_r = sizeof(double) * (2 * (size_t)cols * (cols + 1) + 64 + 17) + sizeof(int) * 128;
-          hipLaunchKernelGGL(k_rr_tail, dim3(1), dim3(1024), lds_r, st_, Z2, GZ, J, cols, rank, pe2, ptr_,
-                             (int)ntri, Uout, evW, chk);
+          // (the leading eigenvectors also go to the slot's spare basis buffer: accepted = a swap)
+          fused_tail_launches(G, X, J, cols, rank, Omega, QD, m, Z, Z2, GZ, C, H, Uout, evW, chk, status,
+                              pe2, ptr_, (int)ntri, npass, Uout == U ? es.Qn : nullptr);
           if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
           HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
           HIP_CHECK(hipStreamSynchronize(st_));
           HIP_CHECK(hipGetLastError());
+          {  // the residual's per-workgroup shares are added up here
+            double *hcw = (double *)eig_host_;
+            const double *rp = hcw + 16 + 64 + 4 + 64;
+            double r2 = 0;
+            for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
+            hcw[4] = r2;
+          }
           return;
         }
         transpose2d(Omega, F64, J, cols, Ot);  // Omega^T (cols x J): coalesced B operand
@@ -1450,9 +1599,7 @@ class HipOps : public Ops {
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipGetLastError());
       };
-      // (fused tail: the second Cholesky-QR pass costs ~3 us inside the one-workgroup kernel, so it
-      // always runs and a basis that moved far from the previous one is no reason to reject)
-      tail(rank, es.Q, U, fused_tail ? 2 : 1);
+      tail(rank, es.Q, U, 1);
       const double *hc = (const double *)eig_host_, *evn = hc + 16;
       const int *hs = (const int *)(evn + 64);
       const double cnt = 0.5 * (hc[1] + (double)J), res = std::sqrt(hc[4]);
@@ -1468,7 +1615,7 @@ class HipOps : public Ops {
       const double gap_now = std::max(0.0, evn[rank - 1] - sigma);
       const double res_tol = (strict ? 1e-13 * evn[0] : std::max(1e-9 * gap_now, 1e-14 * evn[0])) *
                              std::sqrt((double)rank);
-      const bool chol_ok = fused_tail ? (hs[0] != 1 && hs[1] == 0) : hs[0] == 0;
+      const bool chol_ok = hs[0] == 0;
       const bool good = converged && std::fabs(cnt - rank) < 1e-6 && chol_ok && hs[2] != 1 && hs[3] == 0 &&
                         res <= res_tol && std::isfinite(rho_now);
       if (eig_debug_)
@@ -1491,7 +1638,10 @@ class HipOps : public Ops {
         es.rho_frob = rho_now;
         if (strict) es.lamR1 = std::min(es.lamR1, es.lamR * (1 - 1e-6));  // (a rough estimate)
         if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;  // next call: full solver
-        HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
+        if (fused_tail)
+          std::swap(es.Q, es.Qn);
+        else
+          HIP_CHECK(hipMemcpyAsync(es.Q, U, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
         es.fast++;
         return true;
       }
@@ -1561,10 +1711,23 @@ class HipOps : public Ops {
                        (uint64_t)(0x5eed + slot));
     double *cur = Z, *oth = Z2;
     for (int it = 0; it < 4; it++) {
-      transpose2d(cur, F64, J, b, Zt);
-      gemm_nt(G, J, Zt, b, nullptr, 0, oth, J, Ji, b, Ji, 1.0, 0.0);  // G * block
-      double *res = chol_qr2(oth, cur, J, b, C, status);             // two passes: ends in `oth`
-      if (res != oth) return false;
+      gemm_nn(G, J, cur, J, nullptr, 0, oth, J, Ji, b, Ji, 1.0, 0.0);  // G * block
+      if (eig_fused_) {
+        // Cholesky QR twice: Gram (one wave per entry) | M = R^-1 by one workgroup | thin product
+        double *src = oth, *dst = cur;
+        for (int pass = 0; pass < 2; pass++) {
+          hipLaunchKernelGGL(k_tn_two, dim3((b * b + 15) / 16), dim3(1024), 0, st_, src, (const double *)nullptr,
+                             J, b, 0, C);
+          hipLaunchKernelGGL(k_chol_m, dim3(1), dim3(1024), sizeof(double) * (4 * (size_t)b * b + b + 8), st_,
+                             src, (const double *)nullptr, J, b, 0, C, H, status + pass);
+          gemm_nn(src, J, H, b, nullptr, 0, dst, J, Ji, b, b, 1.0, 0.0);
+          std::swap(src, dst);
+        }
+        // (two passes: the result is back in `oth`)
+      } else {
+        double *res = chol_qr2(oth, cur, J, b, C, status);  // two passes: ends in `oth`
+        if (res != oth) return false;
+      }
       std::swap(cur, oth);
     }
     rayleigh_ritz(G, cur, J, b, Zt, GB, H, Yr, Uo, ev, nullptr);
@@ -1589,7 +1752,9 @@ class HipOps : public Ops {
     if (!ok) return false;
     if (!es.Q || es.J != J || es.rank != rank) {
       if (es.Q) hipFree(es.Q);
+      if (es.Qn) hipFree(es.Qn);
       HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+      HIP_CHECK(hipMalloc(&es.Qn, sizeof(double) * J * rank));
     }
     es.J = J;
     es.rank = rank;
@@ -1619,9 +1784,7 @@ class HipOps : public Ops {
     const int Ji = (int)J, b = cold_b_;
     const size_t nJJ = (size_t)J * J, nJR = (size_t)J * rank, nJW = (size_t)J * (rank + kWide);
     if (rank + kWide > b || rank + kWide >= Ji) return false;
-    if (sizeof(double) * ((size_t)J * (rank + kWide) + 2 * (size_t)(rank + kWide) * (rank + kWide) + 64) >
-        (size_t)150 * 1024)
-      return false;
+    if (rank + kWide > 64) return false;
     const double *th = cold_th_;
     int m = 0;
     for (int d = 1; d < rank; d++)
@@ -1629,14 +1792,15 @@ class HipOps : public Ops {
     if (m > 1) return false;
     const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
-                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 256));
+                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 512));
     double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
     double *Z = Y + nJJ, *Z2 = Z + nJW, *GZ = Z2 + nJW, *QD = GZ + nJW, *y0 = QD + nJW, *y1 = y0 + nJW,
            *Uw = y1 + nJW;
+    double *Cw = Y + nJJ + 10 * nJW, *Hw = Cw + 64 * 64;
     double *chk = Y + nJJ + 10 * nJW + 3 * 64 * 64, *evW = chk + 16;
     int *status = (int *)(evW + 64);
     double *lamD = evW + 64 + 4;
-    constexpr size_t kReadback = sizeof(double) * (16 + 64) + sizeof(int) * 8;
+    constexpr size_t kReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
     double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
     double *ptr_ = pe2 + ntri;
     if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
@@ -1761,16 +1925,18 @@ class HipOps : public Ops {
     // ---- the tail on `cols` columns: P applied to the Ritz block (a generic basis), two Cholesky-QR
     // passes, Rayleigh-Ritz; the deflated eigenvector takes the place of the first column
     HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
-    gemm_nn(X, J, Om, J, Om, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
-    const size_t lds_o = sizeof(double) * ((size_t)J * cols + 2 * (size_t)cols * cols + 64);
-    hipLaunchKernelGGL(k_block_orth, dim3(1), dim3(1024), lds_o, st_, Z, J, cols, QD, m, 2, Z2, status);
-    gemm_nn(G, J, Z2, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);
-    const size_t lds_r = sizeof(double) * (2 * (size_t)cols * (cols + 1) + 64 + 17) + sizeof(int) * 128;
-    hipLaunchKernelGGL(k_rr_tail, dim3(1), dim3(1024), lds_r, st_, Z2, GZ, J, cols, rank, pe2, ptr_,
-                       (int)ntri, Uw, evW, chk);
+    fused_tail_launches(G, X, J, cols, rank, Om, QD, m, Z, Z2, GZ, Cw, Hw, Uw, evW, chk, status, pe2, ptr_,
+                        (int)ntri, 2);
     HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipGetLastError());
+    {
+      double *hcw = (double *)eig_host_;
+      const double *rp = hcw + 16 + 64 + 4 + 64;
+      double r2 = 0;
+      for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
+      hcw[4] = r2;
+    }
     const double *hc = (const double *)eig_host_, *evn = hc + 16;
     const int *hs = (const int *)(evn + 64);
     const double res = std::sqrt(hc[4]);
@@ -1786,7 +1952,9 @@ class HipOps : public Ops {
     HIP_CHECK(hipMemcpyAsync(U, Uw, sizeof(double) * nJR, hipMemcpyDeviceToDevice, st_));
     if (!es.Q || es.J != J || es.rank != rank) {
       if (es.Q) hipFree(es.Q);
+      if (es.Qn) hipFree(es.Qn);
       HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+      HIP_CHECK(hipMalloc(&es.Qn, sizeof(double) * J * rank));
     }
     es.J = J;
     es.rank = rank;
@@ -1829,6 +1997,38 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(256), 0, st_, x, n, part);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, g, out);
     HIP_CHECK(hipGetLastError());
+  }
+
+  // ------------------------------------------------------------------ launch graphs
+  bool graph_capture_begin() override {
+    if (profiling_ || !graphs_) return false;
+    if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return true;
+  }
+  void *graph_capture_end() override {
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t rc = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return (void *)ex;
+  }
+  void graph_launch(void *graph) override { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph, st_)); }
+  void graph_destroy(void *graph) override {
+    if (graph) {
+      hipStreamSynchronize(st_);
+      hipGraphExecDestroy((hipGraphExec_t)graph);
+    }
   }
 
   // ------------------------------------------------------------------ profiling
@@ -1904,6 +2104,18 @@ class HipOps : public Ops {
 
   int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
   int eig_debug_ = 0;
+  SysArgs sys_;             // arm_gram_system: the system the next contraction prepares on the side
+  int sys_R_ = 0;
+  bool sys_armed_ = false, sys_ready_ = false;
+  int update_mfma_ = 1;     // PPALS_UPDATE_MFMA=0: the row products of the fused update as VALU loops
+  int update_presolve_ = 1; // PPALS_UPDATE_PRESOLVE=0: S / S^-1 always inside the update launch
+  NormArgs norm_;           // arm_normalize: folded into the next cp_mode_update
+  int norm_mode_ = -1;
+  const double *norm_G_ = nullptr;
+  bool norm_armed_ = false;
+  int update_fuse_norm_ = 1;  // PPALS_UPDATE_FUSE_NORM=0: Normalize always a launch of its own
+  int graphs_ = 0;          // PPALS_GRAPH=1: replay the approximate sweep as a recorded launch graph
+                            // (A/B: 9 launches take 103 us one by one, 114-122 us as a graph)
   bool eig_frob_once_ = false;
   int eig_fused_ = 1;  // PPALS_EIG_FUSED=0: the multi-launch tail and the Frobenius scale (A/B, tests)
   int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
@@ -1911,6 +2123,7 @@ class HipOps : public Ops {
   size_t ws_cold_sz_ = 0;
   double eig_sigma_scale_ = 0;  // PPALS_EIG_SIGMA_SCALE=f: shift = f * (estimate of the next eigenvalue) (tests)
   int gram_mfma_ = 1;     // PPALS_GRAM_MFMA=0: the fp64 VALU Gram kernel (A/B, tests)
+  int gram_syrk_ = 1;     // PPALS_GRAM_SYRK=0: the 32 x 32-tile Gram kernel of round 2 (A/B)
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
   int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)

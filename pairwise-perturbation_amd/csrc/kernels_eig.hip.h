@@ -230,6 +230,132 @@ __global__ __launch_bounds__(256) void k_unfold_gram_mfma(const TV *__restrict__
   }
 }
 
+// K13, second generation (fp32 tensor storage): the same Gram as a real SYRK.
+//   * only the tiles on and above the diagonal are computed (blockIdx.x enumerates them), every
+//     value is written at (p, q) and (q, p) of the slab;
+//   * 64 x 64 tile per workgroup, each of its four waves a 32 x 32 quarter = four 16 x 16
+//     v_mfma_f64_16x16x4_f64 accumulators fed from two A and two B fragments per reduction step
+//     (one LDS read per MFMA instead of two);
+//   * 32 reduction indices per barrier pair as before, but the NEXT chunk's global loads are in
+//     flight (16 floats per thread in registers) while the current one is multiplied;
+//   * operands are widened to fp64 on their way into LDS: products of fp32 values are exact in
+//     fp64, so the Gram carries fp64 rounding only (lambda_1 is 1e4 x the bulk for a tensor with
+//     a mean component; fp32 products would smear it over the eigenvectors that matter).
+// Needs 4-element aligned rows: J % 4 == 0 when L == 1 (p fastest), L % 4 == 0 otherwise, and
+// c_per_split % 32 == 0. LDS: As, Bs [32][80] doubles (row stride 80: the four k-groups of an MFMA
+// operand read land in different bank groups).
+__global__ __launch_bounds__(256) void k_unfold_syrk_f32(const float *__restrict__ X, int64_t L,
+                                                         int64_t J, int64_t T, int64_t c_per_split,
+                                                         double *__restrict__ slab) {
+  constexpr int TS = 64, KC = 32, LD = 80;
+  __shared__ double As[KC][LD];
+  __shared__ double Bs[KC][LD];
+  const int64_t C = L * T;
+  const int nt = (int)((J + TS - 1) / TS);
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ti++;
+  }
+  const int tj = ti + rem;
+  const bool diag = ti == tj;
+  const int64_t p0 = (int64_t)ti * TS, q0 = (int64_t)tj * TS;
+  const int64_t c_begin = (int64_t)blockIdx.z * c_per_split;
+  const int64_t c_end = min(C, c_begin + c_per_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+  const bool p_fast = (L == 1);
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // per-thread slice of a 64 x 32 panel: p-fast: rows pq..pq+3 of columns cc, cc + 16;
+  // c-fast: row pp, columns cq..cq+7
+  const int pq = (tid & 15) * 4, cc = tid >> 4;
+  const int pp = tid >> 2, cq = (tid & 3) * 8;
+  float ra[8], rb[8];
+  auto fetch = [&](int64_t c0, int64_t r0, float *r) {
+    if (p_fast) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int64_t c = c0 + cc + 16 * h;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < c_end && r0 + pq < J) v = *reinterpret_cast<const float4 *>(X + (r0 + pq) + J * c);
+        r[4 * h + 0] = v.x;
+        r[4 * h + 1] = v.y;
+        r[4 * h + 2] = v.z;
+        r[4 * h + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int64_t c = c0 + cq + 4 * h;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < c_end && r0 + pp < J) {
+          const int64_t l = c % L, t = c / L;
+          v = *reinterpret_cast<const float4 *>(X + l + L * ((r0 + pp) + J * t));
+        }
+        r[4 * h + 0] = v.x;
+        r[4 * h + 1] = v.y;
+        r[4 * h + 2] = v.z;
+        r[4 * h + 3] = v.w;
+      }
+    }
+  };
+  auto stash = [&](double (*S)[LD], const float *r) {
+    if (p_fast) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) S[cc + 16 * h][pq + k] = (double)r[4 * h + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) S[cq + k][pp] = (double)r[k];
+    }
+  };
+  fetch(c_begin, p0, ra);
+  if (!diag) fetch(c_begin, q0, rb);
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += KC) {
+    __syncthreads();  // the previous chunk's fragments have been read
+    stash(As, ra);
+    if (!diag) stash(Bs, rb);
+    __syncthreads();
+    if (c0 + KC < c_end) {  // next chunk on its way while this one is multiplied
+      fetch(c0 + KC, p0, ra);
+      if (!diag) fetch(c0 + KC, q0, rb);
+    }
+    double (*Bp)[LD] = diag ? As : Bs;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ks++) {
+      const double a0 = As[4 * ks + g][wi + l16], a1 = As[4 * ks + g][wi + 16 + l16];
+      const double b0 = Bp[4 * ks + g][wj + l16], b1 = Bp[4 * ks + g][wj + 16 + l16];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  double *gs = slab + (int64_t)blockIdx.z * J * J;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int64_t q = q0 + wj + 16 * b + l16;  // D: lane holds column l16, rows g + 4 r
+      if (q < J) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int64_t pr = p0 + wi + 16 * a + g + 4 * r;
+          if (pr < J) {
+            gs[pr + J * q] = acc[a][b][r];
+            if (!diag) gs[q + J * pr] = acc[a][b][r];
+          }
+        }
+      }
+    }
+}
+
 // X = (G - sigma I) / rho   (J x J)
 __global__ void k_shift_scale(const double *__restrict__ G, int64_t J, double sigma, double inv_rho,
                               double *__restrict__ X) {
@@ -587,120 +713,201 @@ __global__ void k_half_sum(const double *__restrict__ a, const double *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// The tail of a projector step in TWO single-workgroup launches (was ~17: projections, Gram,
-// Cholesky, triangular product, transposition, H = B^T G B, Jacobi, two back-products, residual,
-// reductions of the check sums). Everything here is a few hundred rows by a few dozen columns.
+// The tail of a projector step: thin products and reductions over the J rows stay multi-workgroup
+// (a lone workgroup waits a full memory round trip per dependent access: the first fused version,
+// two one-workgroup kernels, took 320 us where these six launches take ~60); what is only
+// cols x cols — the Cholesky factor of the basis' Gram, the eigen-decomposition of H — is done by
+// EVERY workgroup of the launch that needs it, redundantly, in its own LDS, instead of a launch of
+// its own plus a global round trip.
 //
-// k_block_orth: Z (J x cols, global) -> B (J x cols, global) with orthonormal columns spanning the
-// same space: [optional] the m leading columns are REPLACED by QD (J x m, orthonormal: the deflated
-// eigenvectors from the power iteration) and the others are cleared of them (twice); then Cholesky
-// QR, `npass` passes (2 unless Z is known to be nearly orthonormal). Z lives in LDS as it goes
-// (J * cols * 8 bytes of dynamic LDS + 2 cols^2 + 64). status[0..npass): as k_chol_rinv.
-__global__ __launch_bounds__(1024) void k_block_orth(const double *__restrict__ Z, int64_t J, int cols,
-                                                     const double *__restrict__ QD, int m, int npass,
-                                                     double *__restrict__ B, int *__restrict__ status) {
+// k_tn_two: C[p + cols q] = z_p^T z_q (cols x cols) and, behind it, t[d + m c] = q_d^T z_c (m x cols):
+// one wave per entry.
+__global__ void k_tn_two(const double *__restrict__ Z, const double *__restrict__ QD, int64_t rows,
+                         int cols, int m, double *__restrict__ C) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int n1 = cols * cols, ntot = n1 + m * cols;
+  for (int e = wid; e < ntot; e += nw) {
+    const double *a, *b;
+    if (e < n1) {
+      a = Z + rows * (e % cols);
+      b = Z + rows * (e / cols);
+    } else {
+      a = QD + rows * ((e - n1) % m);
+      b = Z + rows * ((e - n1) / m);
+    }
+    double s = 0;
+    for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
+    s = wave_sum(s);
+    if (lane == 0) C[e] = s;
+  }
+}
+
+// k_chol_m (ONE workgroup, cols x cols work only): the matrix M (cols x cols) with
+//   B = [Q_D | Z[:, m:]] * M  =  orthonormal basis of [Q_D | (I - Q_D Q_D^T) Z[:, m:]]   (Cholesky QR),
+// from C = Z^T Z and t = Q_D^T Z (k_tn_two). With C' = C[m:, m:] - t^T t (the Gram of the deflated
+// block; Q_D is orthonormal) = L L^T and Rinv = L^-T:  M = [[I_m, -t[:, m:] Rinv], [0, Rinv]].
+// Rinv comes from ONE elimination of the augmented matrix [C' | I] (row operations, all 2 n^2
+// elements of a step in parallel, ping-pong buffers: one barrier per pivot): C' -> D L_1^T, I ->
+// L_1^-1 (unit lower), Rinv[p][q] = L_1^-1[q][p] / sqrt(d_q). The thin product itself is a launch
+// of the MFMA GEMM. Also copies Q_D into the first m columns of Z. *status: 1 = a pivot is not
+// safely positive (numerically rank deficient), 2 = pivots spread by more than 4 (one Cholesky-QR
+// pass leaves an orthogonality error of eps * cond), else 0.
+// dynamic LDS: 2 buffers of n x 2n | T[max(m,1) x cols] | sc[8]
+__global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const double *__restrict__ QD,
+                                                 int64_t J, int cols, int m,
+                                                 const double *__restrict__ C, double *__restrict__ M,
+                                                 int *__restrict__ status) {
   extern __shared__ double lds[];
-  double *Zs = lds;                           // J x cols, column-major
-  double *Cm = Zs + (size_t)J * cols;         // cols x cols
-  double *Ri = Cm + cols * cols;              // cols x cols
-  double *red = Ri + cols * cols;             // 64
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int Ji = (int)J;
-  for (int e = tid; e < Ji * cols; e += blockDim.x) {
-    const int c = e / Ji;
-    Zs[e] = (c < m) ? QD[e] : Z[e];
+  const int n = cols - m, w2 = 2 * n;
+  double *E0 = lds, *E1 = E0 + n * w2;   // row-major n x 2n: [C' | I] being eliminated
+  double *T = E1 + n * w2;
+  double *sc = T + (m > 0 ? m : 1) * cols;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int64_t e = tid; e < J * m; e += nthr) Z[e] = QD[e];
+  const double *tg = C + cols * cols;
+  for (int e = tid; e < m * cols; e += nthr) T[e] = tg[e];
+  __syncthreads();
+  for (int e = tid; e < n * w2; e += nthr) {
+    const int i = e / w2, j = e - i * w2;
+    double v;
+    if (j < n) {
+      v = C[(m + i) + cols * (m + j)];
+      for (int d = 0; d < m; d++) v -= T[d + m * (m + i)] * T[d + m * (m + j)];
+    } else {
+      v = (j - n == i) ? 1.0 : 0.0;
+    }
+    E0[e] = v;
   }
   __syncthreads();
-  for (int pass = 0; pass < 2 && m > 0; pass++) {
-    // t[d][c] = q_d^T z_c, then z_c -= sum_d q_d t[d][c]   (c >= m)
-    for (int e = wave; e < m * (cols - m); e += nw) {
-      const int d = e % m, c = m + e / m;
-      double s = 0;
-      for (int i = lane; i < Ji; i += 64) s += Zs[i + Ji * d] * Zs[i + Ji * c];
-      s = wave_sum(s);
-      if (lane == 0) Cm[d + m * (c - m)] = s;
-    }
-    __syncthreads();
-    for (int e = tid; e < Ji * (cols - m); e += blockDim.x) {
-      const int i = e % Ji, c = m + e / Ji;
-      double a = 0;
-      for (int d = 0; d < m; d++) a += Zs[i + Ji * d] * Cm[d + m * (c - m)];
-      Zs[i + Ji * c] -= a;
-    }
-    __syncthreads();
+  if (tid == 0) {
+    double dmax = 0;
+    for (int k = 0; k < n; k++) dmax = fmax(dmax, E0[k * w2 + k]);
+    sc[0] = dmax;
+    sc[1] = dmax;
+    sc[2] = 0.0;
   }
-  for (int pass = 0; pass < npass; pass++) {
-    // C = Z^T Z (upper triangle computed, mirrored)
-    const int ntri = cols * (cols + 1) / 2;
-    for (int e = wave; e < ntri; e += nw) {
-      int p = 0, rem = e;
-      while (rem >= cols - p) {
-        rem -= cols - p;
-        p++;
-      }
-      const int q = p + rem;
-      double s = 0;
-      for (int i = lane; i < Ji; i += 64) s += Zs[i + Ji * p] * Zs[i + Ji * q];
-      s = wave_sum(s);
-      if (lane == 0) {
-        Cm[p + cols * q] = s;
-        Cm[q + cols * p] = s;
-      }
+  __syncthreads();
+  double *src = E0, *dst = E1;
+  for (int k = 0; k < n; k++) {
+    const double d = src[k * w2 + k];
+    if (!(d > 1e-14 * sc[0])) {  // (uniform)
+      if (tid == 0) sc[2] = 1.0;
+      break;
+    }
+    if (tid == 0) sc[1] = fmin(sc[1], d);
+    const double dinv = 1.0 / d;
+    for (int e = tid; e < n * w2; e += nthr) {
+      const int i = e / w2, j = e - i * w2;
+      double v = src[e];
+      if (i > k) v -= (src[i * w2 + k] * dinv) * src[k * w2 + j];
+      dst[e] = v;
     }
     __syncthreads();
-    if (wave == 0) {  // Cholesky C = L L^T in place (lower), Ri = L^{-T}: one wave, as k_chol_rinv
-      const int r = cols;
-      double *L = Cm, *X = Ri;
-      for (int e = lane; e < r * r; e += 64) X[e] = 0.0;
-      wave_sync();
-      double dmax = 0;
-      for (int k = 0; k < r; k++) dmax = fmax(dmax, L[k + r * k]);
-      bool bad = false;
-      double pmin = dmax;
-      for (int k = 0; k < r; k++) {
-        const double d = L[k + r * k];
-        if (!(d > 1e-14 * dmax)) {
-          bad = true;
-          break;
-        }
-        pmin = fmin(pmin, d);
-        const double sk = sqrt(d);
-        wave_sync();
-        for (int i = k + lane; i < r; i += 64) L[i + r * k] = (i == k) ? sk : L[i + r * k] / sk;
-        wave_sync();
-        for (int e = lane; e < (r - k - 1) * (r - k - 1); e += 64) {
-          const int i = k + 1 + e % (r - k - 1), j = k + 1 + e / (r - k - 1);
-          if (i >= j) L[i + r * j] -= L[i + r * k] * L[j + r * k];
-        }
-        wave_sync();
-      }
-      if (lane == 0) status[pass] = bad ? 1 : (dmax > 4.0 * pmin ? 2 : 0);
-      if (lane == 0) red[0] = bad ? 1.0 : 0.0;
-      if (!bad) {
-        for (int c = lane; c < r; c += 64) {  // X = L^{-1}, one column per lane
-          for (int i = c; i < r; i++) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; k++) s -= L[i + r * k] * X[k + r * c];
-            X[i + r * c] = s / L[i + r * i];
-          }
-        }
-      }
-      wave_sync();
-    }
-    __syncthreads();
-    if (red[0] != 0.0) break;  // rank deficient: the caller falls back (status says so)
-    // Z <- Z * L^{-T}: column q of the result = sum_{p <= q} z_p * Linv[q][p] needs the OLD columns
-    // p <= q only, so the columns are replaced from the last one down, every thread its own rows
-    for (int i = tid; i < Ji; i += blockDim.x) {
-      for (int q = cols - 1; q >= 0; q--) {
+    double *t0 = src;
+    src = dst;
+    dst = t0;
+  }
+  __syncthreads();
+  const bool bad = sc[2] != 0.0;
+  if (tid == 0) *status = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
+  if (bad) return;
+  // src = [D L_1^T | L_1^-1]; Rinv[p][q] = L_1^-1[q][p] / sqrt(d_q)  (upper triangular)
+  for (int e = tid; e < cols * cols; e += nthr) {
+    const int r = e % cols, c = e / cols;  // M[r + cols c]
+    double v;
+    if (c < m) {
+      v = (r == c) ? 1.0 : 0.0;
+    } else {
+      const int q = c - m;
+      const double isq = 1.0 / sqrt(src[q * w2 + q]);
+      if (r >= m) {
+        const int p = r - m;
+        v = (p <= q) ? src[q * w2 + n + p] * isq : 0.0;
+      } else {  // -(t[:, m:] Rinv)[r][q] = -sum_{p <= q} t[r][m + p] Rinv[p][q]
         double a = 0;
-        for (int p = 0; p <= q; p++) a += Zs[i + Ji * p] * Ri[q + cols * p];
-        Zs[i + Ji * q] = a;
+        for (int p = 0; p <= q; p++) a += T[r + m * (m + p)] * src[q * w2 + n + p];
+        v = -a * isq;
       }
     }
-    __syncthreads();
+    M[e] = v;
   }
-  for (int e = tid; e < Ji * cols; e += blockDim.x) B[e] = Zs[e];
+}
+
+// k_rr_apply: every workgroup loads H = B^T G B (cols x cols), diagonalises it (block Jacobi in
+// LDS), ranks the eigenvalues descending and forms, for its own `rows_per` rows, U = B Y[:, :rank]
+// and its share of || G U - U diag(ev) ||_F^2 (-> resp[blockIdx.x]; the host adds them up).
+// Workgroup 0 also writes the eigenvalues (evW[0..cols)) and adds up the check sums the sign
+// iteration's last two products left (np each): chk[0] = ||X_prev^2 - I||_F^2, chk[1] = trace(X).
+// dynamic LDS: top_eig_small_lds(cols) + 64 ints (ord)
+__global__ __launch_bounds__(1024) void k_rr_apply(const double *__restrict__ Bm,
+                                                  const double *__restrict__ GB, int64_t J, int cols,
+                                                  int rank, const double *__restrict__ H, int rows_per,
+                                                  const double *__restrict__ part_e2,
+                                                  const double *__restrict__ part_tr, int np,
+                                                  double *__restrict__ U, double *__restrict__ U2,
+                                                  double *__restrict__ evW, double *__restrict__ chk,
+                                                  double *__restrict__ resp) {
+  extern __shared__ double lds[];
+  const int ldA = cols + 1;
+  double *A0 = lds, *A1 = A0 + cols * ldA, *Q0 = A1 + cols * ldA, *Q1 = Q0 + cols * ldA;
+  double *rc = Q1 + cols * ldA, *rs = rc + 128, *red = rs + 128;
+  int *partner = (int *)(red + 17);
+  int *ord = partner + 128;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int e = tid; e < cols * cols; e += nthr) {  // symmetrised on the way in
+    const int i = e % cols, j = e / cols;
+    A0[i * ldA + j] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
+  }
+  __syncthreads();
+  double *A, *Q;
+  jacobi_eig_block(A0, A1, Q0, Q1, cols, rc, rs, partner, red, &A, &Q);
+  if (tid < cols) {
+    const double wk = A[tid * ldA + tid];
+    int pos = 0;
+    for (int j = 0; j < cols; j++) {
+      const double wj = A[j * ldA + j];
+      if (wj > wk || (wj == wk && j < tid)) pos++;
+    }
+    ord[pos] = tid;
+    if (blockIdx.x == 0) evW[pos] = wk;
+  }
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int nrow = (int)max((int64_t)0, min(J, r0 + rows_per) - r0);
+  double res = 0;
+  for (int e = tid; e < nrow * rank; e += nthr) {
+    const int64_t i = r0 + e % nrow;
+    const int k = e / nrow;
+    const int col = ord[k];
+    double u = 0, gu = 0;
+    for (int p = 0; p < cols; p++) {
+      const double y = Q[p * ldA + col];
+      u += Bm[i + J * p] * y;
+      gu += GB[i + J * p] * y;
+    }
+    U[i + J * k] = u;
+    if (U2) U2[i + J * k] = u;
+    const double d = gu - u * A[col * ldA + col];
+    res += d * d;
+  }
+  res = block_sum(res, red);
+  if (tid == 0) resp[blockIdx.x] = res;
+  if (blockIdx.x == 0) {
+    for (int b = gridDim.x + tid; b < 64; b += nthr) resp[b] = 0.0;  // (the host adds all 64)
+    double e2 = 0, tr = 0;
+    for (int i = tid; i < np; i += nthr) {
+      e2 += part_e2[i];
+      tr += part_tr[i];
+    }
+    e2 = block_sum(e2, red);
+    tr = block_sum(tr, red);
+    if (tid == 0) {
+      chk[0] = e2;
+      chk[1] = tr;
+    }
+  }
 }
 
 // out[0] = sum a[0..n), out[1] = sum b[0..n)  (the check sums of a counting trial)
@@ -718,94 +925,6 @@ __global__ __launch_bounds__(256) void k_chk_sums(const double *__restrict__ a,
   if (threadIdx.x == 0) {
     out[0] = x;
     out[1] = y;
-  }
-}
-
-// k_rr_tail: Rayleigh-Ritz of G on the orthonormal basis B (J x cols) given GB = G B: H = B^T GB
-// (cols x cols), its eigen-decomposition by the in-LDS Jacobi, eigenvalues sorted descending ->
-// evW[0..cols), U = B Y[:, :rank] and the residual ||G U - U diag(ev)||_F^2 of the leading `rank`
-// pairs -> chk[4]; on the way the partial check sums the sign iteration's last two products left
-// (np each) are added up: chk[0] = ||X_prev^2 - I||_F^2, chk[1] = trace(X).
-// dynamic LDS: A[cols][cols+1] | Q[cols][cols+1] | cs[64] | pq[64 ints] | red[17] | ord[64 ints]
-__global__ __launch_bounds__(1024) void k_rr_tail(const double *__restrict__ Bm,
-                                                  const double *__restrict__ GB, int64_t J, int cols,
-                                                  int rank, const double *__restrict__ part_e2,
-                                                  const double *__restrict__ part_tr, int np,
-                                                  double *__restrict__ U, double *__restrict__ evW,
-                                                  double *__restrict__ chk) {
-  extern __shared__ double lds[];
-  const int ldA = cols + 1;
-  double *A = lds;
-  double *Q = A + cols * ldA;
-  double *cs = Q + cols * ldA;
-  int *pq = (int *)(cs + 64);
-  double *red = (double *)(pq + 64);
-  int *ord = (int *)(red + 17);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int Ji = (int)J;
-  // H = B^T (G B), symmetrised from its upper triangle
-  const int ntri = cols * (cols + 1) / 2;
-  for (int e = wave; e < ntri; e += nw) {
-    int p = 0, rem = e;
-    while (rem >= cols - p) {
-      rem -= cols - p;
-      p++;
-    }
-    const int q = p + rem;
-    const double *a = Bm + J * p, *b = GB + J * q;
-    double s = 0;
-    for (int i = lane; i < Ji; i += 64) s += a[i] * b[i];
-    s = wave_sum(s);
-    if (lane == 0) {
-      A[p * ldA + q] = s;
-      A[q * ldA + p] = s;
-    }
-  }
-  __syncthreads();
-  if (cols <= 32) {  // one wave: wave-level barriers only (rounds of <= 16 rotations x 32 rows)
-    if (wave == 0) jacobi_eig_t<64>(A, Q, cs, pq, cols, nullptr);
-    __syncthreads();
-  } else {
-    jacobi_eig_t<1024>(A, Q, cs, pq, cols, red);
-  }
-  if (tid < cols) {
-    const double wk = A[tid * ldA + tid];
-    int pos = 0;
-    for (int j = 0; j < cols; j++) {
-      const double wj = A[j * ldA + j];
-      if (wj > wk || (wj == wk && j < tid)) pos++;
-    }
-    ord[pos] = tid;
-    evW[pos] = wk;
-  }
-  __syncthreads();
-  // U = B Y, residual of the leading pairs: r_i,k = (GB Y)_ik - U_ik * ev_k
-  double res = 0;
-  for (int e = tid; e < Ji * rank; e += blockDim.x) {
-    const int i = e % Ji, k = e / Ji;
-    const int col = ord[k];
-    double u = 0, gu = 0;
-    for (int p = 0; p < cols; p++) {
-      const double y = Q[p * ldA + col];
-      u += Bm[i + J * p] * y;
-      gu += GB[i + J * p] * y;
-    }
-    U[e] = u;
-    const double d = gu - u * A[col * ldA + col];
-    res += d * d;
-  }
-  res = block_sum(res, red);
-  double e2 = 0, tr = 0;
-  for (int i = tid; i < np; i += blockDim.x) {
-    e2 += part_e2[i];
-    tr += part_tr[i];
-  }
-  e2 = block_sum(e2, red);
-  tr = block_sum(tr, red);
-  if (tid == 0) {
-    chk[0] = e2;
-    chk[1] = tr;
-    chk[4] = res;
   }
 }
 

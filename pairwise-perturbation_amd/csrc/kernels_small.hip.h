@@ -9,6 +9,9 @@
 
 namespace ppals {
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));  // (also in kernels_scan.hip.h)
+
+
 // ------------------------------------------------------------------ RNG (bit-identical to the
 // host generator in ppals_api.cpp and to oracle/ppals_oracle.cpp)
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
@@ -457,8 +460,31 @@ struct PPTerms {
 // block = 16 consecutive x for one r, 256 threads. Both storage orders are read with 16 lanes along
 // the contiguous index (128-byte segments) and every thread keeps 4 independent partial sums, so a
 // block has ~64 loads per thread in flight instead of a dependent chain: the launch is latency.
+// A normal-equation system to prepare on the side: the S and S^-1 of the mode update that FOLLOWS a
+// contraction depend on the other modes' Grams only, which are final before the contraction starts.
+// One extra workgroup of the contraction's launch computes them (Gall == nullptr: none), so the
+// update kernel — one workgroup, a chain of dependent phases — starts with them in hand instead of
+// spending its first 3-8 us on the Hadamard product and the R x R inverse.
+__device__ inline void gram_system_wave(const double *__restrict__ Gall, int N, int mode, int R,
+                                        double lambda, double *__restrict__ S,
+                                        double *__restrict__ Sinv, int force_jacobi, double *lds);
+struct SysArgs {
+  const double *Gall = nullptr;
+  int N = 0, mode = 0;
+  double lambda = 0;
+  double *S = nullptr, *Sinv = nullptr;
+  int force_jacobi = 0;
+};
 __global__ __launch_bounds__(256) void k_pp_correct(const double *__restrict__ M0, int64_t rows,
-                                                    int R, PPTerms tm, double *__restrict__ M) {
+                                                    int R, PPTerms tm, double *__restrict__ M,
+                                                    SysArgs sys) {
+  extern __shared__ double sys_lds[];
+  if (blockIdx.x == gridDim.x - 1 && sys.Gall) {  // (the launcher added this column of blocks)
+    if (blockIdx.y == 0 && threadIdx.x < 64)
+      gram_system_wave(sys.Gall, sys.N, sys.mode, R, sys.lambda, sys.S, sys.Sinv, sys.force_jacobi,
+                       sys_lds);
+    return;
+  }
   __shared__ double part[16][17];
   __shared__ double rowsum[16];
   const int t = threadIdx.x;
@@ -695,6 +721,131 @@ __device__ inline void jacobi_eig_t(double *A, double *Q, double *cs, int *pq, i
   }
   sync();
 }
+// The same eigen-decomposition for a whole workgroup, built for latency: ONE barrier per round.
+//  * a round's R/2 rotations are applied to A and Q in one pass — every element of A' = J^T A J
+//    and Q' = Q J is written from four (two) elements of the previous iterate into a second pair of
+//    buffers (jacobi_eig_t: three passes and three barriers per round, div/mod per element);
+//  * the NEXT round's rotations are computed in the same pass, by the last wave of the workgroup
+//    (which owns no elements): each of its lanes forms the three entries a'_pp, a'_qq, a'_pq of
+//    its next pair from the old buffer with the formula above and leaves (c, s, partner) in the
+//    other half of the rotation tables — so nothing waits for the angles after the barrier.
+// LDS: A0, A1, Q0, Q1 [R][R+1] each | rc[2][64], rs[2][64] doubles | red[17] | partner[2][64] ints.
+// blockDim.x >= 128 (a multiple of 64). Result: *Aout (eigenvalues on its diagonal), *Qout.
+__device__ inline void jacobi_pair(int n2, int rd, int t, int *p, int *q) {
+  int a, b;
+  if (t == 0) {  // round-robin pairing: player n2-1 fixed, the others rotate
+    a = n2 - 1;
+    b = rd % (n2 - 1);
+  } else {
+    a = (rd + t) % (n2 - 1);
+    b = (rd - t + (n2 - 1)) % (n2 - 1);
+  }
+  *p = min(a, b);
+  *q = max(a, b);
+}
+__device__ inline void jacobi_rotation(double app, double aqq, double apq, double *c, double *sn) {
+  *c = 1.0;
+  *sn = 0.0;
+  if (apq != 0.0) {
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    *c = 1.0 / sqrt(t * t + 1.0);
+    *sn = t * *c;
+  }
+}
+__device__ inline void jacobi_eig_block(double *A0, double *A1, double *Q0, double *Q1, int R,
+                                        double *rc, double *rs, int *partner, double *red,
+                                        double **Aout, double **Qout) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nel = nthr - 64;           // threads that own elements
+  const int rt = tid - nel;            // >= 0: lane of the rotation wave
+  const int ldA = R + 1;
+  for (int e = tid; e < R * R; e += nthr) {
+    const int i = e / R, j = e - i * R;
+    Q0[i * ldA + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int n2 = (R + 1) & ~1, npair = n2 / 2;
+  double *A = A0, *An = A1, *Q = Q0, *Qn = Q1;
+  // rotation tables of the pairing (p, q) with the angle (c, sn): coefficient of the PARTNER's
+  // entry is -sn for p and +sn for q  (J[p][p] = J[q][q] = c, J[q][p] = -sn, J[p][q] = sn)
+  auto put = [&](int half, int p, int q, double c, double sn) {
+    int *pt = partner + 64 * half;
+    double *pc = rc + 64 * half, *ps = rs + 64 * half;
+    if (q < R) {
+      pt[p] = q;
+      pt[q] = p;
+      pc[p] = c;
+      pc[q] = c;
+      ps[p] = -sn;
+      ps[q] = sn;
+    } else {  // bye
+      pt[p] = p;
+      pc[p] = 1.0;
+      ps[p] = 0.0;
+    }
+  };
+  for (int sweep = 0; sweep < 40; sweep++) {
+    double off = 0, diag = 0;
+    for (int e = tid; e < R * R; e += nthr) {
+      const int i = e / R, j = e - i * R;
+      const double a = A[i * ldA + j];
+      if (i == j)
+        diag += a * a;
+      else
+        off += a * a;
+    }
+    off = block_sum(off, red);
+    diag = block_sum(diag, red);
+    if (off <= 1e-30 * diag || off == 0.0) break;
+    if (rt >= 0 && rt < npair) {  // rotations of round 0 from the current iterate
+      int p, q;
+      jacobi_pair(n2, 0, rt, &p, &q);
+      double c = 1.0, sn = 0.0;
+      if (q < R) jacobi_rotation(A[p * ldA + p], A[q * ldA + q], A[p * ldA + q], &c, &sn);
+      put(0, p, q, c, sn);
+    }
+    __syncthreads();
+    for (int rd = 0; rd < n2 - 1; rd++) {
+      const int half = rd & 1;
+      const int *pt = partner + 64 * half;
+      const double *pc = rc + 64 * half, *ps = rs + 64 * half;
+      // a'_ij = ci (cj a_ij + sj a_i,pj) + si (cj a_pi,j + sj a_pi,pj)
+      auto rotated = [&](int i, int j) {
+        const int pi = pt[i], pj = pt[j];
+        const double ci = pc[i], si = ps[i], cj = pc[j], sj = ps[j];
+        const double x = cj * A[i * ldA + j] + sj * A[i * ldA + pj];
+        const double y = cj * A[pi * ldA + j] + sj * A[pi * ldA + pj];
+        return ci * x + si * y;
+      };
+      if (rt < 0) {
+        for (int e = tid; e < R * R; e += nel) {
+          const int i = e / R, j = e - i * R;
+          An[i * ldA + j] = rotated(i, j);
+          const int pj = pt[j];
+          Qn[i * ldA + j] = pc[j] * Q[i * ldA + j] + ps[j] * Q[i * ldA + pj];
+        }
+      } else if (rt < npair && rd + 1 < n2 - 1) {  // next round's angles, from the old buffer
+        int p, q;
+        jacobi_pair(n2, rd + 1, rt, &p, &q);
+        double c = 1.0, sn = 0.0;
+        if (q < R) jacobi_rotation(rotated(p, p), rotated(q, q), rotated(p, q), &c, &sn);
+        put(half ^ 1, p, q, c, sn);
+      }
+      __syncthreads();
+      double *t0 = A;
+      A = An;
+      An = t0;
+      t0 = Q;
+      Q = Qn;
+      Qn = t0;
+    }
+  }
+  __syncthreads();
+  *Aout = A;
+  *Qout = Q;
+}
+
 __device__ inline void jacobi_eig_wave(double *A, double *Q, double *cs, int *pq, int R) {
   jacobi_eig_t<64>(A, Q, cs, pq, R, nullptr);
 }
@@ -756,17 +907,15 @@ __device__ inline bool spd_inverse_wave(double *A, double *X, int R, double *Sin
 // S and S^{-1} for one mode, ONE wave (used stand-alone by the sharded path and the parity tests;
 // the single-GPU sweep uses the fused k_cp_mode_update below).
 // dynamic LDS: A[R][R+1], Q[R][R+1], cs[64] doubles, pq[64] ints  (R <= 64)
-__global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ Gall, int N,
-                                                    int mode, int R, double lambda,
-                                                    double *__restrict__ S,
-                                                    double *__restrict__ Sinv, int force_jacobi) {
-  extern __shared__ double lds[];
+__device__ inline void gram_system_wave(const double *__restrict__ Gall, int N, int mode, int R,
+                                        double lambda, double *__restrict__ S,
+                                        double *__restrict__ Sinv, int force_jacobi, double *lds) {
   const int ldA = R + 1;
   double *A = lds;
   double *Q = A + R * ldA;
   double *cs = Q + R * ldA;
   int *pq = (int *)(cs + 64);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   for (int e = lane; e < R * R; e += 64) {
     const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
     S[e] = v;
@@ -781,6 +930,13 @@ __global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ G
     wave_sync();
     jacobi_inverse_wave(A, Q, cs, pq, R, Sinv);
   }
+}
+__global__ __launch_bounds__(64) void k_gram_system(const double *__restrict__ Gall, int N,
+                                                    int mode, int R, double lambda,
+                                                    double *__restrict__ S,
+                                                    double *__restrict__ Sinv, int force_jacobi) {
+  extern __shared__ double lds[];
+  gram_system_wave(Gall, N, mode, R, lambda, S, Sinv, force_jacobi, lds);
 }
 
 // ------------------------------------------------------------------ rank above 64
@@ -1003,13 +1159,35 @@ __global__ __launch_bounds__(1024) void k_cp_update(
 // global memory sees one read of M, W and one write of grad, W — the launch is a chain of
 // dependent phases, so every global round trip removed is ~1-2 us off a ~23 us kernel.
 // extra dynamic LDS with STAGE: sM[rows*R] | sW[rows*R] after the areas listed above.
-template <bool STAGE>
+struct PtrsN {
+  double *p[MAX_ORDER];
+  double *q[MAX_ORDER];
+  double *d[MAX_ORDER];
+  int64_t n[MAX_ORDER];
+};
+// Normalize at the tail of the sweep's LAST mode update (same arithmetic as k_normalize_fused, no
+// cached multi-sweep tensors involved): one launch less per sweep where a launch is 8 % of it.
+struct NormArgs {
+  int on = 0;
+  PtrsN w;             // the N factors (p, n)
+  double *scales = nullptr;
+  double *wsq = nullptr;
+};
+// MF (with STAGE): the two row products — grad = W_old S - M and W = M S^-1, (rows x R)(R x R) —
+// run on the matrix cores out of LDS. As VALU loops they are LDS-bandwidth bound (2 reads per FMA:
+// ~35 of the 69 us of a launch at R = 20, rows = 400); v_mfma_f64_16x16x4_f64 needs two LDS
+// fragments per 1024 multiply-adds. Computed transposed, D'[j][i] = sum_k S[k][j] W[i][k], so that
+// the lanes of a result register run along i: stores to grad / W are 128-byte segments.
+// presolved: S and S^-1 were prepared by the preceding contraction's launch (SysArgs) and are
+// read from S_out / Sinv_out instead of being computed here.
+template <bool STAGE, bool MF = false>
 __global__ __launch_bounds__(1024) void k_cp_mode_update(
     double *__restrict__ Gall, int N, int mode, int R, double lambda, const double *__restrict__ M,
     int64_t ldm, double *W, int64_t ldw, double *__restrict__ grad, int64_t ldg, int64_t rows,
     double *__restrict__ gradsq, const double *__restrict__ Winit, int64_t ldi,
     double *__restrict__ dW, int64_t ldd, double ratio, double *__restrict__ S_out,
-    double *__restrict__ Sinv_out, double *__restrict__ dwsq) {
+    double *__restrict__ Sinv_out, double *__restrict__ dwsq, int presolved = 0,
+    NormArgs nrm = NormArgs()) {
   extern __shared__ double lds[];
   const int ldA = R + 1;
   double *red = lds;
@@ -1025,35 +1203,100 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   const int64_t total = rows * R;
   const int rows_i = (int)rows, total_i = (int)total;  // launcher: rows * R < 2^31 (32-bit index math)
 
-  for (int e = tid; e < R * R; e += blockDim.x) {
-    const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
-    sS[e] = v;
-    A[(e % R) * ldA + e / R] = v;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    bool ok = spd_inverse_wave(A, Q, R, sI);
-    if (!ok) {
-      wave_sync();
-      for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = sS[e];
-      wave_sync();
-      jacobi_inverse_wave(A, Q, cs, pq, R, sI);
-    }
-  } else if (STAGE) {
-    for (int e = tid - 64; e < total_i; e += (int)blockDim.x - 64) {
-      const int i = e % rows_i, j = e / rows_i;
-      sM[e] = M[i + ldm * j];
-      sW[e] = W[i + ldw * j];
-    }
-  }
-  __syncthreads();
-  if (S_out)
+  if (presolved) {
+    // S, S^-1 come from the launch before this one; M and the pre-update W are staged by everybody
     for (int e = tid; e < R * R; e += blockDim.x) {
-      S_out[e] = sS[e];
-      Sinv_out[e] = sI[e];
+      sS[e] = S_out[e];
+      sI[e] = Sinv_out[e];
     }
+    if (STAGE)
+      for (int e = tid; e < total_i; e += (int)blockDim.x) {
+        const int i = e % rows_i, j = e / rows_i;
+        sM[e] = M[i + ldm * j];
+        sW[e] = W[i + ldw * j];
+      }
+    __syncthreads();
+  } else {
+    for (int e = tid; e < R * R; e += blockDim.x) {
+      const double v = hadamard_entry(Gall, N, mode, R, lambda, e);
+      sS[e] = v;
+      A[(e % R) * ldA + e / R] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      bool ok = spd_inverse_wave(A, Q, R, sI);
+      if (!ok) {
+        wave_sync();
+        for (int e = lane; e < R * R; e += 64) A[(e % R) * ldA + e / R] = sS[e];
+        wave_sync();
+        jacobi_inverse_wave(A, Q, cs, pq, R, sI);
+      }
+    } else if (STAGE) {
+      for (int e = tid - 64; e < total_i; e += (int)blockDim.x - 64) {
+        const int i = e % rows_i, j = e / rows_i;
+        sM[e] = M[i + ldm * j];
+        sW[e] = W[i + ldw * j];
+      }
+    }
+    __syncthreads();
+    if (S_out)
+      for (int e = tid; e < R * R; e += blockDim.x) {
+        S_out[e] = sS[e];
+        Sinv_out[e] = sI[e];
+      }
+  }
 
-  double gs = 0;
+  double gs = 0, dd = 0;
+  if constexpr (STAGE && MF) {
+    const int g4 = lane >> 4, l16 = lane & 15;
+    const int nti = (rows_i + 15) / 16, ntj = (R + 15) / 16, ksteps = (R + 3) / 4;
+    const int nwv = (int)blockDim.x >> 6;
+    for (int phase = 0; phase < 2; phase++) {
+      const double *sA = phase == 0 ? sS : sI;   // S or S^-1 (symmetric: [k + R j])
+      const double *sB = phase == 0 ? sW : sM;   // W_old or M (rows x R, ld rows)
+      for (int tle = wave; tle < nti * ntj; tle += nwv) {
+        const int i0 = (tle % nti) * 16, j0 = (tle / nti) * 16;
+        const int ja = j0 + l16, ib = i0 + l16;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < ksteps; ks++) {
+          const int k = 4 * ks + g4;
+          const bool kin = k < R;
+          const double a = (kin && ja < R) ? sA[k + R * ja] : 0.0;
+          const double b = (kin && ib < rows_i) ? sB[ib + rows_i * k] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        // acc[r] = D'[j0 + g4 + 4 r][i0 + l16]
+        if (ib < rows_i) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int j = j0 + g4 + 4 * r;
+            if (j < R) {
+              if (phase == 0) {
+                const double gv = acc[r] - sM[ib + rows_i * j];
+                grad[ib + ldg * j] = gv;
+                gs += gv * gv;
+              } else {
+                double w = acc[r];
+                if (Winit) {
+                  const double wi = Winit[ib + ldi * j];
+                  const double d = ratio * (w - wi);
+                  dW[ib + ldd * j] = d;
+                  dd += d * d;
+                  if (ratio != 1.0) w = wi + d;
+                }
+                W[ib + ldw * j] = w;
+                sW[ib + rows_i * j] = w;  // old W is dead since the barrier below
+              }
+            }
+          }
+        }
+      }
+      if (phase == 0) {
+        gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
+        if (tid == 0) *gradsq = gs;
+      }
+    }
+  } else {
   for (int e = tid; e < total_i; e += (int)blockDim.x) {
     const int i = e % rows_i, j = e / rows_i;
     double acc = 0;
@@ -1068,7 +1311,6 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   }
   gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
   if (tid == 0) *gradsq = gs;
-  double dd = 0;
   for (int e = tid; e < total_i; e += (int)blockDim.x) {
     const int i = e % rows_i, j = e / rows_i;
     double acc = 0;
@@ -1086,6 +1328,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     }
     W[i + ldw * j] = acc;
     if (STAGE) sW[e] = acc;  // old W is dead since the block_sum barrier
+  }
   }
   if (dwsq) {  // ||dW||^2 for the restart test of the PP phase (block-uniform branch)
     dd = block_sum(dd, red);
@@ -1113,15 +1356,44 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       G[q + R * p] = sacc;
     }
   }
+  if constexpr (STAGE) {
+    if (nrm.on) {  // (block-uniform) Normalize, common.cxx:644-689, on all N factors
+      __threadfence();
+      __syncthreads();
+      double *nr = red;  // nrm[N] | fs[N]   (red has 32 doubles)
+      if (tid < N) {
+        double tr = 0;
+        for (int k = 0; k < R; k++) tr += Gall[(int64_t)tid * R * R + k + R * k];
+        nr[tid] = sqrt(tr);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double prod = 1;
+        for (int i = 0; i < N; i++) prod = prod * nr[i];
+        const double c = pow(prod, 1.0 / N);
+        for (int i = 0; i < N; i++) {
+          nr[MAX_ORDER + i] = c / nr[i];
+          nrm.scales[i] = nr[MAX_ORDER + i];
+          if (nrm.wsq) nrm.wsq[2 * i] = (nr[i] * nr[MAX_ORDER + i]) * (nr[i] * nr[MAX_ORDER + i]);
+        }
+      }
+      __syncthreads();
+      for (int i = 0; i < N; i++) {
+        const double f = nr[MAX_ORDER + i];
+        for (int e = tid; e < R * R; e += blockDim.x) Gall[(int64_t)i * R * R + e] *= f * f;
+        double *pw = nrm.w.p[i];
+        if (i == mode) {  // this launch's own factor: from its LDS copy (ld = rows)
+          for (int e = tid; e < total_i; e += (int)blockDim.x)
+            W[(e % rows_i) + ldw * (e / rows_i)] = f * sW[e];
+        } else {
+          for (int64_t e = tid; e < nrm.w.n[i]; e += blockDim.x) pw[e] = f * pw[e];
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ Normalize (K7)
-struct PtrsN {
-  double *p[MAX_ORDER];
-  double *q[MAX_ORDER];
-  double *d[MAX_ORDER];
-  int64_t n[MAX_ORDER];
-};
 // ONE wave: scales[i] = (prod_j ||W_j||)^(1/N) / ||W_i||, with ||W_i||^2 = trace(G_i); the Grams
 // are rescaled in place (G_i *= scales[i]^2) so they stay consistent with the scaled factors.
 __global__ __launch_bounds__(1024) void k_norm_scales(double *__restrict__ Gall, int N, int R,
@@ -1306,21 +1578,24 @@ __global__ __launch_bounds__(256) void k_unfold_gram(const TV *__restrict__ X, i
 // elements: 4 waves shorten the 2.8 ms one wave needs at J = 50 to well under a millisecond),
 // eigenvalues ranked descending. Used for the Tucker eigen-step whenever the mode extent is small
 // (no vendor library involved). dynamic LDS: A[J][J+1] | Q[J][J+1] | cs[64] | pq[64 ints] | red[17]
-__global__ __launch_bounds__(256) void k_top_eig_small(const double *__restrict__ G, int J,
-                                                       int rank, double *__restrict__ U,
-                                                       double *__restrict__ evals) {
+// dynamic LDS (bytes): top_eig_small_lds(J)
+__host__ __device__ inline size_t top_eig_small_lds(int J) {
+  return sizeof(double) * (4 * (size_t)J * (J + 1) + 256 + 17) + sizeof(int) * 128;
+}
+__global__ __launch_bounds__(1024) void k_top_eig_small(const double *__restrict__ G, int J,
+                                                        int rank, double *__restrict__ U,
+                                                        double *__restrict__ evals) {
   extern __shared__ double lds[];
   const int ldA = J + 1;
-  double *A = lds;
-  double *Q = A + J * ldA;
-  double *cs = Q + J * ldA;
-  int *pq = (int *)(cs + 64);
-  double *red = (double *)(pq + 64);
+  double *A0 = lds, *A1 = A0 + J * ldA, *Q0 = A1 + J * ldA, *Q1 = Q0 + J * ldA;
+  double *rc = Q1 + J * ldA, *rs = rc + 128, *red = rs + 128;
+  int *partner = (int *)(red + 17);
   const int tid = threadIdx.x;
-  for (int e = tid; e < J * J; e += 256) A[(e % J) * ldA + e / J] = G[e];
+  for (int e = tid; e < J * J; e += blockDim.x) A0[(e % J) * ldA + e / J] = G[e];
   __syncthreads();
-  jacobi_eig_t<256>(A, Q, cs, pq, J, red);
-  for (int k = tid; k < J; k += 256) {
+  double *A, *Q;
+  jacobi_eig_block(A0, A1, Q0, Q1, J, rc, rs, partner, red, &A, &Q);
+  for (int k = tid; k < J; k += blockDim.x) {
     const double wk = A[k * ldA + k];
     int pos = 0;  // number of eigenvalues that come before k in descending order
     for (int j = 0; j < J; j++) {

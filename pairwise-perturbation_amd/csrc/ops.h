@@ -230,6 +230,18 @@ class Ops {
     gram(W, rows, ldw, R, Gall + (size_t)mode * R * R);
     if (dwsq && Winit) sumsq(dW, rows * R, dwsq);
   }
+  // Hint: the next cp_mode_update will be for `mode` with these arguments, and the Grams of the
+  // other modes are final NOW — a back end may prepare S / S^-1 on the side of the contraction that
+  // is launched next (mttv / pp_correct) instead of at the head of the update launch. Optional.
+  virtual void arm_gram_system(const double * /*Gall*/, int /*N*/, int /*mode*/, int /*R*/,
+                               double /*lambda*/, double * /*S*/, double * /*Sinv*/) {}
+  // Hint: the next cp_mode_update is the last of a sweep and a Normalize of these N full factors
+  // (no cached multi-sweep tensors alive) follows it immediately — a back end may fold it into that
+  // launch. Returns true when it WILL (the caller then skips its normalize call).
+  virtual bool arm_normalize(double *const * /*W*/, const int64_t * /*rows*/, int /*N*/, int /*R*/,
+                             double * /*Gall*/, int /*mode*/, double * /*wsq*/) {
+    return false;
+  }
   // Normalize (common.cxx:680-688) on N full factors using ||W_i||^2 = trace(G_i); rescales the
   // Grams consistently.
   virtual void normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall) = 0;
@@ -269,6 +281,16 @@ class Ops {
   virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
   // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
+
+  // ---- launch graphs: record the launches a piece of host code enqueues instead of running them,
+  // then replay the recording with one call (latency-bound sweeps: nine ~10 us launches). Between
+  // begin and end nothing may allocate, free or synchronise. begin returns false when the back end
+  // cannot record right now (no support, profiling on); end returns nullptr when the recording
+  // failed — the caller then runs the code normally.
+  virtual bool graph_capture_begin() { return false; }
+  virtual void *graph_capture_end() { return nullptr; }
+  virtual void graph_launch(void * /*graph*/) {}
+  virtual void graph_destroy(void * /*graph*/) {}
 
   // profiling of the scan kernels (HIP events on the launch stream)
   virtual void profile_enable(int /*level*/) {}

@@ -339,3 +339,35 @@ def test_eigen_step_wide_tail(pp, tmp_path, monkeypatch, capfd):
     c2.close()
     err = capfd.readouterr().err
     assert "wide tail" in err and "accepted" in err.split("wide tail", 1)[1], err[-2000:]
+
+
+@pytest.mark.parametrize("lens,ranks", [([100, 68, 76], [6, 5, 4]), ([128, 64, 72], [8, 4, 6]),
+                                        ([90, 68, 76], [5, 5, 5])])
+def test_hosvd_gram_syrk_f32(pp, lens, ranks, monkeypatch):
+    """K13 for fp32 tensor storage at a size where the tiled SYRK runs (k_unfold_syrk_f32: upper
+    triangle of 64 x 64 tiles, ragged edges, both unfolding layouts — mode in front / mode behind —
+    and reduction splits): the HOSVD factors as subspaces and ||core|| against the oracle on the
+    SAME fp32-representable values (the products are exact in fp64, so only rounding order differs),
+    and against the round-2 kernel (PPALS_GRAM_SYRK=0). The third shape has no 4-aligned rows and
+    takes the old kernel either way."""
+    V = _decaying_tensor(lens, [min(s, r + 4) for s, r in zip(lens, ranks)], 7, 0.05)
+    V = np.asfortranarray(V.astype(np.float32).astype(np.float64))
+    W_ref, core_ref = O.hosvd(V, ranks)
+    got = []
+    for syrk in ("1", "0"):
+        monkeypatch.setenv("PPALS_GRAM_SYRK", syrk)
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, 0).upload(V)
+        s = pp.Tucker(c2, t, ranks)
+        s.hosvd()
+        W, core = s.get_factors()
+        for a, b, r in zip(W, W_ref, ranks):
+            assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+            assert relerr(proj(a), proj(b)) < 1e-8, (syrk, relerr(proj(a), proj(b)))
+        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-6 * np.linalg.norm(core_ref)
+        got.append(W)
+        s.close()
+        t.close()
+        c2.close()
+    for a, b in zip(*got):
+        assert relerr(proj(a), proj(b)) < 1e-9

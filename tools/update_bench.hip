@@ -20,9 +20,11 @@ using namespace ppals;
     }                                                                           \
   } while (0)
 int main() {
-  CK(hipFuncSetAttribute((const void *)k_cp_mode_update<false>,
+  CK(hipFuncSetAttribute((const void *)k_cp_mode_update<false, false>,
                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-  CK(hipFuncSetAttribute((const void *)k_cp_mode_update<true>,
+  CK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, false>,
+                         hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+  CK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, true>,
                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   for (int cfg = 0; cfg < 2; cfg++) {
     const int R = cfg ? 20 : 10, N = 4;
@@ -46,24 +48,37 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int st = 1; st >= 0; st--)
-      for (int bs : {256, 512, 1024}) {
+    // variants: 0 = no LDS staging, 1 = staged VALU loops (round 2), 2 = staged + the two row
+    // products on the matrix cores, 3 = 2 + S / S^-1 handed in (prepared by the previous launch)
+    for (int var = 3; var >= 0; var--)
+      for (int bs : {512, 1024}) {
         // one launch at a time from pristine inputs (repeating the update on its own output
         // drives the Grams out of range and into the Jacobi fallback): median of 40
         std::vector<float> ts;
         for (int it = 0; it < 40; it++) {
           CK(hipMemcpy(G, hG.data(), sizeof(double) * N * R * R, hipMemcpyHostToDevice));
           CK(hipMemcpy(W, hW.data(), sizeof(double) * rows * R, hipMemcpyHostToDevice));
+          if (var == 3) {  // a valid system in S / Si
+            hipLaunchKernelGGL(k_gram_system, dim3(1), dim3(64),
+                               sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64, 0, G, N,
+                               it % N, R, 0.0, S, Si, 0);
+          }
           CK(hipDeviceSynchronize());
           CK(hipEventRecord(e0, 0));
-          if (st)
-            hipLaunchKernelGGL(k_cp_mode_update<true>, dim3(1), dim3(bs), lds + stage, 0, G, N, it % N, R,
-                               0.0, M, rows, W, rows, grad, rows, rows, gs, (const double *)nullptr,
-                               rows, (double *)nullptr, rows, 1.0, S, Si, (double *)nullptr);
+          if (var >= 2)
+            hipLaunchKernelGGL((k_cp_mode_update<true, true>), dim3(1), dim3(bs), lds + stage, 0, G, N,
+                               it % N, R, 0.0, M, rows, W, rows, grad, rows, rows, gs,
+                               (const double *)nullptr, rows, (double *)nullptr, rows, 1.0, S, Si,
+                               (double *)nullptr, var == 3 ? 1 : 0);
+          else if (var == 1)
+            hipLaunchKernelGGL((k_cp_mode_update<true, false>), dim3(1), dim3(bs), lds + stage, 0, G, N,
+                               it % N, R, 0.0, M, rows, W, rows, grad, rows, rows, gs,
+                               (const double *)nullptr, rows, (double *)nullptr, rows, 1.0, S, Si,
+                               (double *)nullptr, 0);
           else
-            hipLaunchKernelGGL(k_cp_mode_update<false>, dim3(1), dim3(bs), lds, 0, G, N, it % N, R, 0.0,
-                               M, rows, W, rows, grad, rows, rows, gs, (const double *)nullptr, rows,
-                               (double *)nullptr, rows, 1.0, S, Si, (double *)nullptr);
+            hipLaunchKernelGGL((k_cp_mode_update<false, false>), dim3(1), dim3(bs), lds, 0, G, N, it % N, R,
+                               0.0, M, rows, W, rows, grad, rows, rows, gs, (const double *)nullptr, rows,
+                               (double *)nullptr, rows, 1.0, S, Si, (double *)nullptr, 0);
           CK(hipEventRecord(e1, 0));
           CK(hipEventSynchronize(e1));
           CK(hipGetLastError());
@@ -72,9 +87,8 @@ int main() {
           ts.push_back(ms);
         }
         std::sort(ts.begin(), ts.end());
-        const float best = ts[ts.size() / 2] * 200;
-        printf("R=%d rows=%lld stage=%d block=%4d: %.2f us per launch (single launch between events, median)\n", R, (long long)rows,
-               st, bs, best * 1e3 / 200);
+        printf("R=%d rows=%lld variant=%d block=%4d: %.2f us per launch (single launch between events, median)\n",
+               R, (long long)rows, var, bs, ts[ts.size() / 2] * 1e3);
       }
   }
   return 0;
