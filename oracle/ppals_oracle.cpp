@@ -1758,6 +1758,238 @@ int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wfla
   return sweeps == maxsweep + 1 ? 0 : 1;
 }
 
+// ---- the low-rank-update optimizers of the class API -------------------------------------------
+// get_rankR_update_cholesky (common.cxx:768-786) with random == false: gamma = L L^T,
+// X = (M - A gamma) L^-T, X ~ U_r s_r VT_r (leading r singular triplets), VT_r <- VT_r L^-1.
+// Returns Us = U_r diag(s_r) (rows x r) and VT (r x R, row k = k-th right vector): the update of A
+// is Us * VT, and the same pair updates the cached first contraction (update_cached_tensor).
+static void rankR_update_cholesky(int r, i64 rows, int R, const double *M, const double *A,
+                                  const double *gamma, vector<double> &Us, vector<double> &VT) {
+  vector<double> L((size_t)R * R, 0.0);
+  for (int j = 0; j < R; j++) {
+    double d = gamma[j + R * j];
+    for (int k = 0; k < j; k++) d -= L[j + R * k] * L[j + R * k];
+    d = std::sqrt(d);
+    L[j + R * j] = d;
+    for (int i = j + 1; i < R; i++) {
+      double v = gamma[i + R * j];
+      for (int k = 0; k < j; k++) v -= L[i + R * k] * L[j + R * k];
+      L[i + R * j] = v / d;
+    }
+  }
+  // rhs = M - A gamma; X L^T = rhs  (row by row: forward substitution)
+  vector<double> X((size_t)rows * R);
+  for (i64 i = 0; i < rows; i++) {
+    vector<double> rhs(R);
+    for (int j = 0; j < R; j++) {
+      double v = M[i + rows * j];
+      for (int k = 0; k < R; k++) v -= A[i + rows * k] * gamma[k + R * j];
+      rhs[j] = v;
+    }
+    for (int j = 0; j < R; j++) {
+      double v = rhs[j];
+      for (int k = 0; k < j; k++) v -= X[i + rows * k] * L[j + R * k];
+      X[i + rows * j] = v / L[j + R * j];
+    }
+  }
+  vector<double> U((size_t)rows * R), sv(R), Vm((size_t)R * R);
+  jacobi_svd((int)rows, R, X.data(), U.data(), sv.data(), Vm.data());
+  Us.assign((size_t)rows * r, 0.0);
+  VT.assign((size_t)r * R, 0.0);
+  for (int k = 0; k < r; k++) {
+    for (i64 i = 0; i < rows; i++) Us[i + rows * k] = U[i + rows * k] * sv[k];
+    // y L = v_k^T  (row vector): back substitution, L lower triangular
+    vector<double> y(R);
+    for (int j = R - 1; j >= 0; j--) {
+      double v = Vm[j + (size_t)R * k];
+      for (int q = j + 1; q < R; q++) v -= y[q] * L[q + R * j];
+      y[j] = v / L[j + R * j];
+    }
+    for (int j = 0; j < R; j++) VT[k + (size_t)r * j] = y[j];
+  }
+}
+// cached[..., c] += sum_k (V x_left Us[:, k]) * VT[k, c]   (update_cached_tensor,
+// cp_dt_lr_optimizer.cxx:142-168, cp_msdt_lr_optimizer.cxx:117-161)
+static void lr_update_cached(Ten &cached, const Ten &V, int left, const vector<double> &Us, int r,
+                             const vector<double> &VT, int R) {
+  Ten T = ttm_r(V, pos_of(V, left), Us.data(), r);
+  const i64 n = T.nsp();
+  double *c = cached.own.data();
+  for (int col = 0; col < R; col++)
+    for (int k = 0; k < r; k++) {
+      const double w = VT[k + (size_t)r * col];
+      const double *t = T.d + n * k;
+      double *o = c + n * col;
+      for (i64 e = 0; e < n; e++) o[e] += w * t[e];
+    }
+}
+
+// CPD<double, CPDTLROptimizer>::als / CPD<double, CPMSDTLROptimizer>::als (src/CP.cxx:100-186 with
+// cp_dt_lr_optimizer.cxx:170-236, cp_msdt_lr_optimizer.cxx:163-205; run.cxx:401-407 `-pp 2|3`),
+// randomsvd = 0. kind 3: DT with low-rank updates, kind 4: MSDT with low-rank updates.
+int ppo_cpd_als_lr(int N, const int64_t *lens, int R, const double *V, double *Wflat,
+                   double *gradWflat, int kind, int update_rank, double lambda, double tol,
+                   double timelimit, int maxsweep, int resprint, const char *csv_path, int verbose,
+                   double *sweeps_out, int *iters_out) {
+  if ((kind != 3 && kind != 4) || update_rank < 1 || update_rank > R) return -1;
+  Factors F = factors(N, lens, R, Wflat), G = factors(N, lens, R, gradWflat);
+  Ten Vt = view_of(N, lens, V);
+  Log log;
+  log.verbose = verbose != 0;
+  log.open(csv_path);
+  log.header("[dim],[iter],[gradnorm],[tol],[pp_update],[diffV],[dtime]");
+  ClassStep st;
+  st.N = N;
+  st.R = R;
+  st.V = &Vt;
+  st.F = &F;
+  {
+    vector<int> top;
+    for (int i = 0; i < N - 1; i++) top.push_back(i);
+    st.tree.construct_subtree(top);
+  }
+  string topkey;
+  for (int i = 0; i < N - 1; i++) topkey.push_back((char)('a' + i));
+  auto cyclic_after = [&](int left) {
+    vector<int> idx;
+    for (int i = left + 1; i < N; i++) idx.push_back(i);
+    for (int i = 0; i < left; i++) idx.push_back(i);
+    return idx;
+  };
+  vector<double> S((size_t)R * R), Us, VT;  // the latest low-rank update (this->U * s, this->VT)
+  const int r = update_rank;
+  auto exact_update = [&](int mode, const double *Msrc) {
+    vector<double> M(Msrc, Msrc + lens[mode] * R);
+    update_S(F, mode, lambda, S.data());
+    gradient(lens[mode], R, M.data(), F.W[mode], S.data(), G.W[mode]);
+    cholesky_solve(lens[mode], R, M.data(), S.data(), F.W[mode]);
+  };
+  // low-rank update of W[mode] relative to `base` (W itself for DT-LR, old_W for MSDT-LR)
+  auto lr_update = [&](int mode, const double *Msrc, const double *base) {
+    const i64 rows = lens[mode];
+    vector<double> M(Msrc, Msrc + rows * R);
+    update_S(F, mode, lambda, S.data());
+    gradient(rows, R, M.data(), F.W[mode], S.data(), G.W[mode]);
+    vector<double> A(base, base + rows * R);
+    rankR_update_cholesky(r, rows, R, M.data(), A.data(), S.data(), Us, VT);
+    for (int c = 0; c < R; c++)
+      for (i64 i = 0; i < rows; i++) {
+        double v = A[i + rows * c];
+        for (int k = 0; k < r; k++) v += Us[i + rows * k] * VT[k + (size_t)r * c];
+        F.W[mode][i + rows * c] = v;
+      }
+  };
+  // ---- CPDTLROptimizer state (cp_dt_optimizer.cxx:24-37, cp_dt_lr_optimizer.cxx:9-33)
+  bool first_subtree = true, low_rank_decomp = false;
+  int left1 = N - 1, left2 = N - 2, special_index = 0, count_sub = 0;
+  const int num_sub = 5;
+  Ten cached1, cached2;
+  bool have1 = false, have2 = false;
+  // ---- CPMSDTLROptimizer state (cp_msdt_optimizer.cxx:28, cp_msdt_lr_optimizer.cxx:9-27)
+  int msdt_left = N;
+  vector<char> is_cached(N, 0);
+  vector<Ten> cached(N);
+  vector<vector<double>> old_W(N);
+  auto set_top = [&](const Ten &t) {
+    st.cache.clear();
+    st.cache[topkey] = t;
+    Ten &ref = st.cache[topkey];
+    ref.d = ref.own.data();
+  };
+  auto step = [&]() -> double {
+    if (kind == 3) {
+      const int left = first_subtree ? left1 : left2;
+      st.indexes = cyclic_after(left);
+      Ten &cx = first_subtree ? cached1 : cached2;
+      bool &have = first_subtree ? have1 : have2;
+      if (low_rank_decomp && count_sub > 1 && have) {  // mttkrp_map_init, :72-78
+        lr_update_cached(cx, Vt, left, Us, r, VT, R);
+        set_top(cx);
+      } else {
+        st.init(left);
+        cx = st.cache[topkey];
+        cx.d = cx.own.data();
+        have = true;
+      }
+      for (int i = 0; i < N - 1; i++) {
+        if (first_subtree && i < special_index) continue;
+        if (!first_subtree && i > special_index) break;
+        const Ten &Mt = st.node(string(1, (char)('a' + i)));
+        const int mode = st.indexes[i];
+        if (((first_subtree && i == N - 2) || (!first_subtree && i == 0)) && count_sub >= 1) {
+          lr_update(mode, Mt.d, F.W[mode]);
+          low_rank_decomp = true;
+        } else {
+          exact_update(mode, Mt.d);
+        }
+      }
+      if (!first_subtree) count_sub++;
+      if (count_sub == num_sub && !first_subtree) {
+        special_index = (special_index + 1) % (N - 1);
+        count_sub = 0;
+        low_rank_decomp = false;
+        if (special_index != 0) {
+          left1 = (left1 + N - 1) % N;
+          left2 = (left2 + N - 1) % N;
+        } else {
+          left1 = N - 1;
+          left2 = N - 2;
+        }
+      }
+      first_subtree = !first_subtree;
+      return 0.5;
+    }
+    msdt_left = (msdt_left + N - 1) % N;
+    const int left = msdt_left;
+    st.indexes = cyclic_after(left);
+    if (low_rank_decomp && is_cached[left]) {
+      lr_update_cached(cached[left], Vt, left, Us, r, VT, R);
+      old_W[left].assign(F.W[left], F.W[left] + lens[left] * R);
+      set_top(cached[left]);
+    } else {
+      st.init(left);
+      cached[left] = st.cache[topkey];
+      cached[left].d = cached[left].own.data();
+      old_W[left].assign(F.W[left], F.W[left] + lens[left] * R);
+      is_cached[left] = 1;
+    }
+    for (int i = 0; i < N - 1; i++) {
+      const Ten &Mt = st.node(string(1, (char)('a' + i)));
+      const int mode = st.indexes[i];
+      if (!is_cached[mode] || i != N - 2) {
+        exact_update(mode, Mt.d);
+      } else {
+        lr_update(mode, Mt.d, old_W[mode].data());
+        low_rank_decomp = true;
+      }
+    }
+    return 1.0 * (N - 1) / N;
+  };
+  double st_time = now(), sweeps = 0, gradnorm = 0, diffnorm_V = 1000.;
+  int iters = 0;
+  while ((int)sweeps <= maxsweep) {
+    if (iters % resprint == 0 || sweeps >= maxsweep || sweeps == 0) {
+      double st_time1 = now();
+      gradnorm = gradnorm_of(G);
+      diffnorm_V = residual(Vt, F);
+      st_time += now() - st_time1;
+      double dtime = now() - st_time;
+      if (log.has_csv) {
+        log.csv << lens[0] << "," << sweeps << "," << gradnorm << "," << tol << "," << 0 << ","
+                << diffnorm_V << "," << dtime << "\n";
+        if (iters % 100 == 0 && iters != 0) log.csv << std::endl;
+      }
+      if (gradnorm < tol || now() - st_time > timelimit) break;
+    }
+    sweeps += step();
+    iters += 1;
+  }
+  if (log.has_csv) log.csv.close();
+  if (sweeps_out) *sweeps_out = sweeps;
+  if (iters_out) *iters_out = iters;
+  return sweeps == maxsweep + 1 ? 0 : 1;
+}
+
 // the mode order alsCP_PP_partupdate uses (sort_indexes, als_CP.cxx:835-843): descending values
 void ppo_sort_indexes(int n, const double *v, int *idx) {
   vector<int> ord(n);

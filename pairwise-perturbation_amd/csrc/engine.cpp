@@ -340,6 +340,7 @@ CpEngine::~CpEngine() {
   for (auto p : Mm_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
   pp_graph_drop();
+  lr_release();
   pp_clear();
   for (auto &kv : pp_pool_) ops_.free(kv.second.buf);
   ops_.free(pp_norms_);
@@ -937,11 +938,11 @@ void CpEngine::ms_start_step(int first) {
   if ((size_t)L * T * R_ * dtype_size(ms_X_.dt) != xbytes)
     throw std::runtime_error("ppals: internal error (first-level intermediate size)");
   auto launch_scan = [&](int64_t off) {
-    ms_X_.buf = (char *)ms_X_base_ + off;
+    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)ms_X_base_ + off;
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
   };
-  if (slack > 0 && !ms_tuned_[first] && ms_tuning_now_) {
+  if (slack > 0 && !ms_tuned_[first] && ms_tuning_now_ && !ms_X_override_) {
     // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
     // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
     ms_tuned_[first] = true;
@@ -1130,8 +1131,223 @@ void CpEngine::update_modes(int first, int count, double lambda) {
 // and the fractional sweep counter (Simple 1, DT 0.5 [modes 0..N-2 | mode N-1], MSDT (N-1)/N);
 // the ALS iterates are the same cyclic mode updates for all three, computed with this engine's
 // own contraction schedule. No Normalize (src/CP.cxx:171).
+// ---------------------------------------------------------------------------- low-rank updates
+void CpEngine::lr_release() {
+  for (int m = 0; m < MAX_ORDER; m++) {
+    ops_.free(lr_cache_[m]);
+    lr_cache_[m] = nullptr;
+    lr_have_[m] = false;
+  }
+  ops_.free(lr_X_);
+  ops_.free(lr_Us_);
+  ops_.free(lr_G2_);
+  ops_.free(lr_small_);
+  ops_.free(lr_T_);
+  lr_X_ = lr_Us_ = lr_G2_ = lr_small_ = lr_T_ = nullptr;
+  lr_T_cap_ = 0;
+}
+
+// mttkrp_map_init of the LR optimizers (cp_dt_lr_optimizer.cxx:36-94, cp_msdt_lr_optimizer.cxx:
+// 31-75): the step's first contraction X = V x_left W_left in the root's own buffer — computed by
+// one tensor scan, or (reuse) the kept one brought up to date with the rank-r change of W_left
+// that lr_mode_update left in lr_Us_ (rows x r) and lr_small_ (VT, r x R).
+void CpEngine::lr_step_begin(int left, bool reuse, int r) {
+  check_tensor_generation();
+  if (ms_k_ != 1) ms_set_roots(1);
+  if (!lr_cache_[left]) lr_cache_[left] = big_alloc(ms_X_bytes(left, 1));
+  if (reuse && lr_have_[left]) {
+    ScanPlan pl;
+    if (!plan_scan(left, 1, false, pl)) throw std::runtime_error("ppals: internal error (LR scan plan)");
+    const int64_t n = pl.Lc * pl.T;
+    if (lr_T_cap_ < sizeof(double) * (size_t)n * r) {
+      ops_.free(lr_T_);
+      lr_T_ = (double *)ops_.alloc(sizeof(double) * (size_t)n * r);
+      lr_T_cap_ = sizeof(double) * (size_t)n * r;
+    }
+    FactorRef f;
+    f.ptr = lr_Us_ + (left == 0 ? V_.row0 : 0);
+    f.rows = ext(left);
+    f.ld = V_.glens[left];
+    ops_.scan_contract(pl.lay->ptr, V_.dtype, pl.L, ext(left), pl.T, &f, 1, r, lr_T_, F64, pl.Lc, n,
+                       pl.pad);
+    ops_.lowrank_accumulate(lr_cache_[left], V_.dtype, n, R_, lr_T_, r, lr_small_);
+    ms_X_ = lr_desc_[left];
+    ms_X_.buf = lr_cache_[left];
+    ms_X_.valid = true;
+    ms_X_.pending = false;
+    ms_root_ = left;
+    ms_order_.clear();
+    for (int q = 1; q < N_; q++) ms_order_.push_back((left + q) % N_);
+    for (auto &nd : ms_nodes_) nd.t.valid = false;
+  } else {
+    ms_X_override_ = lr_cache_[left];
+    ms_start_step(left);
+    ms_X_override_ = nullptr;
+    lr_desc_[left] = ms_X_;
+    lr_have_[left] = true;
+  }
+}
+
+// One mode update of an LR step. r == 0: the exact update (cholesky_solve in the reference).
+// r > 0: get_rankR_update_cholesky (common.cxx:768-786, random == false) relative to `base`
+// (device, s x R; null: the current W_i): gamma = L L^T, X = (M - base gamma) L^-T, its leading r
+// singular triplets, W_i = base + (U_r s_r)(VT_r L^-1). Leaves Us = U_r s_r in lr_Us_ (s x r) and
+// VT in lr_small_ (r x R) for the next lr_step_begin. The R x R algebra runs on the host.
+void CpEngine::lr_mode_update(int i, double lambda, int r, const double *base) {
+  int pos = -1;
+  for (size_t q = 0; q < ms_order_.size(); q++)
+    if (ms_order_[q] == i) pos = (int)q;
+  if (pos < 0) throw std::runtime_error("ppals: internal error (LR update of the root mode)");
+  const int leaf = ms_leaf_[pos];
+  ms_compute(leaf);
+  const double *M = (const double *)ms_nodes_[leaf].t.buf;
+  const int64_t s = V_.glens[i];
+  if (r <= 0) {
+    mode_update(i, M, ext(i), lambda, false, 1.0);
+    ms_nodes_[leaf].t.valid = false;
+    return;
+  }
+  const size_t nsr = (size_t)s * R_;
+  if (!lr_X_) {
+    lr_X_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+    lr_Us_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+    lr_G2_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
+    lr_small_ = (double *)ops_.alloc(sizeof(double) * 4 * (size_t)R_ * R_);
+  }
+  ops_.gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
+  // the gradient with the CURRENT factor (what [gradnorm] reports), W_new of the exact solve unused
+  ops_.cp_update(M, s, W_[i], s, lr_X_, s, gradW_[i], s, s, R_, S_, Sinv_, gradsq_ + i, nullptr, 0,
+                 nullptr, 0, 1.0);
+  grad_replicated_[i] = true;
+  const double *negrhs = gradW_[i];  // -(M - base gamma)
+  if (base && base != W_[i]) {
+    ops_.cp_update(M, s, base, s, lr_X_, s, lr_G2_, s, s, R_, S_, Sinv_, scal_ + 3 * MAX_ORDER,
+                   nullptr, 0, nullptr, 0, 1.0);
+    negrhs = lr_G2_;
+  } else {
+    base = W_[i];
+  }
+  // host: L = chol(gamma), T1 = -L^-T  (X = negrhs * T1)
+  std::vector<double> Sg((size_t)R_ * R_), L((size_t)R_ * R_, 0.0), Li((size_t)R_ * R_, 0.0),
+      T1((size_t)R_ * R_, 0.0);
+  ops_.d2h(Sg.data(), S_, sizeof(double) * R_ * R_);
+  for (int j = 0; j < R_; j++) {
+    double d = Sg[j + (size_t)R_ * j];
+    for (int k = 0; k < j; k++) d -= L[j + (size_t)R_ * k] * L[j + (size_t)R_ * k];
+    if (!(d > 0)) throw std::runtime_error("ppals: low-rank update: S is not positive definite");
+    d = std::sqrt(d);
+    L[j + (size_t)R_ * j] = d;
+    for (int q = j + 1; q < R_; q++) {
+      double v = Sg[q + (size_t)R_ * j];
+      for (int k = 0; k < j; k++) v -= L[q + (size_t)R_ * k] * L[j + (size_t)R_ * k];
+      L[q + (size_t)R_ * j] = v / d;
+    }
+  }
+  for (int c = 0; c < R_; c++)  // Li = L^-1 (lower), column by column
+    for (int q = c; q < R_; q++) {
+      double v = (q == c) ? 1.0 : 0.0;
+      for (int k = c; k < q; k++) v -= L[q + (size_t)R_ * k] * Li[k + (size_t)R_ * c];
+      Li[q + (size_t)R_ * c] = v / L[q + (size_t)R_ * q];
+    }
+  for (int a = 0; a < R_; a++)
+    for (int b = 0; b < R_; b++) T1[a + (size_t)R_ * b] = -Li[b + (size_t)R_ * a];  // -(L^-1)^T
+  double *dT1 = lr_small_ + (size_t)R_ * R_, *dGX = dT1 + (size_t)R_ * R_, *dV = dGX + (size_t)R_ * R_;
+  ops_.h2d(dT1, T1.data(), sizeof(double) * R_ * R_);
+  ops_.rows_times_small(negrhs, s, R_, dT1, R_, nullptr, lr_X_);    // X = rhs L^-T
+  ops_.gram(lr_X_, s, s, R_, dGX);                                   // X^T X
+  ops_.top_eigvecs(dGX, R_, r, dV);                                  // leading right singular vectors
+  std::vector<double> Vr((size_t)R_ * r), VT((size_t)r * R_, 0.0);
+  ops_.d2h(Vr.data(), dV, sizeof(double) * R_ * r);
+  for (int k = 0; k < r; k++)  // VT[k, :] = v_k^T L^-1
+    for (int c = 0; c < R_; c++) {
+      double v = 0;
+      for (int q = c; q < R_; q++) v += Vr[q + (size_t)R_ * k] * Li[q + (size_t)R_ * c];
+      VT[k + (size_t)r * c] = v;
+    }
+  ops_.h2d(lr_small_, VT.data(), sizeof(double) * r * R_);
+  ops_.rows_times_small(lr_X_, s, R_, dV, r, nullptr, lr_Us_);       // Us = X V_r = U_r s_r
+  ops_.rows_times_small(lr_Us_, s, r, lr_small_, R_, base, W_[i]);   // W = base + Us VT
+  ops_.gram(W_[i], s, s, R_, G_ + (size_t)i * R_ * R_);
+  (void)nsr;
+  ms_nodes_[leaf].t.valid = false;
+}
+
 int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iters_out) {
-  if (kind < 0 || kind > 2) throw std::runtime_error("ppals: unknown class-API optimizer");
+  if (kind < 0 || kind > 4) throw std::runtime_error("ppals: unknown class-API optimizer");
+  const bool lr = kind >= 3;
+  if (lr) {
+    if (dist_) throw std::runtime_error("ppals: the low-rank-update optimizers run on one GPU");
+    if (N_ < 3) throw std::runtime_error("ppals: the low-rank-update optimizers need order >= 3");
+    if (o.update_rank < 1 || o.update_rank > R_)
+      throw std::runtime_error("ppals: update rank must be in [1, R]");
+    for (int m = 0; m < MAX_ORDER; m++) lr_have_[m] = false;
+    for (auto &nd : nodes_) nd.valid = false;
+    ms_invalidate();
+  }
+  // CPDTLROptimizer state (cp_dt_optimizer.cxx:24-37, cp_dt_lr_optimizer.cxx:9-33)
+  bool lr_first = true, lr_low = false;
+  int lr_left1 = N_ - 1, lr_left2 = N_ - 2, lr_special = 0, lr_count = 0;
+  // CPMSDTLROptimizer state (cp_msdt_optimizer.cxx:28, cp_msdt_lr_optimizer.cxx:9-27)
+  int lr_msleft = N_;
+  bool lr_cached[MAX_ORDER] = {false};
+  std::vector<double *> lr_oldW(N_, nullptr);
+  const int ur = o.update_rank;
+  auto lr_step = [&]() -> double {
+    if (kind == 3) {
+      const int left = lr_first ? lr_left1 : lr_left2;
+      lr_step_begin(left, lr_low && lr_count > 1, ur);
+      for (int p = 0; p < N_ - 1; p++) {
+        if (lr_first && p < lr_special) continue;
+        if (!lr_first && p > lr_special) break;
+        const int mode = (left + 1 + p) % N_;
+        if (((lr_first && p == N_ - 2) || (!lr_first && p == 0)) && lr_count >= 1) {
+          lr_mode_update(mode, o.lambda, ur, nullptr);
+          lr_low = true;
+        } else {
+          lr_mode_update(mode, o.lambda, 0, nullptr);
+        }
+      }
+      if (!lr_first) lr_count++;
+      if (lr_count == 5 && !lr_first) {
+        lr_special = (lr_special + 1) % (N_ - 1);
+        lr_count = 0;
+        lr_low = false;
+        if (lr_special != 0) {
+          lr_left1 = (lr_left1 + N_ - 1) % N_;
+          lr_left2 = (lr_left2 + N_ - 1) % N_;
+        } else {
+          lr_left1 = N_ - 1;
+          lr_left2 = N_ - 2;
+        }
+      }
+      lr_first = !lr_first;
+      return 0.5;
+    }
+    lr_msleft = (lr_msleft + N_ - 1) % N_;
+    const int left = lr_msleft;
+    const bool reuse = lr_low && lr_cached[left];
+    lr_step_begin(left, reuse, ur);
+    if (!lr_oldW[left]) lr_oldW[left] = (double *)ops_.alloc(sizeof(double) * V_.glens[left] * R_);
+    ops_.d2d(lr_oldW[left], W_[left], sizeof(double) * V_.glens[left] * R_);
+    lr_cached[left] = true;
+    for (int p = 0; p < N_ - 1; p++) {
+      const int mode = (left + 1 + p) % N_;
+      if (!lr_cached[mode] || p != N_ - 2) {
+        lr_mode_update(mode, o.lambda, 0, nullptr);
+      } else {
+        lr_mode_update(mode, o.lambda, ur, lr_oldW[mode]);
+        lr_low = true;
+      }
+    }
+    return 1.0 * (N_ - 1) / N_;
+  };
+  struct FreeOld {
+    Ops &ops;
+    std::vector<double *> &v;
+    ~FreeOld() {
+      for (auto p : v) ops.free(p);
+    }
+  } free_old{ops_, lr_oldW};
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
   if (rank_ == 0 && !o.csv_path.empty()) {
@@ -1175,6 +1391,13 @@ int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iter
     }
     int count;
     double frac;
+    if (lr) {
+      sweeps += lr_step();
+      grad_from_sweep_ = true;
+      iters += 1;
+      if (iters % 10 == 0 && rank_ == 0 && o.verbose) printf(".");
+      continue;
+    }
     if (kind == 0) {
       count = N_;
       frac = 1.0;

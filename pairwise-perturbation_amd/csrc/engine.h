@@ -58,6 +58,7 @@ struct CpOpts {
   int bench = 0;
   double tol_init = 1e-2, ratio_step = 1.0;
   double update_percentage = 1.0;  // -pp 2: fraction of the modes updated per PP sweep
+  int update_rank = 0;             // class API, low-rank-update optimizers (run.cxx -updaterank)
   std::string csv_path;
   bool csv_append = false;
   bool verbose = false;
@@ -92,6 +93,7 @@ class CpEngine {
   // CPD<dtype,Optimizer>::als, src/CP.cxx:100-186; kind 0 Simple, 1 DT, 2 MSDT optimizer
   int run_class(int kind, const CpOpts &o, double *sweeps, int *iters);
   void update_modes(int first, int count, double lambda);
+
 
   int order() const { return N_; }
   int rank_r() const { return R_; }
@@ -171,6 +173,23 @@ class CpEngine {
   bool ms_tuning_now_ = false;  // placement is measured at session set-up only
   void *big_alloc(size_t bytes);  // gives optional resident layouts back when the device is full
   std::vector<MsNode> ms_nodes_;
+  // ---- low-rank-update optimizers of the class API (CPDTLROptimizer / CPMSDTLROptimizer,
+  // src/optimizer/cp_dt_lr_optimizer.cxx, cp_msdt_lr_optimizer.cxx; randomsvd = 0). The first
+  // contraction of a step, V x_left W_left, is KEPT per root (lr_cache_) and, when W_left has
+  // changed by a rank-r update Us * VT only, brought up to date with r tensor columns instead of
+  // R: cached += (V x_left Us) * VT.
+  void lr_step_begin(int left, bool reuse, int r);
+  void lr_mode_update(int i, double lambda, int r, const double *base);
+  void lr_release();
+  void *lr_cache_[MAX_ORDER] = {nullptr};
+  bool lr_have_[MAX_ORDER] = {false};
+  RTensor lr_desc_[MAX_ORDER];
+  void *ms_X_override_ = nullptr;  // ms_start_step writes the first-level intermediate here
+  double *lr_X_ = nullptr, *lr_Us_ = nullptr, *lr_G2_ = nullptr, *lr_small_ = nullptr;
+  double *lr_T_ = nullptr;
+  size_t lr_T_cap_ = 0;
+
+
   std::vector<int> ms_order_;  // the N-k modes of the step in update order
   std::vector<int> ms_leaf_;   // node index of each list position
   double *ms_scales_ = nullptr;  // one pending-Normalize scalar per cached tensor (<= 32)

@@ -1991,6 +1991,29 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, st_, dst, src, n);
     HIP_CHECK(hipGetLastError());
   }
+  void rows_times_small(const double *A, int64_t rows, int K, const double *B, int C,
+                        const double *D, double *out) override {
+    if ((size_t)K * C * sizeof(double) > 60 * 1024)
+      throw std::runtime_error("ppals: rows_times_small: the small operand does not fit LDS");
+    double *dst = out;
+    if (out == A) dst = (double *)ensure(ws_big2_, ws_big2_sz_, sizeof(double) * (size_t)rows * C);
+    hipLaunchKernelGGL(k_rows_times_small, dim3(grid_for(rows * C, 256)), dim3(256),
+                       sizeof(double) * (size_t)K * C, st_, A, rows, K, B, C, D, dst);
+    HIP_CHECK(hipGetLastError());
+    if (dst != out)
+      HIP_CHECK(hipMemcpyAsync(out, dst, sizeof(double) * rows * C, hipMemcpyDeviceToDevice, st_));
+  }
+  void lowrank_accumulate(void *X, int xdt, int64_t n, int R, const double *T, int r,
+                          const double *VT) override {
+    const size_t lds = sizeof(double) * (size_t)r * R;
+    if (xdt == F32)
+      hipLaunchKernelGGL(k_lowrank_accumulate<float>, dim3(grid_for(n, 256)), dim3(256), lds, st_,
+                         (float *)X, n, R, T, r, VT);
+    else
+      hipLaunchKernelGGL(k_lowrank_accumulate<double>, dim3(grid_for(n, 256)), dim3(256), lds, st_,
+                         (double *)X, n, R, T, r, VT);
+    HIP_CHECK(hipGetLastError());
+  }
   void sumsq(const double *x, int64_t n, double *out) override {
     int g = grid_for(n, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * g);

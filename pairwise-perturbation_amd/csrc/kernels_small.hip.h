@@ -743,14 +743,42 @@ __device__ inline void jacobi_pair(int n2, int rd, int t, int *p, int *q) {
   *p = min(a, b);
   *q = max(a, b);
 }
+// 1 / sqrt(x), x > 0: the hardware estimate + two Newton steps (full fp64 accuracy) — a dozen
+// instructions where an IEEE division or square root is a sequence of ~30
+__device__ inline double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+// The rotation that annihilates a_pq: with d = a_qq - a_pp, h = 2 a_pq, r = sqrt(d^2 + h^2) the
+// SMALLER angle has cos^2 = (1 + |d| / r) / 2 and sin = sign(d) h / (2 r cos) — the same rotation
+// as the textbook t = sign(theta) / (|theta| + sqrt(theta^2 + 1)) form of jacobi_eig_t, computed
+// with two reciprocal square roots instead of two divisions and two square roots (the next round's
+// angles sit on the critical path of every Jacobi round). (c, s) is renormalised to first order, so
+// c^2 + s^2 = 1 to rounding whatever the estimates' last bits are.
 __device__ inline void jacobi_rotation(double app, double aqq, double apq, double *c, double *sn) {
   *c = 1.0;
   *sn = 0.0;
   if (apq != 0.0) {
-    const double theta = (aqq - app) / (2.0 * apq);
-    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-    *c = 1.0 / sqrt(t * t + 1.0);
-    *sn = t * *c;
+    const double d = aqq - app, h = 2.0 * apq;
+    const double r2 = d * d + h * h;
+    // (scaled: the entries of a Gram with a 1e7 x dominant eigenvalue square to 1e15 and beyond)
+    const double inv_r = fast_rsqrt(r2);
+    if (isfinite(inv_r) && inv_r > 0.0) {
+      const double x = 0.5 * (1.0 + fabs(d) * inv_r);       // cos^2 in [1/2, 1]
+      const double ic = fast_rsqrt(x);                       // 1 / cos
+      double cc = x * ic;
+      double ss = (d >= 0 ? 0.5 : -0.5) * h * inv_r * ic;
+      const double corr = 1.5 - 0.5 * (cc * cc + ss * ss);   // first-order renormalisation
+      *c = cc * corr;
+      *sn = ss * corr;
+    } else {  // overflow / underflow of d^2 + h^2: the division form
+      const double theta = d / h;
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      *c = 1.0 / sqrt(t * t + 1.0);
+      *sn = t * *c;
+    }
   }
 }
 __device__ inline void jacobi_eig_block(double *A0, double *A1, double *Q0, double *Q1, int R,
@@ -829,7 +857,21 @@ __device__ inline void jacobi_eig_block(double *A0, double *A1, double *Q0, doub
         int p, q;
         jacobi_pair(n2, rd + 1, rt, &p, &q);
         double c = 1.0, sn = 0.0;
-        if (q < R) jacobi_rotation(rotated(p, p), rotated(q, q), rotated(p, q), &c, &sn);
+        if (q < R) {
+          // a'_pp, a'_qq, a'_pq of THIS round's result in two LDS round trips: the tables of p and
+          // q, then the 3 x 4 entries of the old iterate they combine
+          const int pp_ = pt[p], pq_ = pt[q];
+          const double cp = pc[p], sp = ps[p], cq = pc[q], sq = ps[q];
+          const double a_pp = A[p * ldA + p], a_pP = A[p * ldA + pp_], a_PP = A[pp_ * ldA + pp_];
+          const double a_qq = A[q * ldA + q], a_qQ = A[q * ldA + pq_], a_QQ = A[pq_ * ldA + pq_];
+          const double a_pq = A[p * ldA + q], a_pQ = A[p * ldA + pq_], a_Pq = A[pp_ * ldA + q],
+                       a_PQ = A[pp_ * ldA + pq_];
+          // (A is symmetric: a_Pp = a_pP)
+          const double npp = cp * (cp * a_pp + sp * a_pP) + sp * (cp * a_pP + sp * a_PP);
+          const double nqq = cq * (cq * a_qq + sq * a_qQ) + sq * (cq * a_qQ + sq * a_QQ);
+          const double npq = cp * (cq * a_pq + sq * a_pQ) + sp * (cq * a_Pq + sq * a_PQ);
+          jacobi_rotation(npp, nqq, npq, &c, &sn);
+        }
         put(half ^ 1, p, q, c, sn);
       }
       __syncthreads();
@@ -1634,6 +1676,40 @@ __global__ void k_sign_align(double *__restrict__ W, const double *__restrict__ 
   c = __shfl(c, 0, 64);
   if (!(c > 0))
     for (int64_t j = lane; j < rows; j += 64) w[j] = -w[j];
+}
+
+// out (rows x C) = A (rows x K) * B (K x C) [+ D]; one thread per output element, B in LDS
+__global__ void k_rows_times_small(const double *__restrict__ A, int64_t rows, int K,
+                                   const double *__restrict__ B, int C,
+                                   const double *__restrict__ D, double *__restrict__ out) {
+  extern __shared__ double sB[];
+  for (int e = threadIdx.x; e < K * C; e += blockDim.x) sB[e] = B[e];
+  __syncthreads();
+  const int64_t total = rows * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % rows;
+    const int c = (int)(e / rows);
+    double acc = D ? D[e] : 0.0;
+    for (int k = 0; k < K; k++) acc += A[i + rows * k] * sB[k + K * c];
+    out[e] = acc;
+  }
+}
+// X[e + n*c] += sum_k T[e + n*k] * VT[k + r*c]  (X in TV, T / VT fp64); VT in LDS
+template <typename TV>
+__global__ void k_lowrank_accumulate(TV *__restrict__ X, int64_t n, int R, const double *__restrict__ T,
+                                     int r, const double *__restrict__ VT) {
+  extern __shared__ double sV[];
+  for (int e = threadIdx.x; e < r * R; e += blockDim.x) sV[e] = VT[e];
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    for (int c = 0; c < R; c++) {
+      double acc = (double)X[e + n * c];
+      for (int k = 0; k < r; k++) acc += T[e + n * k] * sV[k + r * c];
+      X[e + n * c] = (TV)acc;
+    }
+  }
 }
 
 __global__ void k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {

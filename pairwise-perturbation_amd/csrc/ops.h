@@ -278,6 +278,16 @@ class Ops {
   // deficient.
   virtual bool orthonormalize(double *U, int64_t rows, int r) = 0;
   virtual void sumsq(const double *x, int64_t n, double *out) = 0;  // *out = sum x^2
+  // ---- low-rank factor updates (class-API optimizers CPDTLR / CPMSDTLR, src/optimizer/) ----
+  // out (rows x C) = A (rows x K) * B (K x C) [+ D (rows x C)]; all column-major fp64, ld = rows
+  // for the tall ones, ld = K for B; D may be null or alias out
+  virtual void rows_times_small(const double *A, int64_t rows, int K, const double *B, int C,
+                                const double *D, double *out) = 0;
+  // X[e + n*c] += sum_k T[e + n*k] * VT[k + r*c], c < R: the cached first contraction updated by a
+  // rank-r change of the contracted factor (update_cached_tensor, cp_dt_lr_optimizer.cxx:142-168);
+  // X is stored in xdt (the tensor's precision), T (n x r) and VT (r x R) are fp64
+  virtual void lowrank_accumulate(void *X, int xdt, int64_t n, int R, const double *T, int r,
+                                  const double *VT) = 0;
   virtual void add_inplace(double *dst, const double *src, int64_t n) = 0;  // dst += src
   // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;

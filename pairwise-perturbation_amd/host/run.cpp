@@ -3,7 +3,9 @@
 // (run.cxx:129-156; -pp is only clamped below, run.cxx:79-85), the same echo block
 // (run.cxx:222-240), and the dispatch of run.cxx:387-414 onto ppals_cpd_als:
 //   -pp 0  CPD<double, CPDTOptimizer>     -pp 1  CPD<double, CPMSDTOptimizer>
-//   -pp 4  CPD<double, CPSimpleOptimizer> -pp 2/3  low-rank update optimizers: not provided
+//   -pp 2  CPD<double, CPDTLROptimizer>   -pp 3  CPD<double, CPMSDTLROptimizer>  (-updaterank;
+//          -randomsvd 1 draws from CTF's generator in the reference and is refused here)
+//   -pp 4  CPD<double, CPSimpleOptimizer>
 // -model Tucker does nothing in the reference (commented out, run.cxx:421-455) and nothing here.
 // Extra flags as in test_ALS: -prec 32|64, -seed N, -device N.
 #include "driver_common.h"
@@ -36,9 +38,15 @@ int main(int argc, char **argv) {
   }
   if (a.resprint == 0) a.resprint = 10;
   if (a.model[0] == 'C' && (a.pp == 2 || a.pp == 3)) {
-    fprintf(stderr, "-pp %d (low-rank update optimizers, src/optimizer/cp_*_lr_optimizer) is not "
-                    "provided by this engine\n", a.pp);
-    return 2;
+    if (randomsvd) {
+      fprintf(stderr, "-randomsvd 1 (randomized_svd, common.cxx:691-708, seeded by CTF's generator) is "
+                      "not reproduced: run with -randomsvd 0\n");
+      return 2;
+    }
+    if (update_rank < 1 || update_rank > a.R) {
+      fprintf(stderr, "-updaterank must be in [1, rank] (got %d, rank %d)\n", update_rank, a.R);
+      return 2;
+    }
   }
 
   ppals_ctx *ctx = nullptr;
@@ -50,7 +58,7 @@ int main(int argc, char **argv) {
   CHECK(ppals_tensor_norm(V, &Vnorm));
   if (a.rank == 0) cout << "Vnorm= " << Vnorm << endl;
 
-  if (a.model[0] == 'C' && (a.pp == 0 || a.pp == 1 || a.pp == 4)) {
+  if (a.model[0] == 'C' && a.pp >= 0 && a.pp <= 4) {
     ppals_cp_opts opt;
     memset(&opt, 0, sizeof(opt));
     opt.tol = a.tol * Vnorm;  // run.cxx:391
@@ -67,10 +75,15 @@ int main(int argc, char **argv) {
     ppals_cp *cp = nullptr;
     CHECK(ppals_cp_create(ctx, V, a.R, &cp));
     CHECK(ppals_cp_set_factors(cp, W.data(), G.data()));
-    const int optimizer = a.pp == 0 ? PPALS_OPT_DT : (a.pp == 1 ? PPALS_OPT_MSDT : PPALS_OPT_SIMPLE);
     double sweeps = 0;
     int iters = 0;
-    CHECK(ppals_cpd_als(cp, optimizer, &opt, &sweeps, &iters));
+    if (a.pp == 2 || a.pp == 3) {
+      CHECK(ppals_cpd_als_lr(cp, a.pp == 2 ? PPALS_OPT_DT_LR : PPALS_OPT_MSDT_LR, update_rank, &opt,
+                             &sweeps, &iters));
+    } else {
+      const int optimizer = a.pp == 0 ? PPALS_OPT_DT : (a.pp == 1 ? PPALS_OPT_MSDT : PPALS_OPT_SIMPLE);
+      CHECK(ppals_cpd_als(cp, optimizer, &opt, &sweeps, &iters));
+    }
     ppals_cp_destroy(cp);
   }
 

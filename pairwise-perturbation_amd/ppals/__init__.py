@@ -49,7 +49,7 @@ EXPORTS = [
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
     "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_cp_pp_partupdate",
-    "ppals_cpd_als", "ppals_cp_set_schedule", "ppals_cp_get_schedule",
+    "ppals_cpd_als", "ppals_cpd_als_lr", "ppals_cp_set_schedule", "ppals_cp_get_schedule",
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_set_core",
@@ -345,6 +345,16 @@ class CP:
         sw = C.c_double(0)
         rc = _check(lib().ppals_cpd_als(self._h, int(optimizer), C.byref(o), C.byref(sw),
                                         C.byref(it)))
+        return rc, sw.value, it.value
+
+    def cpd_als_lr(self, optimizer, update_rank, **kw):
+        """CPD<dtype, CPDTLROptimizer / CPMSDTLROptimizer>::als (optimizer 3 / 4), randomsvd = 0.
+        Returns (rc, sweeps, iters)."""
+        o = _opts(**kw)
+        it = C.c_int(0)
+        sw = C.c_double(0)
+        rc = _check(lib().ppals_cpd_als_lr(self._h, int(optimizer), int(update_rank), C.byref(o),
+                                           C.byref(sw), C.byref(it)))
         return rc, sw.value, it.value
 
     def run_pp_partupdate(self, **kw):

@@ -445,6 +445,26 @@ class HostOps : public Ops {
     for (int64_t i = 0; i < n; i++) s += x[i] * x[i];
     *out = s;
   }
+  void rows_times_small(const double *A, int64_t rows, int K, const double *B, int C,
+                        const double *D, double *out) override {
+    std::vector<double> tmp((size_t)rows * C);
+    for (int c = 0; c < C; c++)
+      for (int64_t i = 0; i < rows; i++) {
+        double v = D ? D[i + rows * c] : 0.0;
+        for (int k = 0; k < K; k++) v += A[i + rows * k] * B[k + (int64_t)K * c];
+        tmp[i + rows * c] = v;
+      }
+    std::copy(tmp.begin(), tmp.end(), out);
+  }
+  void lowrank_accumulate(void *X, int xdt, int64_t n, int R, const double *T, int r,
+                          const double *VT) override {
+    for (int c = 0; c < R; c++)
+      for (int64_t e = 0; e < n; e++) {
+        double v = ld(X, xdt, e + n * c);
+        for (int k = 0; k < r; k++) v += T[e + n * k] * VT[k + (int64_t)r * c];
+        st(X, xdt, e + n * c, v);
+      }
+  }
 };
 
 // communicator driven by callbacks (the tests put torch.distributed/gloo behind them)

@@ -28,6 +28,7 @@ test_cli_defaults_and_silent_resets = D.test_cli_defaults_and_silent_resets
 test_pp_bench_lines = D.test_pp_bench_lines
 test_every_tensor_source_and_pp_mode_runs = D.test_every_tensor_source_and_pp_mode_runs
 test_run_driver_class_api = D.test_run_driver_class_api
+test_run_driver_low_rank_optimizers = D.test_run_driver_low_rank_optimizers
 test_cfg1_cli_matches_oracle = D.test_cfg1_cli_matches_oracle
 test_file_exchange_and_o_path = D.test_file_exchange_and_o_path
 test_o_path_rejects_short_file = D.test_o_path_rejects_short_file

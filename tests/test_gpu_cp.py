@@ -859,3 +859,49 @@ def test_rank_above_64_non_spd_fallback(pp, monkeypatch):
     s.close()
     t.close()
     c2.close()
+
+
+@pytest.mark.parametrize("kind", [3, 4])
+@pytest.mark.parametrize("lens,R,dtype,ur", [([8, 7, 6, 5], 3, 1, 1), ([8, 7, 6, 5], 3, 1, 3),
+                                             ([10, 8, 9], 4, 1, 2), ([6, 5, 4, 5, 4], 2, 1, 1),
+                                             ([12, 10, 9, 11], 5, 0, 2)])
+def test_class_api_low_rank_optimizers(pp, ctx, lens, R, dtype, ur, kind, tmp_path):
+    """CPD<double, CPDTLROptimizer>::als / CPD<double, CPMSDTLROptimizer>::als (run.cxx -pp 2 / 3,
+    -updaterank ur, randomsvd = 0; src/optimizer/cp_dt_lr_optimizer.cxx:170-236,
+    cp_msdt_lr_optimizer.cxx:163-205, get_rankR_update_cholesky common.cxx:768-786): same CSV rows
+    (fractional sweep counter, gradnorm, residual), sweep and step counts and factors as the
+    oracle's restatement; with ur = R the low-rank update IS the exact one, so the run must also
+    reproduce the exact optimizer it derives from (kind 1 / 2)."""
+    V, W = problem(lens, R, 8, "r")
+    G = O.init_factors(lens, R, 99)
+    Vn = np.linalg.norm(V)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    kw = dict(tol=1e-9 * Vn, resprint=1)
+    maxsweep = 12
+    rc_ref, sw_ref, it_ref, W_ref, G_ref = O.cpd_als_lr(V, W, G, kind, ur, maxsweep=maxsweep,
+                                                        csv=c_ref, **kw)
+    t = pp.Tensor(ctx, lens, dtype).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_factors(W, G)
+    rc, sw, it = s.cpd_als_lr(kind, ur, maxiter=maxsweep, csv=c_got, **kw)
+    assert (rc, it) == (rc_ref, it_ref) and abs(sw - sw_ref) < 1e-12
+    ftol = FTOL[dtype] * 10
+    W_got, G_got = s.get_factors(with_grad=True)
+    for a, b in zip(W_got, W_ref):
+        assert relerr(a, b) < ftol, relerr(a, b)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert len(r1) == len(r2)
+    for a, b in zip(r1, r2):
+        assert abs(a[1] - b[1]) < 1e-5                      # [sweeps] (6 digits in the file)
+        assert abs(a[2] - b[2]) < 200 * ftol * (abs(a[2]) + 1e-9 * Vn)
+        assert abs(a[5] - b[5]) < 200 * ftol * Vn
+    if ur == R and dtype == 1:
+        s.set_factors(W, G)
+        s.cpd_als(kind - 2, maxiter=maxsweep, **kw)
+        for a, b in zip(s.get_factors(), W_got):
+            assert relerr(a, b) < 1e-7, relerr(a, b)
+    with pytest.raises(pp.PpalsError):
+        s.cpd_als_lr(kind, R + 1, maxiter=2)
+    s.close()
+    t.close()
