@@ -231,6 +231,18 @@ def _median(x):
     return x[len(x) // 2] if x else None
 
 
+def _replayed_traffic(key):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json): replayed, not observed in this run"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ent = pm.get(key)
+        ks = {k: v for k, v in ent.items() if k.startswith("k_scan")}
+        return sum(v["fetch_bytes"] + v["write_bytes"] for v in ks.values()) / len(ks)
+    except Exception:
+        return None
+
+
 def cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir):
     """BASELINE configs[2]: `-pp 1` against `-pp 0` on the resident cfg2 tensor, measured the way
     the reference measures it — the [dtime] column of alsCP_DT / alsCP_PP (print blocks excluded,
@@ -512,6 +524,9 @@ def main():
         cp64 = ppals.CP(ctx, V64, R)
         r = measure(cp64, sub_steps, 2)
         r["dtype"] = "f64"
+        if "roofline" in r:
+            r["roofline"]["traffic"] = None
+            r["roofline"]["traffic_replayed"] = _replayed_traffic("cp4_s200_r10/f64/1")
         r["sweep_flops"] = sweep_flops(lens, R, cp64.schedule)
         r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
         sub[f"{cp64.schedule}_schedule_f64"] = r
@@ -540,6 +555,8 @@ def main():
             r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
             if "roofline" in r:
                 r["roofline"]["kernel"] = "k_scan_suffix_fast<float,2,1> (two n-tiles)"
+                r["roofline"]["traffic"] = None
+                r["roofline"]["traffic_replayed"] = _replayed_traffic("cp4_s400_r20/f32/1")
             sub["cfg4_1gpu"] = r
             cp4.close()
             V4.close()

@@ -104,6 +104,9 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_apply,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_LAZY")) eig_lazy_ok_ = atoi(v);
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_small,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   }
@@ -130,9 +133,11 @@ class HipOps : public Ops {
     for (auto &kv : eig_state_) {
       if (kv.second.Q) hipFree(kv.second.Q);
       if (kv.second.Qn) hipFree(kv.second.Qn);
+      free_lazy(kv.second);
     }
     for (auto &kv : eig_small_)
       if (kv.second.Q) hipFree(kv.second.Q);
+    if (st2_) hipStreamDestroy(st2_);
     hipStreamDestroy(st_);
   }
 
@@ -1125,6 +1130,16 @@ class HipOps : public Ops {
     double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, largest eigenvalue
     double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
     double head = 4.0;    // head room of the spectral-bound scale (projector_step, fused form)
+    // lazy Rayleigh-Ritz (eig_lazy): the Jacobi of H runs on the second stream
+    bool lazy = false;          // the session allows it for this slot
+    bool lazy_pending = false;  // eigenvalues of the last step still to be read (evd)
+    bool rot_pending = false;   // the caller has not applied Y yet
+    int lazy_m = 0;
+    bool lazy_strict = false;
+    bool jacobi_launched = false;
+    double *Hd = nullptr, *Yd = nullptr, *evd = nullptr;  // 64*64, 64*64, 64 (device)
+    double *ev_pinned = nullptr;  // 64 doubles of pinned host memory the Jacobi writes directly
+    hipEvent_t ev_h = nullptr, ev_done = nullptr;
     double *Q = nullptr;                  // previous basis (J x rank)
     double *Qn = nullptr;                 // spare buffer of the same size (the step's result lands here)
     double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
@@ -1296,6 +1311,8 @@ class HipOps : public Ops {
       return;
     }
     EigState &es = eig_state_[slot];
+    resolve_lazy(es);
+    es.rot_pending = false;  // (whatever rotation was owed belonged to the factor this call replaces)
     if (es.valid && (es.J != J || es.rank != rank)) es.valid = false;
     if (es.valid && projector_step(es, G, J, rank, U, slot, false)) return;
     if (es.valid && eig_fused_) {  // the spectral bound may have been outrun: once more on the measured norm
@@ -1326,6 +1343,75 @@ class HipOps : public Ops {
   // here and gives it back when it ends, so sessions that alternate on one context (or the thin
   // c x c route and its s x s fallback inside one factor update, which use different slots of the
   // block) never see each other's bases, gaps or eigenvalue scales.
+  void free_lazy(EigState &es) {
+    if (es.Hd) hipFree(es.Hd);
+    if (es.Yd) hipFree(es.Yd);
+    if (es.evd) hipFree(es.evd);
+    if (es.ev_pinned) hipHostFree(es.ev_pinned);
+    es.ev_pinned = nullptr;
+    if (es.ev_h) hipEventDestroy(es.ev_h);
+    if (es.ev_done) hipEventDestroy(es.ev_done);
+    es.Hd = es.Yd = es.evd = nullptr;
+    es.ev_h = es.ev_done = nullptr;
+  }
+  // second stream, events and the slot's buffers: set up when a session ASKS for lazy steps (its
+  // set-up), not inside the first timed sweep
+  void lazy_prepare(EigState &es) {
+    if (!st2_) HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+    if (!es.Hd) {
+      HIP_CHECK(hipMalloc(&es.Hd, sizeof(double) * 64 * 64));
+      HIP_CHECK(hipMalloc(&es.Yd, sizeof(double) * 64 * 64));
+      HIP_CHECK(hipMalloc(&es.evd, sizeof(double) * 64));
+      HIP_CHECK(hipHostMalloc(&es.ev_pinned, sizeof(double) * 64, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&es.ev_h, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&es.ev_done, hipEventDisableTiming));
+    }
+  }
+  void eig_lazy(int slot, bool on) override {
+    if (slot < 0) return;
+    EigState &es = eig_state_[slot];
+    es.lazy = on && eig_lazy_ok_ && eig_fused_;
+    if (es.lazy) lazy_prepare(es);
+  }
+  const double *eig_pending_rotation(int slot) override {
+    auto it = eig_state_.find(slot);
+    if (it == eig_state_.end() || !it->second.rot_pending) return nullptr;
+    HIP_CHECK(hipEventSynchronize(it->second.ev_done));
+    // (the rotation is read by launches on the main stream: order them behind the Jacobi)
+    HIP_CHECK(hipStreamWaitEvent(st_, it->second.ev_done, 0));
+    return it->second.Yd;
+  }
+  void eig_rotation_done(int slot) override {
+    auto it = eig_state_.find(slot);
+    if (it != eig_state_.end()) it->second.rot_pending = false;
+  }
+  // the eigenvalues a lazy step left on the second stream become the slot's state (what the
+  // accepted branch of projector_step does at once when the Jacobi runs inside the step)
+  void resolve_lazy(EigState &es) {
+    if (!es.lazy_pending) return;
+    es.lazy_pending = false;
+    double evn[64];
+    // (the Jacobi wrote them into pinned host memory itself: waiting for ITS event is all it takes —
+    // a copy would queue behind the other slots' Jacobis on the second stream, or drain the main one)
+    HIP_CHECK(hipEventSynchronize(es.ev_done));
+    for (int d = 0; d < es.rank; d++) evn[d] = es.ev_pinned[d];
+    const int rank = es.rank, m = es.lazy_m;
+    bool sane = true;
+    for (int d = 0; d < rank; d++) sane = sane && std::isfinite(evn[d]);
+    if (!sane) {
+      es.valid = false;
+      return;
+    }
+    const int mi = std::min(m, rank - 1);
+    const double growth = es.evh[mi] > 0 ? evn[mi] / es.evh[mi] : 2.0;
+    es.head = std::min(8.0, std::max(1.25, 1.25 * growth * growth));
+    for (int d = 0; d < rank; d++) es.evh[d] = evn[d];
+    const double shift = evn[rank - 1] - es.lamR;
+    es.lamR = evn[rank - 1];
+    es.lamR1 = std::min(std::max(0.0, es.lamR1 + shift), es.lamR);
+    if (es.lazy_strict) es.lamR1 = std::min(es.lamR1, es.lamR * (1 - 1e-6));
+    if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;
+  }
   int eig_session_new() override {
     eig_next_base_ += 64;
     return eig_next_base_;
@@ -1336,6 +1422,7 @@ class HipOps : public Ops {
       if (it->first >= base && it->first < base + 64) {
         if (it->second.Q) hipFree(it->second.Q);
         if (it->second.Qn) hipFree(it->second.Qn);
+        free_lazy(it->second);
         it = eig_state_.erase(it);
       } else {
         ++it;
@@ -1361,7 +1448,7 @@ class HipOps : public Ops {
                            const double *Omega, const double *QD, int m, double *Z, double *Z2,
                            double *GZ, double *C, double *H, double *Uout, double *evW, double *chk,
                            int *status, const double *pe2, const double *ptr_, int np, int rounds = 1,
-                           double *Uout2 = nullptr) {
+                           double *Uout2 = nullptr, EigState *lazy = nullptr) {
     const int Ji = (int)J;
     gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
     const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
@@ -1383,6 +1470,27 @@ class HipOps : public Ops {
     gemm_nn(G, J, B, J, nullptr, 0, GB, J, Ji, cols, Ji, 1.0, 0.0);
     hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H);
     double *resp = chk + 16 + 64 + 4 + 64;
+    if (lazy) {
+      // the basis itself goes out, checked as a subspace; the Jacobi of H moves to the second stream
+      EigState &es = *lazy;
+      lazy_prepare(es);
+      // (H is copied for the Jacobi: the workspace copy is overwritten by the next step; a Jacobi
+      // of this slot that is still in flight — a step that was not accepted — must be through with
+      // the buffers first)
+      if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
+      es.jacobi_launched = true;
+      HIP_CHECK(hipMemcpyAsync(es.Hd, H, sizeof(double) * cols * cols, hipMemcpyDeviceToDevice, st_));
+      HIP_CHECK(hipEventRecord(es.ev_h, st_));
+      HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
+      const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
+      hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
+                         es.Hd, cols, es.Yd, es.evd, es.ev_pinned);
+      HIP_CHECK(hipEventRecord(es.ev_done, st2_));
+      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
+                         sizeof(double) * ((size_t)cols * cols + 17 + 128), st_, B, GB, J, cols, H, rows_per,
+                         pe2, ptr_, np, Uout, Uout2, chk, resp);
+      return;
+    }
     // (two elements of H per thread + the wave that prepares the next Jacobi round's angles)
     const int nthr_rr = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
     hipLaunchKernelGGL(k_rr_apply, dim3(nblk), dim3(nthr_rr), top_eig_small_lds(cols) + sizeof(int) * 64, st_, B,
@@ -1559,11 +1667,15 @@ class HipOps : public Ops {
       // `tail(cols, Omega, Uout)`: basis of `cols` columns = P applied to Omega (J x cols), Cholesky
       // QR, Rayleigh-Ritz on cols x cols; the leading `rank` eigenvectors land in Uout (ld J), their
       // residual in chk[4], all `cols` eigenvalues in evW; then the one read-back of the step
+      bool lazy_used = false;
       auto tail = [&](int cols, const double *Omega, double *Uout, int npass) {
         if (fused_tail) {
           // (the leading eigenvectors also go to the slot's spare basis buffer: accepted = a swap)
+          const bool lazy_now = es.lazy && cols == rank && Uout == U && npass == 1;
+          lazy_used = lazy_now;
           fused_tail_launches(G, X, J, cols, rank, Omega, QD, m, Z, Z2, GZ, C, H, Uout, evW, chk, status,
-                              pe2, ptr_, (int)ntri, npass, Uout == U ? es.Qn : nullptr);
+                              pe2, ptr_, (int)ntri, npass, Uout == U ? es.Qn : nullptr,
+                              lazy_now ? &es : nullptr);
           if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
           HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
           HIP_CHECK(hipStreamSynchronize(st_));
@@ -1612,8 +1724,11 @@ class HipOps : public Ops {
       // (from THIS step's quantities only: trace(P) == rank says that exactly `rank` eigenvalues
       // lie above this step's shift, so the gap below the rank-th one is at least its distance to
       // the shift; the slot's previous gap / eigenvalue scale only scheduled the iteration)
-      const double gap_now = std::max(0.0, evn[rank - 1] - sigma);
-      const double res_tol = (strict ? 1e-13 * evn[0] : std::max(1e-9 * gap_now, 1e-14 * evn[0])) *
+      // (lazy tail: the Jacobi has not run yet — Gershgorin bounds of H's spectrum stand in for
+      // the smallest / largest eigenvalue of the subspace, and the residual is the subspace's)
+      const double ev_lo = lazy_used ? hc[5] : evn[rank - 1], ev_hi = lazy_used ? hc[6] : evn[0];
+      const double gap_now = std::max(0.0, ev_lo - sigma);
+      const double res_tol = (strict ? 1e-13 * ev_hi : std::max(1e-9 * gap_now, 1e-14 * ev_hi)) *
                              std::sqrt((double)rank);
       const bool chol_ok = hs[0] == 0;
       const bool good = converged && std::fabs(cnt - rank) < 1e-6 && chol_ok && hs[2] != 1 && hs[3] == 0 &&
@@ -1625,6 +1740,22 @@ class HipOps : public Ops {
                 slot, (long long)J, rank, es.lamR, es.lamR1, m, rho, rho_now, ell0, iters, hc[0], cnt,
                 res, gap_now, hs[0], hs[1], hs[2], hs[3],
                 good ? "accepted" : (converged ? "not accepted as it is" : "more steps"), es.fast, es.full);
+      if (good && lazy_used) {
+        // the eigenvalues arrive with the second stream's Jacobi: resolve_lazy() turns them into
+        // the slot's state when the slot is used next; U holds the basis, Y is owed to the caller
+        es.lazy_pending = true;
+        es.rot_pending = true;
+        es.lazy_m = m;
+        es.lazy_strict = strict;
+        es.rho_frob = rho_now;
+        std::swap(es.Q, es.Qn);
+        es.fast++;
+        return true;
+      }
+      if (lazy_used) {
+        // not accepted: the Jacobi on the second stream is of no use (its buffers are the slot's own)
+        lazy_used = false;
+      }
       if (good) {
         {
           const int mi = std::min(m, rank - 1);
@@ -2156,6 +2287,8 @@ class HipOps : public Ops {
   void *ws_eig_ = nullptr, *ws_orth_ = nullptr, *ws_pow_ = nullptr, *ws_part2_ = nullptr;
   size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;
   hipStream_t st_ = nullptr;
+  hipStream_t st2_ = nullptr;  // the Jacobi of a lazy eigen-step (created on first use)
+  int eig_lazy_ok_ = 1;        // PPALS_EIG_LAZY=0: eigenvectors always inside the step (A/B, tests)
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;
   size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0,

@@ -910,6 +910,118 @@ __global__ __launch_bounds__(1024) void k_rr_apply(const double *__restrict__ Bm
   }
 }
 
+// ---- the tail WITHOUT the eigen-decomposition on the critical path (plain HOOI sweeps) ----------
+// What the sweep needs from an eigen-step is the invariant SUBSPACE: every later contraction, the
+// core's norm and the convergence measure depend on W_i W_i^T only. So the step hands out the
+// orthonormal basis B itself and checks it as a subspace, ||G B - B H||_F with H = B^T G B, while
+// the Jacobi of H (70 us in one workgroup) runs on a second stream beside the next mode's tensor
+// scans; its rotation Y is applied when somebody asks for the factors (eigenvectors one by one,
+// sorted, as the reference returns them) and its eigenvalues schedule the slot's next step.
+//
+// k_sub_residual: every workgroup loads H and forms, for its rows, r = G B - B H (-> resp[block])
+// and copies B into U (and U2). Workgroup 0 adds up the sign iteration's check sums and leaves
+// Gershgorin bounds of H's spectrum: chk[5] <= lambda_min(H), chk[6] >= lambda_max(H).
+__global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__ Bm,
+                                                      const double *__restrict__ GB, int64_t J, int cols,
+                                                      const double *__restrict__ H, int rows_per,
+                                                      const double *__restrict__ part_e2,
+                                                      const double *__restrict__ part_tr, int np,
+                                                      double *__restrict__ U, double *__restrict__ U2,
+                                                      double *__restrict__ chk,
+                                                      double *__restrict__ resp) {
+  extern __shared__ double sH[];  // cols x cols | red[17] | lo[64] | hi[64]
+  double *red = sH + cols * cols;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int e = tid; e < cols * cols; e += nthr) {
+    const int i = e % cols, j = e / cols;
+    sH[e] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
+  }
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int nrow = (int)max((int64_t)0, min(J, r0 + rows_per) - r0);
+  double res = 0;
+  for (int e = tid; e < nrow * cols; e += nthr) {
+    const int64_t i = r0 + e % nrow;
+    const int k = e / nrow;
+    double bh = 0;
+    for (int p = 0; p < cols; p++) bh += Bm[i + J * p] * sH[p + cols * k];
+    const double b = Bm[i + J * k];
+    U[i + J * k] = b;
+    if (U2) U2[i + J * k] = b;
+    const double d = GB[i + J * k] - bh;
+    res += d * d;
+  }
+  res = block_sum(res, red);
+  if (tid == 0) resp[blockIdx.x] = res;
+  if (blockIdx.x == 0) {
+    for (int b = gridDim.x + tid; b < 64; b += nthr) resp[b] = 0.0;
+    double e2 = 0, tr = 0;
+    for (int i = tid; i < np; i += nthr) {
+      e2 += part_e2[i];
+      tr += part_tr[i];
+    }
+    e2 = block_sum(e2, red);
+    tr = block_sum(tr, red);
+    double *lo = red + 17, *hi = lo + 64;
+    if (tid < cols) {
+      double off = 0;
+      for (int j = 0; j < cols; j++)
+        if (j != tid) off += fabs(sH[tid + cols * j]);
+      lo[tid] = sH[tid + cols * tid] - off;
+      hi[tid] = sH[tid + cols * tid] + off;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double l = lo[0], h = hi[0];
+      for (int i = 1; i < cols; i++) {
+        l = fmin(l, lo[i]);
+        h = fmax(h, hi[i]);
+      }
+      chk[0] = e2;
+      chk[1] = tr;
+      chk[5] = l;
+      chk[6] = h;
+    }
+  }
+}
+// k_rr_small (ONE workgroup, second stream): eigen-decomposition of H; Y (cols x cols, column k =
+// the eigenvector of the k-th largest eigenvalue) and the eigenvalues, descending.
+// dynamic LDS: top_eig_small_lds(cols) + 64 ints
+__global__ __launch_bounds__(1024) void k_rr_small(const double *__restrict__ H, int cols,
+                                                   double *__restrict__ Y, double *__restrict__ ev,
+                                                   double *__restrict__ ev_host) {
+  extern __shared__ double lds[];
+  const int ldA = cols + 1;
+  double *A0 = lds, *A1 = A0 + cols * ldA, *Q0 = A1 + cols * ldA, *Q1 = Q0 + cols * ldA;
+  double *rc = Q1 + cols * ldA, *rs = rc + 128, *red = rs + 128;
+  int *partner = (int *)(red + 17);
+  int *ord = partner + 128;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int e = tid; e < cols * cols; e += nthr) {
+    const int i = e % cols, j = e / cols;
+    A0[i * ldA + j] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
+  }
+  __syncthreads();
+  double *A, *Q;
+  jacobi_eig_block(A0, A1, Q0, Q1, cols, rc, rs, partner, red, &A, &Q);
+  if (tid < cols) {
+    const double wk = A[tid * ldA + tid];
+    int pos = 0;
+    for (int j = 0; j < cols; j++) {
+      const double wj = A[j * ldA + j];
+      if (wj > wk || (wj == wk && j < tid)) pos++;
+    }
+    ord[pos] = tid;
+    ev[pos] = wk;
+    if (ev_host) ev_host[pos] = wk;  // (pinned host memory: the host reads it after the event)
+  }
+  __syncthreads();
+  for (int e = tid; e < cols * cols; e += nthr) {
+    const int p = e % cols, k = e / cols;
+    Y[p + cols * k] = Q[p * ldA + ord[k]];
+  }
+}
+
 // out[0] = sum a[0..n), out[1] = sum b[0..n)  (the check sums of a counting trial)
 __global__ __launch_bounds__(256) void k_chk_sums(const double *__restrict__ a,
                                                   const double *__restrict__ b, int n,

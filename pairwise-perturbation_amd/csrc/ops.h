@@ -268,6 +268,16 @@ class Ops {
   virtual void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int /*slot*/) {
     top_eigvecs(G, J, rank, U);
   }
+  // Lazy eigenvectors. With eig_lazy(slot, true) a warm top_eigvecs_warm may return ANY orthonormal
+  // basis of the invariant subspace (all a HOOI sweep needs) and finish the eigen-decomposition
+  // inside the subspace off the critical path; eig_pending_rotation(slot) then returns the
+  // rank x rank matrix Y (device, column-major, columns sorted by descending eigenvalue) with
+  // U_eigenvectors = U_returned * Y — nullptr when U already holds the eigenvectors. The caller
+  // applies Y (to the factor and to whatever it derived from it) when it needs eigenvectors and
+  // says so with eig_rotation_done(slot).
+  virtual void eig_lazy(int /*slot*/, bool /*on*/) {}
+  virtual const double *eig_pending_rotation(int /*slot*/) { return nullptr; }
+  virtual void eig_rotation_done(int /*slot*/) {}
   // A session's block of 64 warm-start slots [base, base + 64) (what a back end remembers under a
   // slot dies with the session that drew the block)
   virtual int eig_session_new() { return 0; }

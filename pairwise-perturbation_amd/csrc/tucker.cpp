@@ -32,6 +32,10 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   dist_ = P_ > 1 || (force_comm_path() && !comm.is_self());
   rank_ = comm.rank();
   eig_base_ = ops_.eig_session_new();  // this session's warm-start slots: base + {i, 8 + i, 16 + i}
+  // (the back end sets up what lazy eigen-steps need now, not inside the first sweep)
+  if (!dist_)
+    for (int i = 0; i < N_ && i < MAX_ORDER; i++)
+      if (V_.glens[i] > 64) ops_.eig_lazy(eig_base_ + i, true);
   int64_t maxs = 0;
   for (int i = 0; i < N_; i++) {
     if (ranks[i] <= 0 || ranks[i] > V_.glens[i])
@@ -358,7 +362,33 @@ void TuckerEngine::compute_core_full() {
   ops_.d2d(core_, Y, sizeof(double) * ncore_);
 }
 
+// Eigenvectors on demand. A plain HOOI sweep lets the back end return ANY orthonormal basis of a
+// mode's subspace (Ops::eig_lazy): the contractions, ||core|| and the convergence measure depend on
+// W_i W_i^T only. Whoever needs the eigenvectors one by one, sorted — the caller reading the
+// factors, the PP phases that difference them — asks here: W_i <- W_i Y_i, core <- core x_i Y_i.
+void TuckerEngine::finalize_rotations() {
+  for (int i = 0; i < N_; i++) {
+    const double *Y = ops_.eig_pending_rotation(eig_base_ + i);
+    if (!Y) continue;
+    const int r = r_[i];
+    ops_.rows_times_small(W_[i], V_.glens[i], r, Y, r, nullptr, W_[i]);
+    int64_t L = 1, T = 1;
+    for (int q = 0; q < i; q++) L *= r_[q];
+    for (int q = i + 1; q < N_; q++) T *= r_[q];
+    double *tmp = (double *)ops_.alloc(sizeof(double) * ncore_);
+    ops_.ttm_keep(core_, F64, L, r, T, Y, r, r, tmp);
+    ops_.d2d(core_, tmp, sizeof(double) * ncore_);
+    ops_.sync();
+    ops_.free(tmp);
+    ops_.eig_rotation_done(eig_base_ + i);
+  }
+}
+void TuckerEngine::drop_rotations() {
+  for (int i = 0; i < N_; i++) ops_.eig_rotation_done(eig_base_ + i);
+}
+
 void TuckerEngine::set_factors(const double *Wflat) {
+  drop_rotations();  // (they belonged to the factors being replaced)
   const double *w = Wflat;
   for (int i = 0; i < N_; i++) {
     size_t n = (size_t)V_.glens[i] * r_[i];
@@ -369,12 +399,14 @@ void TuckerEngine::set_factors(const double *Wflat) {
 // core == nullptr: core = V x_i W_i^T from the current factors (TTMc(core, V, W, -1)); the value
 // becomes the `core` argument (and the initial core_prev) of the next alsTucker_DT / _PP call
 void TuckerEngine::set_core(const double *core) {
+  finalize_rotations();
   if (core)
     ops_.h2d(core_, core, sizeof(double) * ncore_);
   else
     compute_core_full();
 }
 void TuckerEngine::get_factors(double *Wflat, double *core) {
+  finalize_rotations();
   double *w = Wflat;
   for (int i = 0; i < N_; i++) {
     size_t n = (size_t)V_.glens[i] * r_[i];
@@ -470,6 +502,7 @@ void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
     for (int q = i + 1; q < N_; q++) T *= r_[q];
     double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
+    ops_.eig_lazy(eig_base_ + i, align_ref == nullptr && !dist_);
     factor_update(i, Y, L, T);  // K12
     if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
   }
@@ -825,6 +858,7 @@ void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, in
 }
 
 int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
+  finalize_rotations();  // the PP phases difference the eigenvectors themselves
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
   if (rank_ == 0 && !o.csv_path.empty()) {

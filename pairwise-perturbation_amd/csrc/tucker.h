@@ -72,6 +72,8 @@ class TuckerEngine {
   double *thin_ = nullptr;  // [s_i x (L*T) unfolding | (L*T) x r_i right vectors] of the thin route
   int64_t thin_cap_ = 0;
   int eig_base_ = 0;  // block of warm-start slots drawn from the back end (Ops::eig_session_new)
+  void finalize_rotations();
+  void drop_rotations();
   bool thin_enabled_ = true;  // PPALS_TUCKER_THIN=0: always the s_i x s_i Gram (A/B, tests)
   void *VT_ = nullptr;  // second resident layout [(right modes), (left modes)], nullptr: not held
   uint64_t tensor_gen_ = 0;  // generation of the tensor contents VT_ and the caches were built from
