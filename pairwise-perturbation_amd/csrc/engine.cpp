@@ -862,7 +862,20 @@ void CpEngine::ms_set_roots(int k) {
 // too short to time from the host and the effect does not matter
 size_t CpEngine::ms_X_slack() const {
   const double bytes = (double)V_.nloc * dtype_size(V_.dtype);
-  return bytes >= 1.5e9 ? ((size_t)64 << 20) + 4096 : 0;
+  if (bytes < 1.5e9) return 0;
+  // Within one process every offset of a 64 MB window can fall into the same slow class (five
+  // runs of bench.py on one box: 535 / 598 / 539 / 594 / 590 sweeps/s — all four roots at 1.22 ms or
+  // all at 1.06-1.13 ms, whatever the offset below 64 MB; profiles/r03j_place_lottery.txt), so the
+  // candidates reach 2 GB where the device has the room (PPALS_PLACE_SLACK_MB overrides)
+  if (ms_slack_ == (size_t)-1) {  // decided once per session (the block is sized with it)
+    size_t mb = 2048;
+    if (const char *e = std::getenv("PPALS_PLACE_SLACK_MB")) mb = (size_t)std::max(0, std::atoi(e));
+    // on a device that is nearly full keep the window small rather than shed a resident layout for it
+    const size_t avail = ops_.mem_available();
+    if (avail != 0 && (double)avail < bytes + 16e9) mb = std::min<size_t>(mb, 64);
+    ms_slack_ = (mb << 20) + 4096;
+  }
+  return ms_slack_;
 }
 
 // bytes of the first-level intermediate of the root set first .. first+k-1 (layout-independent)
@@ -947,8 +960,9 @@ void CpEngine::ms_start_step(int first) {
     // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
     ms_tuned_[first] = true;
     ms_X_off_[first] = 0;
-    static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
-    static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
+    static const int64_t cand_small[] = {0,   4,   8,   12,  16,  24,  32,  48,   64,   96,  128,
+                                         192, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536, 2048};
+    static const int64_t cand_large[] = {0, 12, 24, 64, 256, 512, 1024, 2048};
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
     // (worth measuring only where the result stream matters: an HBM-bound scan — up to two
     // n-tiles — that writes at least 1 % of what it reads)
@@ -956,7 +970,7 @@ void CpEngine::ms_start_step(int first) {
       const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
       const int reps = large ? 1 : 2;
       const int64_t *cand_mb = large ? cand_large : cand_small;
-      const int ncand = large ? 8 : 14;
+      const int ncand = large ? 8 : 22;
       double best = 1e300;
       for (int ci = 0; ci < ncand; ci++) {
         const int64_t mb = cand_mb[ci];
@@ -1023,6 +1037,9 @@ void CpEngine::ms_mode_update(int i, double lambda) {
   for (size_t q = 0; q < ms_order_.size(); q++)
     if (ms_order_[q] == i) pos = (int)q;
   const int leaf = ms_leaf_[pos];
+  // (S and S^-1 of this update depend on the other modes' Grams only: the contraction launched
+  // next may prepare them on the side)
+  ops_.arm_gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
   ms_compute(leaf);
   mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
   ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update

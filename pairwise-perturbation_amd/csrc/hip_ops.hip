@@ -692,28 +692,42 @@ class HipOps : public Ops {
   void mttv_t(const TX *X, int64_t L, int64_t J, int64_t T, int R, const double *B, int64_t ldb,
               double *out, int64_t rs, int accumulate, const double *scale) {
     constexpr int VL = 16 / sizeof(TX);
+    // one more workgroup prepares S, S^-1 of the mode update this contraction feeds (armed by the
+    // engine: arm_gram_system) — they depend on the other modes' Grams only
+    SysArgs sys;
+    size_t lds = 0;
+    int extra = 0;
+    if (sys_armed_ && sys_R_ == R) {
+      sys = sys_;
+      extra = 1;
+      lds = sizeof(double) * (2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
+    }
     prof_begin(1, (double)L * J * T * R * sizeof(TX));
     if (L == 1) {
       int64_t nw = ((T + 3) / 4) * R;
       int g = grid_for(nw * 64, 256, 16384);
-      hipLaunchKernelGGL(k_mttv_1<TX>, dim3(g), dim3(256), 0, st_, X, J, T, R, B, ldb, out, rs,
-                         accumulate, scale);
+      hipLaunchKernelGGL(k_mttv_1<TX>, dim3(g + extra), dim3(256), lds, st_, X, J, T, R, B, ldb, out, rs,
+                         accumulate, scale, sys);
     } else if (L % VL == 0 && L >= 16 * VL && ((uintptr_t)X & 15) == 0 &&
                ((L + 64 * VL - 1) / (64 * VL)) * T * R >= 1024) {
       // streaming regime: enough (l-tile, t, r) waves to fill the chip on their own
       int64_t nb = ((L + 64 * VL - 1) / (64 * VL)) * T * R;
       int g = (int)std::min<int64_t>(nb, 1 << 20);
-      hipLaunchKernelGGL(k_mttv_vec<TX>, dim3(g), dim3(64), 0, st_, X, L, J, T, R, B, ldb, out, rs,
-                         accumulate, scale);
+      hipLaunchKernelGGL(k_mttv_vec<TX>, dim3(g + extra), dim3(64), lds, st_, X, L, J, T, R, B, ldb, out,
+                         rs, accumulate, scale, sys);
     } else {
       int64_t nb = ((L + 63) / 64) * T * R;
       int g = (int)std::min<int64_t>(nb, 32768);
       if (nb * 4 < 1024)  // few blocks: split the j loop 16 ways instead of 4
-        hipLaunchKernelGGL((k_mttv_l<TX, 16>), dim3(g), dim3(1024), 0, st_, X, L, J, T, R, B, ldb,
-                           out, rs, accumulate, scale);
+        hipLaunchKernelGGL((k_mttv_l<TX, 16>), dim3(g + extra), dim3(1024), lds, st_, X, L, J, T, R, B,
+                           ldb, out, rs, accumulate, scale, sys);
       else
-        hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g), dim3(256), 0, st_, X, L, J, T, R, B, ldb,
-                           out, rs, accumulate, scale);
+        hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g + extra), dim3(256), lds, st_, X, L, J, T, R, B, ldb,
+                           out, rs, accumulate, scale, sys);
+    }
+    if (extra) {
+      sys_ready_ = true;
+      sys_armed_ = false;
     }
     prof_end();
     HIP_CHECK(hipGetLastError());

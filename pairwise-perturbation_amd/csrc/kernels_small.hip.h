@@ -302,20 +302,51 @@ __global__ void k_krp(double *__restrict__ out, KrpArgs a, int64_t J, int col0, 
 // may be null) is the pending Normalize factor of a cached tensor (see engine.cpp, MSDT).
 __device__ inline double mttv_scale(const double *scale) { return scale ? *scale : 1.0; }
 
+// A normal-equation system to prepare on the side: the S and S^-1 of the mode update that FOLLOWS a
+// contraction depend on the other modes' Grams only, which are final before the contraction starts.
+// One extra workgroup of the contraction's launch computes them (Gall == nullptr: none), so the
+// update kernel — one workgroup, a chain of dependent phases — starts with them in hand instead of
+// spending its first 3-8 us on the Hadamard product and the R x R inverse.
+__device__ inline void gram_system_wave(const double *__restrict__ Gall, int N, int mode, int R,
+                                        double lambda, double *__restrict__ S,
+                                        double *__restrict__ Sinv, int force_jacobi, double *lds);
+struct SysArgs {
+  const double *Gall = nullptr;
+  int N = 0, mode = 0;
+  double lambda = 0;
+  double *S = nullptr, *Sinv = nullptr;
+  int force_jacobi = 0;
+};
+// the extra workgroup of a contraction launch: true when THIS workgroup was it (and is done)
+#define PPALS_SYS_BLOCK(sys_, R_, nblk_)                                                        \
+  int nblk_ = (int)gridDim.x;                                                                   \
+  if ((sys_).Gall) {                                                                            \
+    nblk_ -= 1;                                                                                 \
+    if ((int)blockIdx.x == nblk_) {                                                             \
+      extern __shared__ double sys_lds_[];                                                      \
+      if (threadIdx.x < 64)                                                                     \
+        gram_system_wave((sys_).Gall, (sys_).N, (sys_).mode, R_, (sys_).lambda, (sys_).S,       \
+                         (sys_).Sinv, (sys_).force_jacobi, sys_lds_);                           \
+      return;                                                                                   \
+    }                                                                                           \
+  }
+
 // variant V (large L, L % VL == 0): one wave per (256*VL/4.. l-tile, t, r), 16-byte loads along l,
 // B[j,r] is wave-uniform. This is the streaming kernel for the s^(N-1) R intermediates.
 template <typename TX>
 __global__ __launch_bounds__(64) void k_mttv_vec(const TX *__restrict__ X, int64_t L, int64_t J,
                                                  int64_t T, int R, const double *__restrict__ B,
                                                  int64_t ldb, double *__restrict__ out, int64_t rs,
-                                                 int accumulate, const double *__restrict__ scale) {
+                                                 int accumulate, const double *__restrict__ scale,
+                                                 SysArgs sys = SysArgs()) {
+  PPALS_SYS_BLOCK(sys, R, nblk)
   constexpr int VL = 16 / sizeof(TX);
   typedef TX vecx __attribute__((ext_vector_type(VL)));
   const int lane = threadIdx.x;
   const int64_t ltiles = (L + 64 * VL - 1) / (64 * VL);
   const int64_t total = ltiles * T * R;
   const double sc = mttv_scale(scale);
-  for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  for (int64_t blk = blockIdx.x; blk < total; blk += nblk) {
     const int64_t lt = blk % ltiles;
     const int64_t t = (blk / ltiles) % T;
     const int r = (int)(blk / (ltiles * T));
@@ -357,13 +388,15 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
                                                     int64_t T, int R, const double *__restrict__ B,
                                                     int64_t ldb, double *__restrict__ out,
                                                     int64_t rs, int accumulate,
-                                                    const double *__restrict__ scale) {
+                                                    const double *__restrict__ scale,
+                                                    SysArgs sys = SysArgs()) {
+  PPALS_SYS_BLOCK(sys, R, nblk)
   __shared__ double part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ltiles = (L + 63) / 64;
   const int64_t total = ltiles * T * R;
   const double sc = mttv_scale(scale);
-  for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+  for (int64_t blk = blockIdx.x; blk < total; blk += nblk) {
     const int64_t lt = blk % ltiles;
     const int64_t t = (blk / ltiles) % T;
     const int r = (int)(blk / (ltiles * T));
@@ -406,10 +439,12 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
 template <typename TX>
 __global__ void k_mttv_1(const TX *__restrict__ X, int64_t J, int64_t T, int R,
                          const double *__restrict__ B, int64_t ldb, double *__restrict__ out,
-                         int64_t rs, int accumulate, const double *__restrict__ scale) {
+                         int64_t rs, int accumulate, const double *__restrict__ scale,
+                         SysArgs sys = SysArgs()) {
+  PPALS_SYS_BLOCK(sys, R, nblk)
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t nw = ((int64_t)nblk * blockDim.x) >> 6;
   const int64_t T4 = (T + 3) / 4;
   const int64_t total = T4 * R;
   const double sc = mttv_scale(scale);
@@ -460,21 +495,6 @@ struct PPTerms {
 // block = 16 consecutive x for one r, 256 threads. Both storage orders are read with 16 lanes along
 // the contiguous index (128-byte segments) and every thread keeps 4 independent partial sums, so a
 // block has ~64 loads per thread in flight instead of a dependent chain: the launch is latency.
-// A normal-equation system to prepare on the side: the S and S^-1 of the mode update that FOLLOWS a
-// contraction depend on the other modes' Grams only, which are final before the contraction starts.
-// One extra workgroup of the contraction's launch computes them (Gall == nullptr: none), so the
-// update kernel — one workgroup, a chain of dependent phases — starts with them in hand instead of
-// spending its first 3-8 us on the Hadamard product and the R x R inverse.
-__device__ inline void gram_system_wave(const double *__restrict__ Gall, int N, int mode, int R,
-                                        double lambda, double *__restrict__ S,
-                                        double *__restrict__ Sinv, int force_jacobi, double *lds);
-struct SysArgs {
-  const double *Gall = nullptr;
-  int N = 0, mode = 0;
-  double lambda = 0;
-  double *S = nullptr, *Sinv = nullptr;
-  int force_jacobi = 0;
-};
 __global__ __launch_bounds__(256) void k_pp_correct(const double *__restrict__ M0, int64_t rows,
                                                     int R, PPTerms tm, double *__restrict__ M,
                                                     SysArgs sys) {
