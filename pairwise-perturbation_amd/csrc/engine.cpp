@@ -302,11 +302,16 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     }
     ms_X_base_ = big_alloc(xmax + ms_X_slack());
     ms_X_cap_ = xmax + ms_X_slack();
+    ms_alloc_candidates(ms_X_cap_);
     ms_tuning_now_ = true;
     for (int r = 0; r < N_; r++) {
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;
       ms_start_step(r);
     }
+    ms_choose_common_block();
+    ms_release_unchosen();
+    ms_tune_second_layout();
+    ms_cand_.clear();
     ms_tuning_now_ = false;
     ms_invalidate();
     ms_X_.valid = false;
@@ -358,6 +363,7 @@ CpEngine::~CpEngine() {
   for (auto &l : lay_)
     if (l.owned) ops_.free(l.ptr);
   ops_.free(ms_X_base_);
+  for (void *p : ms_X_alt_) ops_.free(p);
   ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
     ops_.free(n.t.buf);
@@ -456,6 +462,7 @@ void CpEngine::ensure_transposed() {
   t.ptr = ops_.try_alloc(bytes_of(t));
   if (!t.ptr) return;
   t.owned = true;
+  t.bytes = bytes_of(t);
   fill_layout(t);
   lay_.push_back(t);
   vt_state_ = 1;
@@ -466,6 +473,7 @@ void CpEngine::ensure_transposed() {
     a.ptr = ops_.try_alloc(bytes_of(a));
     if (a.ptr) {
       a.owned = true;
+      a.bytes = bytes_of(a);
       fill_layout(a);
       lay_.push_back(a);
     }
@@ -862,20 +870,159 @@ void CpEngine::ms_set_roots(int k) {
 // too short to time from the host and the effect does not matter
 size_t CpEngine::ms_X_slack() const {
   const double bytes = (double)V_.nloc * dtype_size(V_.dtype);
-  if (bytes < 1.5e9) return 0;
-  // Within one process every offset of a 64 MB window can fall into the same slow class (five
-  // runs of bench.py on one box: 535 / 598 / 539 / 594 / 590 sweeps/s — all four roots at 1.22 ms or
-  // all at 1.06-1.13 ms, whatever the offset below 64 MB; profiles/r03j_place_lottery.txt), so the
-  // candidates reach 2 GB where the device has the room (PPALS_PLACE_SLACK_MB overrides)
-  if (ms_slack_ == (size_t)-1) {  // decided once per session (the block is sized with it)
-    size_t mb = 2048;
-    if (const char *e = std::getenv("PPALS_PLACE_SLACK_MB")) mb = (size_t)std::max(0, std::atoi(e));
-    // on a device that is nearly full keep the window small rather than shed a resident layout for it
+  return bytes >= 1.5e9 ? ((size_t)64 << 20) + 4096 : 0;
+}
+
+// Candidate result blocks for the placement measurement, spread over the device memory: between two
+// candidates a spacer of a few GB is allocated and freed again afterwards (blocks allocated back to
+// back land in one region and behave alike: profiles/r03q_place6_pairs.txt, second process).
+// Candidates are optional: none are taken when the device is short of room.
+void CpEngine::ms_alloc_candidates(size_t cap) {
+  int nb = 6;
+  if (const char *e = std::getenv("PPALS_PLACE_BLOCKS")) nb = std::max(1, std::atoi(e));
+  size_t spacer = (size_t)6 << 30;
+  if (const char *e = std::getenv("PPALS_PLACE_SPACER_MB")) spacer = (size_t)std::max(0, std::atoi(e)) << 20;
+  const double tensor_bytes = (double)V_.nloc * dtype_size(V_.dtype);
+  if (tensor_bytes >= 2.5e10) nb = std::min(nb, 3);  // scans of >= 4 ms: fewer measurements
+  std::vector<void *> spacers;
+  for (int b = 1; b < nb; b++) {
     const size_t avail = ops_.mem_available();
-    if (avail != 0 && (double)avail < bytes + 16e9) mb = std::min<size_t>(mb, 64);
-    ms_slack_ = (mb << 20) + 4096;
+    // what the session must still allocate (PP scratch, tree nodes: a few X) stays free
+    if (avail != (size_t)-1 && (double)avail < (double)(cap + spacer) + 4.0 * (double)cap + 8e9) break;
+    void *sp = spacer ? ops_.try_alloc(spacer) : nullptr;
+    void *p = ops_.try_alloc(cap);
+    if (sp) spacers.push_back(sp);
+    if (!p) break;
+    ms_X_alt_.push_back(p);
   }
-  return ms_slack_;
+  for (void *sp : spacers) ops_.free(sp);
+}
+
+// PPALS_PLACE_COMMON=1: one block for all roots — the one with the smallest sum of the roots' best
+// times — so that consecutive steps overwrite the same 320 MB (cfg2). Measured and not kept as the
+// default (tools/runs/r03_r.sh, r03_s.sh: three to four sessions per setting on one box, headline
+// 533/558/559 with a common block against 524/591/556 and 580/581/559 with a block per root).
+void CpEngine::ms_choose_common_block() {
+  const char *e = std::getenv("PPALS_PLACE_COMMON");
+  if (!e || std::atoi(e) == 0) return;
+  if (ms_cand_.empty() || ms_X_alt_.empty()) return;
+  const size_t nb = ms_X_alt_.size() + 1;
+  size_t bb = 0;
+  double bsum = 1e300;
+  for (size_t b = 0; b < nb; b++) {
+    double sum = 0;
+    for (auto &r : ms_cand_)
+      if (!r.empty()) sum += b < r.size() ? r[b].first : 1e300;
+    if (sum < bsum) {
+      bsum = sum;
+      bb = b;
+    }
+  }
+  for (size_t r = 0; r < ms_cand_.size(); r++) {
+    if (ms_cand_[r].empty() || bb >= ms_cand_[r].size()) continue;
+    ms_X_root_[r] = bb == 0 ? nullptr : ms_X_alt_[bb - 1];
+    ms_X_off_[r] = ms_cand_[r][bb].second;
+  }
+  if (getenv("PPALS_DEBUG_ADDR")) {
+    fprintf(stderr, "[ppals] X of every root in block %p (sum of the roots' scans %.3f ms):",
+            bb == 0 ? ms_X_base_ : ms_X_alt_[bb - 1], bsum * 1e3);
+    for (size_t r = 0; r < ms_cand_.size(); r++)
+      if (!ms_cand_[r].empty()) fprintf(stderr, " root %zu +%lld MB", r, (long long)(ms_X_off_[r] >> 20));
+    fprintf(stderr, "\n");
+  }
+  ms_cand_.clear();
+}
+
+// The second resident layout is the session's own buffer, so its place can be chosen as well: with
+// the result block fixed (chosen above with the roots that read the tensor's own buffer weighing
+// in), a few further copies of the layout are tried elsewhere in the device memory and the one the
+// roots that read it scan fastest is kept (tools/runs/r03_p.sh, a box where those two roots ran at
+// 1.21-1.25 ms against 1.08-1.11 ms of the other two whatever the result block). Candidates stay
+// allocated until the choice is made, so that each lands somewhere else; all but one are freed.
+void CpEngine::ms_tune_second_layout() {
+  if (lay_.size() < 2 || !lay_[1].owned || lay_[1].bytes == 0) return;
+  int nc = 5;
+  if (const char *e = std::getenv("PPALS_PLACE_LAYOUTS")) nc = std::max(1, std::atoi(e));
+  const size_t bytes = lay_[1].bytes;
+  if (nc <= 1 || (double)bytes > 1.7e10) return;  // larger layouts span the regions anyway
+  std::vector<int> roots;
+  double cur = 0;
+  for (int r = 0; r < N_; r++)
+    if (ms_tuned_[r] && ms_root_layout_[r] == 1 && ms_tuned_ms_[r] > 0) {
+      roots.push_back(r);
+      cur += ms_tuned_ms_[r];
+    }
+  if (roots.empty()) return;
+  const bool dbg = getenv("PPALS_DEBUG_ADDR") != nullptr;
+  struct Cand {
+    void *p;
+    double sum;
+    int64_t off[MAX_ORDER];
+  };
+  auto snapshot = [&](void *p, double sum) {
+    Cand c;
+    c.p = p;
+    c.sum = sum;
+    for (int r = 0; r < MAX_ORDER; r++) c.off[r] = ms_X_off_[r];
+    return c;
+  };
+  Cand best = snapshot(lay_[1].ptr, cur);
+  std::vector<void *> rejected;
+  for (int c = 1; c < nc; c++) {
+    const size_t avail = ops_.mem_available();
+    if (avail != (size_t)-1 && (double)avail < 2.0 * (double)bytes + 4.0 * (double)ms_X_cap_ + 8e9) break;
+    void *p = ops_.try_alloc(bytes);
+    if (!p) break;
+    ops_.d2d(p, best.p, bytes);
+    lay_[1].ptr = p;
+    double sum = 0;
+    for (int r : roots) {
+      ms_tuned_[r] = false;
+      ms_start_step(r);
+      sum += ms_tuned_ms_[r];
+    }
+    if (dbg)
+      fprintf(stderr, "[ppals] second layout at %p: its roots scan in %.3f ms (so far %.3f ms at %p)\n", p,
+              sum * 1e3, best.sum * 1e3, best.p);
+    if (sum < best.sum * 0.99) {
+      rejected.push_back(best.p);
+      best = snapshot(p, sum);
+    } else {
+      rejected.push_back(p);
+    }
+  }
+  ops_.sync();
+  lay_[1].ptr = best.p;
+  for (int r : roots) ms_X_off_[r] = best.off[r];
+  for (void *p : rejected) ops_.free(p);
+}
+
+void CpEngine::ms_release_unchosen() {
+  // all roots in one further block: it becomes the primary one
+  void *common = ms_X_root_[0];
+  bool all = common != nullptr;
+  for (int r = 0; r < N_; r++)
+    if (ms_tuned_[r]) all = all && ms_X_root_[r] == common;
+  if (all) {
+    ops_.sync();
+    ops_.free(ms_X_base_);
+    ms_X_base_ = common;
+    for (int r = 0; r < MAX_ORDER; r++) ms_X_root_[r] = nullptr;
+    for (void *p : ms_X_alt_)
+      if (p != common) ops_.free(p);
+    ms_X_alt_.clear();
+    return;
+  }
+  std::vector<void *> keep;
+  for (void *p : ms_X_alt_) {
+    bool used = false;
+    for (int r = 0; r < N_; r++) used = used || ms_X_root_[r] == p;
+    if (used)
+      keep.push_back(p);
+    else
+      ops_.free(p);
+  }
+  ms_X_alt_.swap(keep);
 }
 
 // bytes of the first-level intermediate of the root set first .. first+k-1 (layout-independent)
@@ -923,6 +1070,9 @@ void CpEngine::ms_start_step(int first) {
     ops_.free(ms_X_base_);
     ms_X_base_ = nullptr;
     ms_X_cap_ = 0;
+    for (void *p : ms_X_alt_) ops_.free(p);
+    ms_X_alt_.clear();
+    for (int r = 0; r < MAX_ORDER; r++) ms_X_root_[r] = nullptr;
     ms_X_base_ = big_alloc(xbytes + slack);
     ms_X_cap_ = xbytes + slack;
     // (the offsets measured at session set-up stay valid — they are bounded by the slack — but
@@ -950,8 +1100,8 @@ void CpEngine::ms_start_step(int first) {
   ms_X_.contracted = mask;
   if ((size_t)L * T * R_ * dtype_size(ms_X_.dt) != xbytes)
     throw std::runtime_error("ppals: internal error (first-level intermediate size)");
-  auto launch_scan = [&](int64_t off) {
-    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)ms_X_base_ + off;
+  auto launch_scan = [&](void *base, int64_t off) {
+    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)base + off;
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
   };
@@ -960,45 +1110,61 @@ void CpEngine::ms_start_step(int first) {
     // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
     ms_tuned_[first] = true;
     ms_X_off_[first] = 0;
-    static const int64_t cand_small[] = {0,   4,   8,   12,  16,  24,  32,  48,   64,   96,  128,
-                                         192, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536, 2048};
-    static const int64_t cand_large[] = {0, 12, 24, 64, 256, 512, 1024, 2048};
+    ms_X_root_[first] = nullptr;
+    static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
+    static const int64_t cand_alt[] = {0, 4, 12, 16, 48, 64};  // in each further block
+    static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
+    static const int64_t cand_large_alt[] = {0, 12, 48};
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
     // (worth measuring only where the result stream matters: an HBM-bound scan — up to two
     // n-tiles — that writes at least 1 % of what it reads)
     if (bytes >= 1.5e9 && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
       const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
       const int reps = large ? 1 : 2;
-      const int64_t *cand_mb = large ? cand_large : cand_small;
-      const int ncand = large ? 8 : 22;
+      const int verbose = getenv("PPALS_DEBUG_ADDR") ? std::atoi(getenv("PPALS_DEBUG_ADDR")) : 0;
       double best = 1e300;
-      for (int ci = 0; ci < ncand; ci++) {
-        const int64_t mb = cand_mb[ci];
-        const int64_t off = mb << 20;
-        if ((size_t)off > slack) break;
-        double tmin = 1e300;
-        for (int rep = 0; rep < reps; rep++) {
-          ops_.sync();
-          const double t0 = now();
-          launch_scan(off);
-          ops_.sync();
-          tmin = std::min(tmin, now() - t0);
-        }
-        if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
-          best = tmin;
-          ms_X_off_[first] = off;
+      for (size_t b = 0; b <= ms_X_alt_.size(); b++) {
+        void *base = b == 0 ? ms_X_base_ : ms_X_alt_[b - 1];
+        const int64_t *cand_mb = b == 0 ? (large ? cand_large : cand_small) : (large ? cand_large_alt : cand_alt);
+        const int ncand = b == 0 ? (large ? 8 : 14) : (large ? 3 : 6);
+        for (int ci = 0; ci < ncand; ci++) {
+          const int64_t mb = cand_mb[ci];
+          const int64_t off = mb << 20;
+          if ((size_t)off > slack) break;
+          double tmin = 1e300;
+          for (int rep = 0; rep < reps; rep++) {
+            ops_.sync();
+            const double t0 = now();
+            launch_scan(base, off);
+            ops_.sync();
+            tmin = std::min(tmin, now() - t0);
+          }
+          if (verbose >= 2)
+            fprintf(stderr, "[ppals] root %d: X %p +%lld MB %.3f ms\n", first, base, (long long)mb,
+                    tmin * 1e3);
+          if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
+            best = tmin;
+            ms_X_off_[first] = off;
+            ms_X_root_[first] = b == 0 ? nullptr : base;
+          }
+          if ((int)ms_cand_.size() <= first) ms_cand_.resize(first + 1);
+          if (ms_cand_[first].size() <= b) ms_cand_[first].resize(b + 1, {1e300, 0});
+          if (tmin < ms_cand_[first][b].first * 0.995) ms_cand_[first][b] = {tmin, off};
         }
       }
-      if (getenv("PPALS_DEBUG_ADDR"))
-        fprintf(stderr, "[ppals] root %d: X placed at +%lld MB (%.3f ms)\n", first,
-                (long long)(ms_X_off_[first] >> 20), best * 1e3);
+      ms_tuned_ms_[first] = best;
+      ms_root_layout_[first] = (int)(pl.lay - lay_.data());
+      if (verbose)
+        fprintf(stderr, "[ppals] root %d: X placed in block %p at +%lld MB (%.3f ms, %zu blocks tried)\n",
+                first, ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_,
+                (long long)(ms_X_off_[first] >> 20), best * 1e3, ms_X_alt_.size() + 1);
     }
   }
   if (getenv("PPALS_DEBUG_ADDR"))
     fprintf(stderr, "[ppals] step roots %d..+%d: src %p (layout %d of %d) X %p L %lld J %lld T %lld\n",
             first, k, src, (int)(pl.lay - lay_.data()), (int)lay_.size(), ms_X_.buf, (long long)L,
             (long long)J, (long long)T);
-  launch_scan(ms_X_off_[first]);
+  launch_scan(ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_, ms_X_off_[first]);
   ms_X_.pending = false;
   ms_X_.valid = true;
   if (const char *tr = std::getenv("PPALS_TRACE_STEPS")) {  // tests: which root sets were scanned

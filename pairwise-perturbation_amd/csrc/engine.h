@@ -161,15 +161,26 @@ class CpEngine {
   // Placement of the first-level intermediate: the scan reads the tensor and writes X at the same
   // time, and how the two streams fall onto the HBM channels depends on where X lies relative to
   // the tensor buffer — 6-9 % of the launch between placements of one and the same kernel
-  // (profiles/r02l_place_bench_*.txt). X lives at a per-root offset inside an over-allocated block;
-  // the offsets are measured once per session (ms_tune_placement).
-  void *ms_X_base_ = nullptr;
+  // (profiles/r02l_place_bench_*.txt), and 15 % between result blocks several GB apart: which block
+  // suits which source is a property of the PAIR (profiles/r03q_place6_pairs.txt: source x block
+  // matrix, 1.14 .. 1.33 ms). X lives at a per-root offset inside a per-root block chosen among a
+  // few candidate blocks spread over the device memory; block and offset are measured once per
+  // session, with the real scan, at set-up. Blocks no root chose are freed again.
+  void *ms_X_base_ = nullptr;            // primary block (every root's default)
+  std::vector<void *> ms_X_alt_;         // further candidate blocks of the same capacity
+  void *ms_X_root_[MAX_ORDER] = {nullptr};  // block chosen for a root (nullptr: the primary one)
   size_t ms_X_cap_ = 0;
   int64_t ms_X_off_[MAX_ORDER] = {0};
+  void ms_alloc_candidates(size_t cap);
+  void ms_release_unchosen();
+  void ms_choose_common_block();
+  void ms_tune_second_layout();
+  double ms_tuned_ms_[MAX_ORDER] = {0};   // the chosen placement's scan time, seconds
+  int ms_root_layout_[MAX_ORDER] = {0};   // which resident layout the root's scan reads
+  std::vector<std::vector<std::pair<double, int64_t>>> ms_cand_;  // [root][block] -> (ms, offset)
   bool ms_tuned_[MAX_ORDER] = {false};
   bool ms_tune_enabled_ = true;
   size_t ms_X_slack() const;
-  mutable size_t ms_slack_ = (size_t)-1;
   size_t ms_X_bytes(int first, int k) const;
   bool ms_tuning_now_ = false;  // placement is measured at session set-up only
   void *big_alloc(size_t bytes);  // gives optional resident layouts back when the device is full
@@ -261,6 +272,7 @@ class CpEngine {
     int q = 0;                // leading modes in the padded block (0: not padded)
     int64_t blk = 0, ld = 0;  // real / stored elements of that block
     bool owned = false;
+    size_t bytes = 0;         // of an owned layout
   };
   std::vector<Layout> lay_;
   int vt_state_ = 0;          // 0 not tried, 1 second layout built, -1 unavailable (disabled / no memory)

@@ -18,7 +18,6 @@
 #include "kernels_eig.hip.h"
 
 namespace ppals {
-
 #define HIP_CHECK(expr)                                                                       \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
@@ -605,10 +604,26 @@ class HipOps : public Ops {
                      k_valid)
         // persistent launch: ncu*40 workgroups (measured best of 3..40 per CU), each walks over its tiles
         dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
-#define LAUNCH_SUFFIX_BUF(NTv)                                                                     \
-  hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, 1>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks, \
+#define LAUNCH_SUFFIX_BUF_O(NTv, OPTv)                                                                \
+  hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, OPTv>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks,  \
                      k_ld, k_valid)
+        // A result too large for the 256 MB Infinity Cache is stored non-temporally: the stream of
+        // ordinary stores costs the scan 0.2 ms per 320 MB (cfg2) next to its 6.4 GB of reads, the
+        // non-temporal one 0.1 ms (tools/place6_bench, profiles/r03q_place6_nt.txt: 1.09-1.10 ms
+        // against 1.19-1.20 ms per launch for the same source and result buffers), and what reads
+        // the result next streams it from HBM either way. PPALS_SCAN_NT_MB moves the threshold.
+        static const double nt_min_bytes = [] {
+          const char *e = std::getenv("PPALS_SCAN_NT_MB");
+          return (e ? std::atof(e) : 192.0) * 1048576.0;
+        }();
+        const bool nt_store = nsplit == 1 && (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes;
+#define LAUNCH_SUFFIX_BUF(NTv)           \
+  if (nt_store) {                        \
+    LAUNCH_SUFFIX_BUF_O(NTv, 5);         \
+  } else {                               \
+    LAUNCH_SUFFIX_BUF_O(NTv, 1);         \
+  }
         // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
@@ -617,10 +632,15 @@ class HipOps : public Ops {
         // at 0.80 of peak on the global-load kernel against 0.70 here: tools/r02_f64.sh)
         if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
             !(sizeof(TV) == 8 && nsplit > 1)) {
-          if (NT == 1) LAUNCH_SUFFIX_BUF(1);
-          else if (NT == 2) LAUNCH_SUFFIX_BUF(2);
-          else if (NT == 3) LAUNCH_SUFFIX_BUF(3);
-          else LAUNCH_SUFFIX_BUF(4);
+          if (NT == 1) {
+            LAUNCH_SUFFIX_BUF(1)
+          } else if (NT == 2) {
+            LAUNCH_SUFFIX_BUF(2)
+          } else if (NT == 3) {
+            LAUNCH_SUFFIX_BUF(3)
+          } else {
+            LAUNCH_SUFFIX_BUF(4)
+          }
         } else if (al && variant_ >= 1 && M >= VEC) {
           if (NT == 1) LAUNCH_SUFFIX_FAST(1);
           else if (NT == 2) LAUNCH_SUFFIX_FAST(2);
@@ -640,6 +660,7 @@ class HipOps : public Ops {
 #undef LAUNCH_SUFFIX
 #undef LAUNCH_SUFFIX_FAST
 #undef LAUNCH_SUFFIX_BUF
+#undef LAUNCH_SUFFIX_BUF_O
         prof_end();
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {

@@ -651,18 +651,29 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
             else
               val[jj] = (double)acc[jj][nt][r];
           }
-          const int64_t idx = cur.obase + (int64_t)n * out_nstride + rm.mo;
+          int64_t idx = cur.obase + (int64_t)n * out_nstride + rm.mo;
+          // OPT bit 1 (tools/place2_bench only): row-blocked result, 256 rows x ncols per block —
+          // what one workgroup stores is then one contiguous piece instead of ncols pieces
+          if constexpr (OPT & 2)
+            idx = cur.obase + (cur.m >> 8) * ((int64_t)ncols << 8) + ((int64_t)n << 8) + (cur.m & 255);
           if (vec_ok && out32) {
             typedef float ovec_t __attribute__((ext_vector_type(VEC)));
             ovec_t ov;
 #pragma unroll
             for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
-            *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+            // OPT bit 2: non-temporal result stores (a result of hundreds of MB: see the launcher)
+            if constexpr (OPT & 4)
+              __builtin_nontemporal_store(ov, reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx));
+            else
+              *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
           } else if (vec_ok) {
 #pragma unroll
             for (int jj = 0; jj < VEC; jj += 2) {
               f64x2 ov = {val[jj], val[jj + 1]};
-              *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
+              if constexpr (OPT & 4)
+                __builtin_nontemporal_store(ov, reinterpret_cast<f64x2 *>(out + idx + jj));
+              else
+                *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
             }
           } else {
 #pragma unroll
