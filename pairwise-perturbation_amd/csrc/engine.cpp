@@ -289,6 +289,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     lay_.push_back(nat);
   }
   ensure_transposed();
+  for (int r = 0; r < MAX_ORDER; r++) ms_X_nt_[r] = -1;
   if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
     // placement of the first-level intermediate, measured per root with the factors at hand
     // (zeros: the timing does not depend on the values); nothing is kept but the offsets.
@@ -300,6 +301,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
       xmax = std::max(xmax, ms_X_bytes(r, ms_k_));
     }
+    const double t_tune0 = now();
     ms_X_base_ = big_alloc(xmax + ms_X_slack());
     ms_X_cap_ = xmax + ms_X_slack();
     ms_alloc_candidates(ms_X_cap_);
@@ -313,6 +315,9 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ms_tune_second_layout();
     ms_cand_.clear();
     ms_tuning_now_ = false;
+    ops_.sync();
+    if (getenv("PPALS_DEBUG_ADDR"))
+      fprintf(stderr, "[ppals] placement measured in %.2f s\n", now() - t_tune0);
     ms_invalidate();
     ms_X_.valid = false;
   }
@@ -878,7 +883,7 @@ size_t CpEngine::ms_X_slack() const {
 // back land in one region and behave alike: profiles/r03q_place6_pairs.txt, second process).
 // Candidates are optional: none are taken when the device is short of room.
 void CpEngine::ms_alloc_candidates(size_t cap) {
-  int nb = 6;
+  int nb = 4;
   if (const char *e = std::getenv("PPALS_PLACE_BLOCKS")) nb = std::max(1, std::atoi(e));
   size_t spacer = (size_t)6 << 30;
   if (const char *e = std::getenv("PPALS_PLACE_SPACER_MB")) spacer = (size_t)std::max(0, std::atoi(e)) << 20;
@@ -941,7 +946,7 @@ void CpEngine::ms_choose_common_block() {
 // allocated until the choice is made, so that each lands somewhere else; all but one are freed.
 void CpEngine::ms_tune_second_layout() {
   if (lay_.size() < 2 || !lay_[1].owned || lay_[1].bytes == 0) return;
-  int nc = 5;
+  int nc = 3;
   if (const char *e = std::getenv("PPALS_PLACE_LAYOUTS")) nc = std::max(1, std::atoi(e));
   const size_t bytes = lay_[1].bytes;
   if (nc <= 1 || (double)bytes > 1.7e10) return;  // larger layouts span the regions anyway
@@ -958,12 +963,16 @@ void CpEngine::ms_tune_second_layout() {
     void *p;
     double sum;
     int64_t off[MAX_ORDER];
+    int nt[MAX_ORDER];
   };
   auto snapshot = [&](void *p, double sum) {
     Cand c;
     c.p = p;
     c.sum = sum;
-    for (int r = 0; r < MAX_ORDER; r++) c.off[r] = ms_X_off_[r];
+    for (int r = 0; r < MAX_ORDER; r++) {
+      c.off[r] = ms_X_off_[r];
+      c.nt[r] = ms_X_nt_[r];
+    }
     return c;
   };
   Cand best = snapshot(lay_[1].ptr, cur);
@@ -993,7 +1002,10 @@ void CpEngine::ms_tune_second_layout() {
   }
   ops_.sync();
   lay_[1].ptr = best.p;
-  for (int r : roots) ms_X_off_[r] = best.off[r];
+  for (int r : roots) {
+    ms_X_off_[r] = best.off[r];
+    ms_X_nt_[r] = best.nt[r];
+  }
   for (void *p : rejected) ops_.free(p);
 }
 
@@ -1102,8 +1114,10 @@ void CpEngine::ms_start_step(int first) {
     throw std::runtime_error("ppals: internal error (first-level intermediate size)");
   auto launch_scan = [&](void *base, int64_t off) {
     ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)base + off;
+    ops_.scan_store_mode(ms_X_nt_[first]);
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
+    ops_.scan_store_mode(-1);
   };
   if (slack > 0 && !ms_tuned_[first] && ms_tuning_now_ && !ms_X_override_) {
     // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
@@ -1111,8 +1125,9 @@ void CpEngine::ms_start_step(int first) {
     ms_tuned_[first] = true;
     ms_X_off_[first] = 0;
     ms_X_root_[first] = nullptr;
+    ms_X_nt_[first] = -1;
     static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
-    static const int64_t cand_alt[] = {0, 4, 12, 16, 48, 64};  // in each further block
+    static const int64_t cand_alt[] = {0, 4, 16, 64};  // in each further block
     static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
     static const int64_t cand_large_alt[] = {0, 12, 48};
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
@@ -1126,7 +1141,7 @@ void CpEngine::ms_start_step(int first) {
       for (size_t b = 0; b <= ms_X_alt_.size(); b++) {
         void *base = b == 0 ? ms_X_base_ : ms_X_alt_[b - 1];
         const int64_t *cand_mb = b == 0 ? (large ? cand_large : cand_small) : (large ? cand_large_alt : cand_alt);
-        const int ncand = b == 0 ? (large ? 8 : 14) : (large ? 3 : 6);
+        const int ncand = b == 0 ? (large ? 8 : 14) : (large ? 3 : 4);
         for (int ci = 0; ci < ncand; ci++) {
           const int64_t mb = cand_mb[ci];
           const int64_t off = mb << 20;
@@ -1151,6 +1166,30 @@ void CpEngine::ms_start_step(int first) {
           if (ms_cand_[first].size() <= b) ms_cand_[first].resize(b + 1, {1e300, 0});
           if (tmin < ms_cand_[first][b].first * 0.995) ms_cand_[first][b] = {tmin, off};
         }
+      }
+      // the other kind of result store at the chosen placement (see hip_ops.hip, nt_store)
+      static const bool try_kinds = [] {
+        const char *e = std::getenv("PPALS_PLACE_STORE_KIND");
+        return !(e && std::atoi(e) == 0);
+      }();
+      if (try_kinds && xbytes >= ((size_t)32 << 20)) {
+        double t_alt[2] = {1e300, 1e300};
+        void *base = ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_;
+        for (int kind = 0; kind < 2; kind++) {
+          ms_X_nt_[first] = kind;
+          for (int rep = 0; rep < reps + 1; rep++) {
+            ops_.sync();
+            const double t0 = now();
+            launch_scan(base, ms_X_off_[first]);
+            ops_.sync();
+            t_alt[kind] = std::min(t_alt[kind], now() - t0);
+          }
+        }
+        ms_X_nt_[first] = t_alt[1] < t_alt[0] ? 1 : 0;
+        best = std::min(t_alt[0], t_alt[1]);
+        if (verbose)
+          fprintf(stderr, "[ppals] root %d: ordinary stores %.3f ms, non-temporal %.3f ms\n", first,
+                  t_alt[0] * 1e3, t_alt[1] * 1e3);
       }
       ms_tuned_ms_[first] = best;
       ms_root_layout_[first] = (int)(pl.lay - lay_.data());

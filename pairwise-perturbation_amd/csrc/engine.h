@@ -174,6 +174,7 @@ class CpEngine {
   void ms_alloc_candidates(size_t cap);
   void ms_release_unchosen();
   void ms_choose_common_block();
+  int ms_X_nt_[MAX_ORDER];  // store kind of the root's scan: -1 the back end's rule, 0 ordinary, 1 non-temporal
   void ms_tune_second_layout();
   double ms_tuned_ms_[MAX_ORDER] = {0};   // the chosen placement's scan time, seconds
   int ms_root_layout_[MAX_ORDER] = {0};   // which resident layout the root's scan reads

@@ -411,6 +411,8 @@ class HipOps : public Ops {
     }
     return p;
   }
+  void scan_store_mode(int mode) override { scan_nt_mode_ = mode; }
+  int scan_nt_mode_ = -1;
   size_t mem_available() override {
     size_t fr = 0, tot = 0;
     hipSetDevice(dev_);
@@ -612,12 +614,17 @@ class HipOps : public Ops {
         // ordinary stores costs the scan 0.2 ms per 320 MB (cfg2) next to its 6.4 GB of reads, the
         // non-temporal one 0.1 ms (tools/place6_bench, profiles/r03q_place6_nt.txt: 1.09-1.10 ms
         // against 1.19-1.20 ms per launch for the same source and result buffers), and what reads
-        // the result next streams it from HBM either way. PPALS_SCAN_NT_MB moves the threshold.
+        // the result next streams it from HBM either way. Not on every pair of buffers, though: in one
+        // process (r03q_place6_nt_same_process.txt) 1.21 -> 1.06 ms for some, +1 % for others — so
+        // the engine's placement tuner measures both kinds for the first-level intermediate
+        // (scan_store_mode); this rule is for every other large result. PPALS_SCAN_NT_MB moves it.
         static const double nt_min_bytes = [] {
           const char *e = std::getenv("PPALS_SCAN_NT_MB");
           return (e ? std::atof(e) : 192.0) * 1048576.0;
         }();
-        const bool nt_store = nsplit == 1 && (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes;
+        const bool nt_store =
+            nsplit == 1 && (scan_nt_mode_ < 0 ? (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes
+                                              : scan_nt_mode_ == 1);
 #define LAUNCH_SUFFIX_BUF(NTv)           \
   if (nt_store) {                        \
     LAUNCH_SUFFIX_BUF_O(NTv, 5);         \

@@ -115,6 +115,8 @@ class Ops {
                              int P, int64_t chunk_bytes, void *full) = 0;
   // alloc that returns nullptr instead of throwing when the device is out of memory
   virtual void *try_alloc(size_t bytes) { return alloc(bytes); }
+  // how the next scans store a large result: -1 the back end's rule, 0 ordinary, 1 non-temporal
+  virtual void scan_store_mode(int mode) { (void)mode; }
   // free device memory in bytes, (size_t)-1: unknown / unlimited
   virtual size_t mem_available() { return (size_t)-1; }
 

@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
   const int64_t M = 8000000;
   const int K = 200, R = 10, rounds = argc > 1 ? atoi(argv[1]) : 5;
   const int order = argc > 2 ? atoi(argv[2]) : 0;
-  const int nt = argc > 3 ? atoi(argv[3]) : 0;  // 1: non-temporal result stores, 2: read side sc1 off  // 0: S,X alternately; 1: all S then all X
+  const int nt = argc > 3 ? atoi(argv[3]) : 0;  // 1: non-temporal result stores, 2: read side sc1 off, 3: columns 3-5 = blocks 0-2 again with non-temporal stores  // 0: S,X alternately; 1: all S then all X
   const int nblk = (K + 15) / 16;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -70,7 +70,11 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e0, 0));
         const dim3 gridf((unsigned)std::min<int64_t>(n_mt, (int64_t)ncu * 40));
         const dim3 gridb((unsigned)std::min<int64_t>((int64_t)n_mtb * Tb, (int64_t)ncu * 40));
-        if (j < NX && nt == 1)
+        if (j < NX && nt == 3 && j >= 3)
+          hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 5>), gridf, dim3(256), 0, 0, S[i], M, (int64_t)K,
+                             M * K, P, n_mt, 1, nblk, nblk, (double *)X[j - 3], M, (int64_t)0, (int64_t)0,
+                             R, 1, (int64_t)n_mt);
+        else if (j < NX && nt == 1)
           hipLaunchKernelGGL((k_scan_suffix_buf<float, 1, 5>), gridf, dim3(256), 0, 0, S[i], M, (int64_t)K,
                              M * K, P, n_mt, 1, nblk, nblk, (double *)X[j], M, (int64_t)0, (int64_t)0, R,
                              1, (int64_t)n_mt);
