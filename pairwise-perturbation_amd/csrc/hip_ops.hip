@@ -600,10 +600,16 @@ class HipOps : public Ops {
   hipLaunchKernelGGL((k_scan_suffix<TV, NTv, ALv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld, \
                      k_valid)
-#define LAUNCH_SUFFIX_FAST(NTv)                                                                  \
-  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 1>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
-                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld, \
+#define LAUNCH_SUFFIX_FAST_O(NTv, OPTv)                                                             \
+  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, OPTv>), grid, dim3(256), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld,    \
                      k_valid)
+#define LAUNCH_SUFFIX_FAST(NTv)   \
+  if (nt_store) {                 \
+    LAUNCH_SUFFIX_FAST_O(NTv, 5); \
+  } else {                        \
+    LAUNCH_SUFFIX_FAST_O(NTv, 1); \
+  }
         // persistent launch: ncu*40 workgroups (measured best of 3..40 per CU), each walks over its tiles
         dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
 #define LAUNCH_SUFFIX_BUF_O(NTv, OPTv)                                                                \
@@ -625,6 +631,12 @@ class HipOps : public Ops {
         const bool nt_store =
             nsplit == 1 && (scan_nt_mode_ < 0 ? (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes
                                               : scan_nt_mode_ == 1);
+        // (Measured and rejected, tools/runs/r03_u.sh: second-level sums in fp32 for short
+        // reductions — 16 NT registers fewer, the two-tile global-load kernel 174 -> 130 registers and
+        // 2 -> 3 waves per SIMD, the one-tile buffer kernel 3 -> 4 waves: cfg4 36.0 / 36.7 -> 33.0 /
+        // 33.6 sweeps/s, cfg2 no gain. More waves in flight make the mixed read/write stream worse.
+        // Fewer do not help either: 64 KB of dynamic LDS per workgroup (2 instead of 3 workgroups per
+        // CU) x 6..40 workgroups per CU in the persistent grid: profiles/r03v_occupancy_sweep.txt.)
 #define LAUNCH_SUFFIX_BUF(NTv)           \
   if (nt_store) {                        \
     LAUNCH_SUFFIX_BUF_O(NTv, 5);         \
@@ -649,10 +661,15 @@ class HipOps : public Ops {
             LAUNCH_SUFFIX_BUF(4)
           }
         } else if (al && variant_ >= 1 && M >= VEC) {
-          if (NT == 1) LAUNCH_SUFFIX_FAST(1);
-          else if (NT == 2) LAUNCH_SUFFIX_FAST(2);
-          else if (NT == 3) LAUNCH_SUFFIX_FAST(3);
-          else LAUNCH_SUFFIX_FAST(4);
+          if (NT == 1) {
+            LAUNCH_SUFFIX_FAST(1)
+          } else if (NT == 2) {
+            LAUNCH_SUFFIX_FAST(2)
+          } else if (NT == 3) {
+            LAUNCH_SUFFIX_FAST(3)
+          } else {
+            LAUNCH_SUFFIX_FAST(4)
+          }
         } else if (al) {
           if (NT == 1) LAUNCH_SUFFIX(1, true);
           else if (NT == 2) LAUNCH_SUFFIX(2, true);
@@ -666,6 +683,7 @@ class HipOps : public Ops {
         }
 #undef LAUNCH_SUFFIX
 #undef LAUNCH_SUFFIX_FAST
+#undef LAUNCH_SUFFIX_FAST_O
 #undef LAUNCH_SUFFIX_BUF
 #undef LAUNCH_SUFFIX_BUF_O
         prof_end();

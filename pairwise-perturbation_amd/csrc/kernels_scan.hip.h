@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
       for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
       if constexpr (TR::NEEDS_FLUSH) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
+        for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0;
       }
     }
 
@@ -464,12 +464,18 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
           ovec_t ov;
 #pragma unroll
           for (int jj = 0; jj < VEC; jj++) ov[jj] = (float)val[jj];
-          *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
+          if constexpr (OPT & 4)  // non-temporal result stores (see the launcher)
+            __builtin_nontemporal_store(ov, reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx));
+          else
+            *reinterpret_cast<ovec_t *>(reinterpret_cast<float *>(out) + idx) = ov;
         } else if (vec_ok) {
 #pragma unroll
           for (int jj = 0; jj < VEC; jj += 2) {
             f64x2 ov = {val[jj], val[jj + 1]};
-            *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
+            if constexpr (OPT & 4)
+              __builtin_nontemporal_store(ov, reinterpret_cast<f64x2 *>(out + idx + jj));
+            else
+              *reinterpret_cast<f64x2 *>(out + idx + jj) = ov;
           }
         } else {
 #pragma unroll
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
         for (int r = 0; r < 4; r++) acc[a][nt][r] = 0;
         if constexpr (TR::NEEDS_FLUSH) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0.0;
+          for (int r = 0; r < 4; r++) acc64[a][nt][r] = 0;
         }
       }
     for (int kc = cur.kb0; kc < cur.kb1; kc += FLUSH) {
