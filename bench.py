@@ -435,6 +435,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def _clocks_ns():
+        out = {"monotonic": time.monotonic_ns(), "realtime": time.time_ns()}
+        for name in ("CLOCK_BOOTTIME", "CLOCK_MONOTONIC_RAW"):
+            if hasattr(time, name):
+                out[name.lower()[6:]] = time.clock_gettime_ns(getattr(time, name))
+        return out
+
     def measure(cp, steps, warmup, W=None, G=None):
         """W untimed sweeps, then EXACTLY `steps` timed ones between barrier + synchronize on both
         sides (max over ranks); HIP events on the engine's stream around the tensor scans only"""
@@ -443,11 +450,13 @@ def main():
         barrier()
         ctx.profile_reset()
         ctx.profile_enable(1)
+        clk0 = _clocks_ns()
         t0 = time.perf_counter()
         cp.sweeps_dt(steps)
         ctx.sync()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        clk1 = _clocks_ns()
         ctx.profile_enable(0)
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -456,7 +465,10 @@ def main():
         barrier()
         launches, scan_ms, scan_bytes = ctx.profile_read(0)
         rec = {"ms_per_step": 1e3 * elapsed / steps, "value": steps / elapsed, "steps": steps,
-               "schedule": cp.schedule}
+               "schedule": cp.schedule,
+               # host clocks at both ends of the timed region: tools/trace_timed_launches.py picks
+               # this region's launches out of a rocprofv3 kernel trace of the same command
+               "timed_region_ns": {k: [clk0[k], clk1[k]] for k in clk0}}
         if launches > 0:
             avg_ms = scan_ms / launches
             achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9
@@ -636,6 +648,7 @@ def main():
                         f"launches per sweep: 2 (dt) or N/(N-1) (msdt: one first-level "
                         f"contraction serves N-1 mode updates)"})
             out["roofline"] = rl
+        out["timed_region_ns"] = head.get("timed_region_ns")
         if sub:
             out["sub_records"] = sub
         if world == 1 and not args.no_cpu_baseline:
