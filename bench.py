@@ -27,6 +27,9 @@ WORKLOADS = {
     "cp4_s200_r10": ([200, 200, 200, 200], 10),
     "cp4_s400_r20": ([400, 400, 400, 400], 20),
     "cp4_s64_r10": ([64, 64, 64, 64], 10),  # smoke-sized
+    # diagnostics (not BASELINE configs): which of size and rank costs cfg4 its 8 % against cfg2
+    "cp4_s400_r10": ([400, 400, 400, 400], 10),
+    "cp4_s200_r20": ([200, 200, 200, 200], 20),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
@@ -504,7 +507,7 @@ def main():
     # own precision (fp64 storage) at N = 1; the other shard plan at N > 1
     sub = {}
     sub_steps = max(4, min(args.steps, 10))
-    if world == 1 and not args.schedule and args.workload != "cp4_s400_r20":
+    if world == 1 and not args.schedule and not args.workload.startswith("cp4_s400"):
         other = "dt" if schedule == "msdt" else "msdt"
         cp.set_schedule(other)
         r = measure(cp, sub_steps, 2)

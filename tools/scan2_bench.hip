@@ -102,6 +102,18 @@ int run(int64_t M, int K, int R, int rounds) {
                   },
                   (const void *)k_scan_suffix_fast<float, NT, 1>, {}});
   }
+  vs.push_back({"fast, MFMAs of tile 0 only (wrong result: timing)", [=]() {
+                  hipLaunchKernelGGL((k_scan_suffix_fast<float, NT, 17>), dim3((unsigned)n_mt), dim3(256), 0,
+                                     0, V, M, (int64_t)K, M * K, P, n_mt, 1, nblk, nblk, (double *)out, M,
+                                     (int64_t)0, (int64_t)0, R, 1);
+                },
+                (const void *)k_scan_suffix_fast<float, NT, 17>, {}});
+  vs.push_back({"fast, non-temporal stores", [=]() {
+                  hipLaunchKernelGGL((k_scan_suffix_fast<float, NT, 5>), dim3((unsigned)n_mt), dim3(256), 0,
+                                     0, V, M, (int64_t)K, M * K, P, n_mt, 1, nblk, nblk, (double *)out, M,
+                                     (int64_t)0, (int64_t)0, R, 1);
+                },
+                (const void *)k_scan_suffix_fast<float, NT, 5>, {}});
   vs.push_back({"buf  U4 fp64 x40", PERSIST((k_scan_suffix_buf<float, NT, 1>), 40), (const void *)k_scan_suffix_buf<float, NT, 1>, {}});
 #define LEAN(NAME, U_, ACC_, W_, mult)                                                      \
   vs.push_back({NAME, PERSIST((k_scan_suffix_lean<NT, U_, ACC_, W_>), mult),                \
