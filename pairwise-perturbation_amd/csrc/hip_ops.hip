@@ -233,6 +233,8 @@ class HipOps : public Ops {
     }
     const int64_t n_mtiles = (M + 64 * VEC - 1) / (64 * VEC);
     // enough workgroups to fill the chip several times, chunks of >= 8 column blocks
+    // (workgroups per CU x 4 .. 128 instead of 16: 1.60-1.73 ms for the whole [diffV] call at cfg2,
+    // 1.61 at 16 — tools/k10_probe.py, profiles/r03z_k10_geometry.txt: the geometry is not the lever)
     int nchunk = (int)std::min<int64_t>(nkb, std::max<int64_t>(1, ((int64_t)ncu_ * 16 + n_mtiles - 1) / n_mtiles));
     int per = (nkb + nchunk - 1) / nchunk;
     per = std::max(per, std::min(nkb, 8));
