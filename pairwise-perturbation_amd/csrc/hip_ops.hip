@@ -578,6 +578,12 @@ class HipOps : public Ops {
         if (T == 1 && n_mtiles < target)
           nsplit = (int)std::min<int64_t>((target + n_mtiles - 1) / n_mtiles,
                                           std::max(1, nblk / 32));
+        // a batched scan of a small tensor (the second-level mode products of a Tucker sweep:
+        // 400 x 400 x 20 -> 2 row tiles x 20 batches = 40 workgroups, 29 us for 25.6 MB): K-split
+        // down to 4 column blocks per workgroup until there are two workgroups per CU
+        else if (T > 1 && n_mtiles64 * T < ncu_ && (double)M * T * ncols * nblk / 4 * 8.0 < 64e6)
+          nsplit = (int)std::min<int64_t>(((int64_t)ncu_ * 2 + n_mtiles64 * T - 1) / (n_mtiles64 * T),
+                                          std::max(1, nblk / 4));
         if (nsplit < 1) nsplit = 1;
         const int per = (nblk + nsplit - 1) / nsplit;
         nsplit = (nblk + per - 1) / per;
@@ -586,10 +592,10 @@ class HipOps : public Ops {
         int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = out_tstride;
         if (nsplit > 1) {
           dst32 = 0;
-          dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M);
+          dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M * T);
           dst_ns = M;
-          dst_ss = (int64_t)ncols * M;
-          dst_bs = 0;
+          dst_ss = (int64_t)ncols * M * T;
+          dst_bs = (int64_t)ncols * M;
         }
         const int64_t nblocks = (int64_t)n_mtiles * nsplit * T;
         if (nblocks > 0x7fffffff) throw std::runtime_error("ppals: scan grid too large");
@@ -651,6 +657,10 @@ class HipOps : public Ops {
         // loses to the global-load kernel, so it is used for one n-tile / fp64 storage only)
         // (and: K-split scans of an fp64 tensor — few, long work items of half-size blocks — run
         // at 0.80 of peak on the global-load kernel against 0.70 here: tools/r02_f64.sh)
+        // (A two-tile launch of 2-3 workgroups per CU — the first mode product of a Tucker sweep at
+        // cfg5, 625 tiles, 73 us — is a round and a quarter at 2 waves per SIMD; handing it to the
+        // register-lean persistent form with 3 waves, k_scan_suffix_lean<2,4,0,3>, was measured:
+        // 40 HOOI sweeps 0.0446 / 0.0443 s against 0.0442 / 0.0441 s. Not kept.)
         if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
             !(sizeof(TV) == 8 && nsplit > 1)) {
           if (NT == 1) {
@@ -691,9 +701,9 @@ class HipOps : public Ops {
         prof_end();
         HIP_CHECK(hipGetLastError());
         if (nsplit > 1) {
-          hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256)), dim3(256), 0, st_, dst,
-                             nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32, pad.ld,
-                             pad.valid);
+          hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256), (unsigned)T), dim3(256), 0,
+                             st_, dst, nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32,
+                             pad.ld, pad.valid, dst_bs, out_tstride);
           HIP_CHECK(hipGetLastError());
         }
       }

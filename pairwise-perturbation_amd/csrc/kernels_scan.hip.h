@@ -1350,7 +1350,11 @@ __global__ void k_krp_pack(TV *__restrict__ P, int nblk, int NT, int prefix_layo
 // m' = m, or the compact row of stored row m of a padded layout (scan_row_map)
 __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64_t split_stride,
                               int64_t M, int ncols, double *__restrict__ out, int64_t out_mstride,
-                              int64_t out_rstride, int out32, int64_t row_ld, int64_t row_valid) {
+                              int64_t out_rstride, int out32, int64_t row_ld, int64_t row_valid,
+                              int64_t slab_batch_stride = 0, int64_t out_batch_stride = 0) {
+  // blockIdx.y = batch (the K-split of a batched scan: slabs [split][batch][ncols][M])
+  slab += (int64_t)blockIdx.y * slab_batch_stride;
+  const int64_t obatch = (int64_t)blockIdx.y * out_batch_stride;
   const int64_t total = M * ncols;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -1360,7 +1364,7 @@ __global__ void k_slab_reduce(const double *__restrict__ slab, int nsplit, int64
     if (rm.nvalid == 0) continue;
     double s = 0;
     for (int sp = 0; sp < nsplit; sp++) s += slab[sp * split_stride + e];
-    scan_store(out, rm.mo * out_mstride + out_rstride * n, s, out32);
+    scan_store(out, obatch + rm.mo * out_mstride + out_rstride * n, s, out32);
   }
 }
 

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B=pairwise-perturbation_amd/bin
+tools/gpu_steps.sh \
+ "r03aa_tests|1000|python -m pytest tests -m gpu -x -q" \
+ "r03aa_cfg5|200|$B/test_ALS -model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -pp 0 -maxiter 40 -prec 32 -filename gpurun_out/r03aa_cfg5_tucker.csv" \
+ "r03aa_cfg5b|200|$B/test_ALS -model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -pp 0 -maxiter 40 -prec 32 -filename gpurun_out/r03aa_cfg5_tucker_b.csv"

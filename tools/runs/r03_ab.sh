@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B=pairwise-perturbation_amd/bin
+C="$B/test_ALS -model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -pp 0 -maxiter 40 -prec 32 -filename"
+tools/gpu_steps.sh \
+ "r03ab_tucker_tests|600|python -m pytest tests/test_gpu_tucker.py tests/test_gpu_fullsize.py -x -q" \
+ "r03ab_a1|100|PPALS_SCAN_LEAN_TAIL=0 $C gpurun_out/r03ab_a1.csv" "r03ab_n1|100|$C gpurun_out/r03ab_n1.csv" \
+ "r03ab_a2|100|PPALS_SCAN_LEAN_TAIL=0 $C gpurun_out/r03ab_a2.csv" "r03ab_n2|100|$C gpurun_out/r03ab_n2.csv"
