@@ -873,9 +873,16 @@ void CpEngine::ms_set_roots(int k) {
 
 // room for the placement candidates of X (ms_start_step): none for small tensors, where a scan is
 // too short to time from the host and the effect does not matter
+// tensors below this size are not worth a placement measurement (their scans are short against the
+// host-side timing); PPALS_PLACE_MIN_MB lowers it so that the CPU tests exercise the machinery
+double CpEngine::place_min_bytes() {
+  const char *e = std::getenv("PPALS_PLACE_MIN_MB");
+  return e ? std::atof(e) * 1048576.0 : 1.5e9;
+}
+
 size_t CpEngine::ms_X_slack() const {
   const double bytes = (double)V_.nloc * dtype_size(V_.dtype);
-  return bytes >= 1.5e9 ? ((size_t)64 << 20) + 4096 : 0;
+  return bytes >= place_min_bytes() ? ((size_t)64 << 20) + 4096 : 0;
 }
 
 // Candidate result blocks for the placement measurement, spread over the device memory: between two
@@ -1133,7 +1140,7 @@ void CpEngine::ms_start_step(int first) {
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
     // (worth measuring only where the result stream matters: an HBM-bound scan — up to two
     // n-tiles — that writes at least 1 % of what it reads)
-    if (bytes >= 1.5e9 && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
+    if (bytes >= place_min_bytes() && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
       const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
       const int reps = large ? 1 : 2;
       const int verbose = getenv("PPALS_DEBUG_ADDR") ? std::atoi(getenv("PPALS_DEBUG_ADDR")) : 0;
@@ -1154,6 +1161,10 @@ void CpEngine::ms_start_step(int first) {
             ops_.sync();
             tmin = std::min(tmin, now() - t0);
           }
+          // (tests: odd roots are made to prefer the given further block, so that the paths that
+          // keep, share and free candidate blocks run on the CPU stand-in as well)
+          if (const char *e = std::getenv("PPALS_PLACE_PREFER_BLOCK"))
+            if ((first & 1) && (int)b == std::atoi(e)) tmin *= 1e-3;
           if (verbose >= 2)
             fprintf(stderr, "[ppals] root %d: X %p +%lld MB %.3f ms\n", first, base, (long long)mb,
                     tmin * 1e3);

@@ -182,6 +182,7 @@ class CpEngine {
   bool ms_tuned_[MAX_ORDER] = {false};
   bool ms_tune_enabled_ = true;
   size_t ms_X_slack() const;
+  static double place_min_bytes();
   size_t ms_X_bytes(int first, int k) const;
   bool ms_tuning_now_ = false;  // placement is measured at session set-up only
   void *big_alloc(size_t bytes);  // gives optional resident layouts back when the device is full

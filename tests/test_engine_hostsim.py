@@ -81,3 +81,39 @@ def test_context_destroyed_before_its_children(pp):
     k.close()
     s.close()
     t.close()
+
+
+def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
+    """the set-up measurement of the multi-sweep schedule (candidate result blocks, copies of the
+    second resident layout, store kind per root: engine.cpp ms_alloc_candidates /
+    ms_tune_second_layout) only chooses WHERE buffers lie: with the size threshold lowered so that a
+    small tensor goes through all of it, sweeps give bit-identical factors to a session that
+    measured nothing — and the machinery runs under the sanitizer build (test_sanitizers.py)"""
+    lens, R = [9, 8, 7, 6], 3
+    W0 = pp.init_factors(lens, R, 5)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = pp.Context(0)
+        t = pp.Tensor(c, lens, 1).fill_uniform(11)
+        s = pp.CP(c, t, R)
+        s.set_factors(W0)
+        s.sweeps_dt(4)
+        out = [w.copy() for w in s.get_factors()]
+        s.close()
+        t.close()
+        c.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    plain = run({"PPALS_PLACE_TUNE": "0"})
+    tuned = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_SPACER_MB": "1", "PPALS_PLACE_BLOCKS": "3",
+                 "PPALS_PLACE_LAYOUTS": "3"})
+    one = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_BLOCKS": "1", "PPALS_PLACE_LAYOUTS": "1",
+               "PPALS_PLACE_COMMON": "1"})
+    mixed = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_SPACER_MB": "1", "PPALS_PLACE_BLOCKS": "4",
+                 "PPALS_PLACE_LAYOUTS": "2", "PPALS_PLACE_PREFER_BLOCK": "2"})   # odd roots elsewhere
+    for a, b, c_, d in zip(plain, tuned, one, mixed):
+        assert (a == b).all() and (a == c_).all() and (a == d).all()

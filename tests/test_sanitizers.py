@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 
 SELECT = ("dt_sweeps_match or driver_pp_matches or normalize_and_owed or pp_operator_after or "
           "tucker_pp_driver or hosvd_and_dt or schedule_switch or tensor_refill or "
-          "context_destroyed or driver_pp_partupdate")
+          "context_destroyed or driver_pp_partupdate or placement_measurement")
 
 
 def test_hostsim_suites_under_asan_ubsan():
