@@ -1071,8 +1071,10 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 //   A[i = lane&15][kk = lane>>4] = P[16*kb + i, 4*rb + kk]   (packed: one 8-byte load per lane)
 //   B[kk = lane>>4][j = lane&15] = Q[m0 + VEC*j + jj, 4*rb + kk]   (tile-invariant registers)
 //   D[i = (lane>>4) + 4*reg][j]  -> the lane's element (row VEC*j + jj, column 16*kb + 4*reg + g)
-// which is exactly where its 16-byte tensor loads put V. 2*ceil(R/4)*4 flops per element at the
-// fp64 matrix rate keep the pipe ~40 % busy at HBM speed. Needs M % VEC == 0, R <= 32.
+// which is exactly where its 16-byte tensor loads put V. 2*ceil(R/4)*4 flops per element: at the
+// 46 TFLOP/s this instruction sustains on an MI355X (tools/mfma64_rate.hip; not the data sheet's
+// 78.6) the pipe is busy 0.83 ms per 6.4 GB at R = 10, beside 0.96 ms for the read alone — the
+// kernel is bound by both (1.31 ms). Needs M % VEC == 0, R <= 32.
 template <typename TV, int MODE, int MAXRB>
 __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M, int64_t K,
                                                    const double *__restrict__ Q,
