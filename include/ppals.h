@@ -178,14 +178,16 @@ int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sw
 /* The low-rank-update optimizers (run.cxx:401-407, `-pp 2` / `-pp 3`): CPDTLROptimizer
  * (cp_dt_lr_optimizer.cxx:170-236, 0.5 sweep/step) and CPMSDTLROptimizer
  * (cp_msdt_lr_optimizer.cxx:163-205, (N-1)/N sweep/step) with update_rank = run.cxx's -updaterank
- * and randomsvd = 0 (get_rankR_update_cholesky with the full SVD, common.cxx:768-786; the
- * randomized variant draws from CTF's generator and is not reproduced). The first contraction of
+ * and randomsvd = run.cxx's -randomsvd: 0 = get_rankR_update_cholesky with the full SVD
+ * (common.cxx:768-786), 1 = with randomized_svd(X, r, 1) (common.cxx:691-709; its R x r start
+ * matrix comes from this library's counter generator — CTF's stream is not reproducible — with a
+ * fixed seed, a fresh block of draws per update, restarted by every call). The first contraction of
  * a step is kept per root and updated with update_rank tensor columns when the contracted factor
  * has changed by a low-rank update only (update_cached_tensor). Single GPU, order >= 3. */
 #define PPALS_OPT_DT_LR 3
 #define PPALS_OPT_MSDT_LR 4
-int ppals_cpd_als_lr(ppals_cp *s, int optimizer, int update_rank, const ppals_cp_opts *o,
-                     double *sweeps, int *iters);
+int ppals_cpd_als_lr(ppals_cp *s, int optimizer, int update_rank, int randomsvd,
+                     const ppals_cp_opts *o, double *sweeps, int *iters);
 
 /* ---- Tucker sessions (als_Tucker.h) ---- */
 int ppals_tucker_create(ppals_ctx *ctx, ppals_tensor *V, const int *ranks, ppals_tucker **out);

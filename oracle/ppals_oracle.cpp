@@ -1763,8 +1763,93 @@ int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wfla
 // X = (M - A gamma) L^-T, X ~ U_r s_r VT_r (leading r singular triplets), VT_r <- VT_r L^-1.
 // Returns Us = U_r diag(s_r) (rows x r) and VT (r x R, row k = k-th right vector): the update of A
 // is Us * VT, and the same pair updates the cached first contraction (update_cached_tensor).
+// Householder QR of an n x k matrix (column-major): returns the thin Q (n x k), X.qr(Q, R) of
+// randomized_svd (common.cxx:697,700). A zero column gives a unit vector (never met in the tests).
+static void thin_q(int n, int k, const vector<double> &A, vector<double> &Q) {
+  vector<double> W(A);
+  vector<vector<double>> vs;
+  for (int j = 0; j < k; j++) {
+    vector<double> v(n, 0.0);
+    double nn = 0;
+    for (int i = j; i < n; i++) nn += W[i + (size_t)n * j] * W[i + (size_t)n * j];
+    nn = std::sqrt(nn);
+    const double a0 = W[j + (size_t)n * j];
+    const double alpha = a0 >= 0 ? -nn : nn;
+    for (int i = j; i < n; i++) v[i] = W[i + (size_t)n * j];
+    v[j] -= alpha;
+    double vn = 0;
+    for (int i = j; i < n; i++) vn += v[i] * v[i];
+    if (vn > 0)
+      for (int c = j; c < k; c++) {
+        double d = 0;
+        for (int i = j; i < n; i++) d += v[i] * W[i + (size_t)n * c];
+        d = 2.0 * d / vn;
+        for (int i = j; i < n; i++) W[i + (size_t)n * c] -= d * v[i];
+      }
+    vs.push_back(v);
+  }
+  Q.assign((size_t)n * k, 0.0);
+  for (int j = 0; j < k; j++) Q[j + (size_t)n * j] = 1.0;
+  for (int j = k - 1; j >= 0; j--) {  // Q = H_0 ... H_{k-1} [I; 0]
+    const vector<double> &v = vs[j];
+    double vn = 0;
+    for (int i = j; i < n; i++) vn += v[i] * v[i];
+    if (!(vn > 0)) continue;
+    for (int c = 0; c < k; c++) {
+      double d = 0;
+      for (int i = j; i < n; i++) d += v[i] * Q[i + (size_t)n * c];
+      d = 2.0 * d / vn;
+      for (int i = j; i < n; i++) Q[i + (size_t)n * c] -= d * v[i];
+    }
+  }
+}
+static const uint64_t LR_RANDOM_SEED = 0x52414e44535644ull;  // the engine's (engine.cpp)
+// randomized_svd(A = X, U, s, VT2, r, iter = 1) (common.cxx:691-709): X is rows x R; the R x r start
+// matrix takes draw block `block` of the counter generator (CTF's fill_random is not reproducible).
+// Returns Us = U diag(s) (rows x r) and VT2 (r x R).
+static void randomized_svd_x(i64 rows, int R, int r, const vector<double> &X, uint64_t block,
+                             vector<double> &Us, vector<double> &VT2) {
+  vector<double> Om((size_t)R * r), Q, Xp((size_t)R * r), XQ((size_t)rows * r);
+  for (int k = 0; k < r; k++)
+    for (int a = 0; a < R; a++) Om[a + (size_t)R * k] = u01(LR_RANDOM_SEED, block * (uint64_t)(R * r) + a + (uint64_t)R * k);
+  thin_q(R, r, Om, Q);
+  for (int it = 0; it < 1; it++) {
+    for (int k = 0; k < r; k++)
+      for (i64 i = 0; i < rows; i++) {
+        double v = 0;
+        for (int l = 0; l < R; l++) v += X[i + rows * l] * Q[l + (size_t)R * k];
+        XQ[i + rows * k] = v;
+      }
+    for (int k = 0; k < r; k++)
+      for (int j = 0; j < R; j++) {
+        double v = 0;
+        for (i64 i = 0; i < rows; i++) v += X[i + rows * j] * XQ[i + rows * k];
+        Xp[j + (size_t)R * k] = v;
+      }
+    thin_q(R, r, Xp, Q);
+  }
+  vector<double> B((size_t)rows * r), U((size_t)rows * r), sv(r), Vb((size_t)r * r);
+  for (int k = 0; k < r; k++)
+    for (i64 i = 0; i < rows; i++) {
+      double v = 0;
+      for (int l = 0; l < R; l++) v += X[i + rows * l] * Q[l + (size_t)R * k];
+      B[i + rows * k] = v;
+    }
+  jacobi_svd((int)rows, r, B.data(), U.data(), sv.data(), Vb.data());
+  Us.assign((size_t)rows * r, 0.0);
+  VT2.assign((size_t)r * R, 0.0);
+  for (int k = 0; k < r; k++) {
+    for (i64 i = 0; i < rows; i++) Us[i + rows * k] = U[i + rows * k] * sv[k];
+    for (int j = 0; j < R; j++) {  // VT2[k, j] = sum_l VT[k, l] Q[j, l],  VT[k, l] = Vb[l, k]
+      double v = 0;
+      for (int l = 0; l < r; l++) v += Vb[l + (size_t)r * k] * Q[j + (size_t)R * l];
+      VT2[k + (size_t)r * j] = v;
+    }
+  }
+}
 static void rankR_update_cholesky(int r, i64 rows, int R, const double *M, const double *A,
-                                  const double *gamma, vector<double> &Us, vector<double> &VT) {
+                                  const double *gamma, vector<double> &Us, vector<double> &VT,
+                                  bool random = false, uint64_t block = 0) {
   vector<double> L((size_t)R * R, 0.0);
   for (int j = 0; j < R; j++) {
     double d = gamma[j + R * j];
@@ -1793,11 +1878,20 @@ static void rankR_update_cholesky(int r, i64 rows, int R, const double *M, const
     }
   }
   vector<double> U((size_t)rows * R), sv(R), Vm((size_t)R * R);
-  jacobi_svd((int)rows, R, X.data(), U.data(), sv.data(), Vm.data());
-  Us.assign((size_t)rows * r, 0.0);
+  vector<double> VT2;
+  if (random) {
+    randomized_svd_x(rows, R, r, X, block, Us, VT2);  // xU * xS and xVT of common.cxx:780
+  } else {
+    jacobi_svd((int)rows, R, X.data(), U.data(), sv.data(), Vm.data());
+    Us.assign((size_t)rows * r, 0.0);
+  }
   VT.assign((size_t)r * R, 0.0);
   for (int k = 0; k < r; k++) {
-    for (i64 i = 0; i < rows; i++) Us[i + rows * k] = U[i + rows * k] * sv[k];
+    if (random) {
+      for (int j = 0; j < R; j++) Vm[j + (size_t)R * k] = VT2[k + (size_t)r * j];
+    } else {
+      for (i64 i = 0; i < rows; i++) Us[i + rows * k] = U[i + rows * k] * sv[k];
+    }
     // y L = v_k^T  (row vector): back substitution, L lower triangular
     vector<double> y(R);
     for (int j = R - 1; j >= 0; j--) {
@@ -1826,12 +1920,13 @@ static void lr_update_cached(Ten &cached, const Ten &V, int left, const vector<d
 
 // CPD<double, CPDTLROptimizer>::als / CPD<double, CPMSDTLROptimizer>::als (src/CP.cxx:100-186 with
 // cp_dt_lr_optimizer.cxx:170-236, cp_msdt_lr_optimizer.cxx:163-205; run.cxx:401-407 `-pp 2|3`),
-// randomsvd = 0. kind 3: DT with low-rank updates, kind 4: MSDT with low-rank updates.
+// randomsvd as run.cxx's flag. kind 3: DT with low-rank updates, kind 4: MSDT with low-rank updates.
 int ppo_cpd_als_lr(int N, const int64_t *lens, int R, const double *V, double *Wflat,
-                   double *gradWflat, int kind, int update_rank, double lambda, double tol,
-                   double timelimit, int maxsweep, int resprint, const char *csv_path, int verbose,
-                   double *sweeps_out, int *iters_out) {
+                   double *gradWflat, int kind, int update_rank, int randomsvd, double lambda,
+                   double tol, double timelimit, int maxsweep, int resprint, const char *csv_path,
+                   int verbose, double *sweeps_out, int *iters_out) {
   if ((kind != 3 && kind != 4) || update_rank < 1 || update_rank > R) return -1;
+  uint64_t lr_blocks = 0;  // draw blocks consumed by randomized updates (one per update)
   Factors F = factors(N, lens, R, Wflat), G = factors(N, lens, R, gradWflat);
   Ten Vt = view_of(N, lens, V);
   Log log;
@@ -1871,7 +1966,8 @@ int ppo_cpd_als_lr(int N, const int64_t *lens, int R, const double *V, double *W
     update_S(F, mode, lambda, S.data());
     gradient(rows, R, M.data(), F.W[mode], S.data(), G.W[mode]);
     vector<double> A(base, base + rows * R);
-    rankR_update_cholesky(r, rows, R, M.data(), A.data(), S.data(), Us, VT);
+    rankR_update_cholesky(r, rows, R, M.data(), A.data(), S.data(), Us, VT, randomsvd != 0, lr_blocks);
+    if (randomsvd) lr_blocks++;
     for (int c = 0; c < R; c++)
       for (i64 i = 0; i < rows; i++) {
         double v = A[i + rows * c];

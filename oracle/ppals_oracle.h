@@ -80,9 +80,9 @@ int ppo_cpd_als(int N, const int64_t *lens, int R, const double *V, double *Wfla
  * (cp_dt_lr_optimizer.cxx:170-236), kind 4 CPMSDTLROptimizer (cp_msdt_lr_optimizer.cxx:163-205);
  * update_rank = run.cxx's -updaterank. Returns -1 on a bad argument. */
 int ppo_cpd_als_lr(int N, const int64_t *lens, int R, const double *V, double *Wflat,
-                   double *gradWflat, int kind, int update_rank, double lambda, double tol,
-                   double timelimit, int maxsweep, int resprint, const char *csv_path, int verbose,
-                   double *sweeps_out, int *iters_out);
+                   double *gradWflat, int kind, int update_rank, int randomsvd, double lambda,
+                   double tol, double timelimit, int maxsweep, int resprint, const char *csv_path,
+                   int verbose, double *sweeps_out, int *iters_out);
 
 /* Tucker. ranks[N]; Wflat holds lens[i] x ranks[i] matrices; core is prod(ranks) */
 void ppo_ttmc(int N, const int64_t *lens, const int *ranks, const double *V, const double *Wflat,

@@ -1422,7 +1422,73 @@ void CpEngine::lr_step_begin(int left, bool reuse, int r) {
 }
 
 // One mode update of an LR step. r == 0: the exact update (cholesky_solve in the reference).
-// r > 0: get_rankR_update_cholesky (common.cxx:768-786, random == false) relative to `base`
+// Host helpers of the randomized variant (small dense algebra, R x r and r x r).
+// Orthonormal basis of the columns of A (n x k, column-major, in place): modified Gram-Schmidt,
+// twice (the second pass restores orthogonality to rounding when the columns are nearly dependent);
+// a column that vanishes is left zero.
+static void host_qr_mgs2(int n, int k, double *A) {
+  for (int j = 0; j < k; j++) {
+    double *aj = A + (size_t)n * j;
+    for (int pass = 0; pass < 2; pass++)
+      for (int p = 0; p < j; p++) {
+        const double *ap = A + (size_t)n * p;
+        double d = 0;
+        for (int i = 0; i < n; i++) d += ap[i] * aj[i];
+        for (int i = 0; i < n; i++) aj[i] -= d * ap[i];
+      }
+    double nn = 0;
+    for (int i = 0; i < n; i++) nn += aj[i] * aj[i];
+    nn = std::sqrt(nn);
+    for (int i = 0; i < n; i++) aj[i] = nn > 0 ? aj[i] / nn : 0.0;
+  }
+}
+// eigen-decomposition of a symmetric n x n matrix (column-major, destroyed) by cyclic Jacobi:
+// ev descending, V columns = eigenvectors
+static void host_jacobi_eig(int n, double *A, double *ev, double *V) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) V[i + (size_t)n * j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i + (size_t)n * j] * A[i + (size_t)n * j];
+    if (off <= 1e-30 * (diag + 1e-300)) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p + (size_t)n * q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q + (size_t)n * q] - A[p + (size_t)n * p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; k++) {  // columns p, q
+          const double akp = A[k + (size_t)n * p], akq = A[k + (size_t)n * q];
+          A[k + (size_t)n * p] = c * akp - sn * akq;
+          A[k + (size_t)n * q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {  // rows p, q
+          const double apk = A[p + (size_t)n * k], aqk = A[q + (size_t)n * k];
+          A[p + (size_t)n * k] = c * apk - sn * aqk;
+          A[q + (size_t)n * k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double vkp = V[k + (size_t)n * p], vkq = V[k + (size_t)n * q];
+          V[k + (size_t)n * p] = c * vkp - sn * vkq;
+          V[k + (size_t)n * q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; i++) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return A[a + (size_t)n * a] > A[b + (size_t)n * b]; });
+  std::vector<double> Vs((size_t)n * n);
+  for (int k = 0; k < n; k++) {
+    ev[k] = A[idx[k] + (size_t)n * idx[k]];
+    for (int i = 0; i < n; i++) Vs[i + (size_t)n * k] = V[i + (size_t)n * idx[k]];
+  }
+  std::copy(Vs.begin(), Vs.end(), V);
+}
+static const uint64_t LR_RANDOM_SEED = 0x52414e44535644ull;  // "RANDSVD"
+
+// r > 0: get_rankR_update_cholesky (common.cxx:768-786; random == true: lr_random_) relative to `base`
 // (device, s x R; null: the current W_i): gamma = L L^T, X = (M - base gamma) L^-T, its leading r
 // singular triplets, W_i = base + (U_r s_r)(VT_r L^-1). Leaves Us = U_r s_r in lr_Us_ (s x r) and
 // VT in lr_small_ (r x R) for the next lr_step_begin. The R x R algebra runs on the host.
@@ -1488,9 +1554,52 @@ void CpEngine::lr_mode_update(int i, double lambda, int r, const double *base) {
   ops_.h2d(dT1, T1.data(), sizeof(double) * R_ * R_);
   ops_.rows_times_small(negrhs, s, R_, dT1, R_, nullptr, lr_X_);    // X = rhs L^-T
   ops_.gram(lr_X_, s, s, R_, dGX);                                   // X^T X
-  ops_.top_eigvecs(dGX, R_, r, dV);                                  // leading right singular vectors
   std::vector<double> Vr((size_t)R_ * r), VT((size_t)r * R_, 0.0);
-  ops_.d2h(Vr.data(), dV, sizeof(double) * R_ * r);
+  if (!lr_random_) {
+    ops_.top_eigvecs(dGX, R_, r, dV);                                // leading right singular vectors
+    ops_.d2h(Vr.data(), dV, sizeof(double) * R_ * r);
+  } else {
+    // randomized_svd(X, r, iter = 1) (common.cxx:691-709), on the R x R Gram G = X^T X alone:
+    //   Q0 = qr(Omega), Omega ~ U(0,1)^{R x r};  Q = qr(G Q0);  B = X Q;  B = U s Vb^T
+    //   => the rank-r factor is X (Q Vb) (Q Vb)^T: right vectors Q Vb, with Vb the eigenvectors of
+    //   Q^T G Q (r x r). Everything but the two tall products stays on the host. Omega comes from
+    //   the build's counter generator (CTF's stream is not reproducible): seed LR_RANDOM_SEED,
+    //   one block of R*r draws per call.
+    std::vector<double> G((size_t)R_ * R_), Q((size_t)R_ * r), Y((size_t)R_ * r), C((size_t)r * r),
+        Vb((size_t)r * r), ev(r);
+    ops_.d2h(G.data(), dGX, sizeof(double) * R_ * R_);
+    const uint64_t base_idx = lr_random_calls_++ * (uint64_t)(R_ * r);
+    for (int k = 0; k < r; k++)
+      for (int a = 0; a < R_; a++) Q[a + (size_t)R_ * k] = u01_host(LR_RANDOM_SEED, base_idx + a + (uint64_t)R_ * k);
+    host_qr_mgs2(R_, r, Q.data());
+    for (int k = 0; k < r; k++)
+      for (int a = 0; a < R_; a++) {
+        double v = 0;
+        for (int b = 0; b < R_; b++) v += G[a + (size_t)R_ * b] * Q[b + (size_t)R_ * k];
+        Y[a + (size_t)R_ * k] = v;
+      }
+    host_qr_mgs2(R_, r, Y.data());  // Y = Q of the second factorisation
+    for (int k = 0; k < r; k++)     // C = Y^T G Y
+      for (int l = 0; l < r; l++) {
+        double v = 0;
+        for (int a = 0; a < R_; a++) {
+          double ga = 0;
+          for (int b = 0; b < R_; b++) ga += G[a + (size_t)R_ * b] * Y[b + (size_t)R_ * l];
+          v += Y[a + (size_t)R_ * k] * ga;
+        }
+        C[k + (size_t)r * l] = v;
+      }
+    for (int k = 0; k < r; k++)  // exactly symmetric input for the Jacobi sweeps
+      for (int l = k + 1; l < r; l++) C[k + (size_t)r * l] = C[l + (size_t)r * k] = 0.5 * (C[k + (size_t)r * l] + C[l + (size_t)r * k]);
+    host_jacobi_eig(r, C.data(), ev.data(), Vb.data());
+    for (int k = 0; k < r; k++)
+      for (int a = 0; a < R_; a++) {
+        double v = 0;
+        for (int l = 0; l < r; l++) v += Y[a + (size_t)R_ * l] * Vb[l + (size_t)r * k];
+        Vr[a + (size_t)R_ * k] = v;
+      }
+    ops_.h2d(dV, Vr.data(), sizeof(double) * R_ * r);
+  }
   for (int k = 0; k < r; k++)  // VT[k, :] = v_k^T L^-1
     for (int c = 0; c < R_; c++) {
       double v = 0;
@@ -1516,6 +1625,8 @@ int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iter
     for (int m = 0; m < MAX_ORDER; m++) lr_have_[m] = false;
     for (auto &nd : nodes_) nd.valid = false;
     ms_invalidate();
+    lr_random_ = o.randomsvd != 0;
+    lr_random_calls_ = 0;
   }
   // CPDTLROptimizer state (cp_dt_optimizer.cxx:24-37, cp_dt_lr_optimizer.cxx:9-33)
   bool lr_first = true, lr_low = false;

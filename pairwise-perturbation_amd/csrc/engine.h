@@ -59,6 +59,7 @@ struct CpOpts {
   double tol_init = 1e-2, ratio_step = 1.0;
   double update_percentage = 1.0;  // -pp 2: fraction of the modes updated per PP sweep
   int update_rank = 0;             // class API, low-rank-update optimizers (run.cxx -updaterank)
+  int randomsvd = 0;               // ... and their randomized range finder (run.cxx -randomsvd)
   std::string csv_path;
   bool csv_append = false;
   bool verbose = false;
@@ -197,6 +198,8 @@ class CpEngine {
   void lr_release();
   void *lr_cache_[MAX_ORDER] = {nullptr};
   bool lr_have_[MAX_ORDER] = {false};
+  bool lr_random_ = false;        // randomized_svd in the rank-r update (common.cxx:691-709)
+  uint64_t lr_random_calls_ = 0;  // blocks of R*r draws consumed in this run
   RTensor lr_desc_[MAX_ORDER];
   void *ms_X_override_ = nullptr;  // ms_start_step writes the first-level intermediate here
   double *lr_X_ = nullptr, *lr_Us_ = nullptr, *lr_G2_ = nullptr, *lr_small_ = nullptr;

@@ -418,16 +418,18 @@ int ppals_cpd_als(ppals_cp *s, int optimizer, const ppals_cp_opts *o, double *sw
   API_END(PPALS_ERR_HIP)
 }
 
-int ppals_cpd_als_lr(ppals_cp *s, int optimizer, int update_rank, const ppals_cp_opts *o,
-                     double *sweeps, int *iters) {
+int ppals_cpd_als_lr(ppals_cp *s, int optimizer, int update_rank, int randomsvd,
+                     const ppals_cp_opts *o, double *sweeps, int *iters) {
   if (!s || !s->eng || !o) return fail(PPALS_ERR_ARG, "NULL argument");
   if (optimizer != PPALS_OPT_DT_LR && optimizer != PPALS_OPT_MSDT_LR)
     return fail(PPALS_ERR_ARG, "optimizer must be PPALS_OPT_DT_LR or PPALS_OPT_MSDT_LR");
   if (update_rank < 1 || update_rank > s->eng->rank_r())
     return fail(PPALS_ERR_ARG, "update_rank must be in [1, R]");
+  if (randomsvd < 0 || randomsvd > 1) return fail(PPALS_ERR_ARG, "randomsvd must be 0 or 1");
   API_BEGIN
   CpOpts c = to_opts(o);
   c.update_rank = update_rank;
+  c.randomsvd = randomsvd;
   return s->eng->run_class(optimizer, c, sweeps, iters);
   API_END(PPALS_ERR_HIP)
 }

@@ -38,11 +38,6 @@ int main(int argc, char **argv) {
   }
   if (a.resprint == 0) a.resprint = 10;
   if (a.model[0] == 'C' && (a.pp == 2 || a.pp == 3)) {
-    if (randomsvd) {
-      fprintf(stderr, "-randomsvd 1 (randomized_svd, common.cxx:691-708, seeded by CTF's generator) is "
-                      "not reproduced: run with -randomsvd 0\n");
-      return 2;
-    }
     if (update_rank < 1 || update_rank > a.R) {
       fprintf(stderr, "-updaterank must be in [1, rank] (got %d, rank %d)\n", update_rank, a.R);
       return 2;
@@ -78,8 +73,8 @@ int main(int argc, char **argv) {
     double sweeps = 0;
     int iters = 0;
     if (a.pp == 2 || a.pp == 3) {
-      CHECK(ppals_cpd_als_lr(cp, a.pp == 2 ? PPALS_OPT_DT_LR : PPALS_OPT_MSDT_LR, update_rank, &opt,
-                             &sweeps, &iters));
+      CHECK(ppals_cpd_als_lr(cp, a.pp == 2 ? PPALS_OPT_DT_LR : PPALS_OPT_MSDT_LR, update_rank,
+                             randomsvd, &opt, &sweeps, &iters));
     } else {
       const int optimizer = a.pp == 0 ? PPALS_OPT_DT : (a.pp == 1 ? PPALS_OPT_MSDT : PPALS_OPT_SIMPLE);
       CHECK(ppals_cpd_als(cp, optimizer, &opt, &sweeps, &iters));

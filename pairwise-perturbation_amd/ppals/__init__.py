@@ -347,14 +347,14 @@ class CP:
                                         C.byref(it)))
         return rc, sw.value, it.value
 
-    def cpd_als_lr(self, optimizer, update_rank, **kw):
-        """CPD<dtype, CPDTLROptimizer / CPMSDTLROptimizer>::als (optimizer 3 / 4), randomsvd = 0.
-        Returns (rc, sweeps, iters)."""
+    def cpd_als_lr(self, optimizer, update_rank, randomsvd=0, **kw):
+        """CPD<dtype, CPDTLROptimizer / CPMSDTLROptimizer>::als (optimizer 3 / 4); randomsvd as
+        run.cxx's flag. Returns (rc, sweeps, iters)."""
         o = _opts(**kw)
         it = C.c_int(0)
         sw = C.c_double(0)
-        rc = _check(lib().ppals_cpd_als_lr(self._h, int(optimizer), int(update_rank), C.byref(o),
-                                           C.byref(sw), C.byref(it)))
+        rc = _check(lib().ppals_cpd_als_lr(self._h, int(optimizer), int(update_rank), int(randomsvd),
+                                           C.byref(o), C.byref(sw), C.byref(it)))
         return rc, sw.value, it.value
 
     def run_pp_partupdate(self, **kw):

@@ -257,9 +257,9 @@ def cpd_als(V, Ws, gradWs, kind, tol, maxsweep, lam=0.0, csv=None, resprint=10, 
 
 
 def cpd_als_lr(V, Ws, gradWs, kind, update_rank, tol, maxsweep, lam=0.0, csv=None, resprint=10,
-               timelimit=5e3):
-    """class API with the low-rank-update optimizers (randomsvd = 0): kind 3 CPDTLROptimizer,
-    4 CPMSDTLROptimizer; update_rank = run.cxx's -updaterank. Returns (rc, sweeps, iters, W, gradW)."""
+               timelimit=5e3, randomsvd=0):
+    """class API with the low-rank-update optimizers: kind 3 CPDTLROptimizer, 4 CPMSDTLROptimizer;
+    update_rank / randomsvd = run.cxx's -updaterank / -randomsvd. Returns (rc, sweeps, iters, W, gradW)."""
     lens = V.shape
     R = Ws[0].shape[1]
     wf, gf = flat(Ws), flat(gradWs)
@@ -268,8 +268,8 @@ def cpd_als_lr(V, Ws, gradWs, kind, update_rank, tol, maxsweep, lam=0.0, csv=Non
     iters = C.c_int(0)
     f = lib().ppo_cpd_als_lr
     f.restype = C.c_int
-    rc = f(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf), kind, update_rank, C.c_double(lam),
-           C.c_double(tol), C.c_double(timelimit), maxsweep, resprint,
+    rc = f(len(lens), _lens(lens), R, _dp(Vf), _dp(wf), _dp(gf), kind, update_rank, int(randomsvd),
+           C.c_double(lam), C.c_double(tol), C.c_double(timelimit), maxsweep, resprint,
            (csv.encode() if csv else None), 0, C.byref(sweeps), C.byref(iters))
     assert rc >= 0, "bad argument"
     return (rc, sweeps.value, iters.value, unflat(wf, lens, [R] * len(lens)),

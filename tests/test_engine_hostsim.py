@@ -40,6 +40,7 @@ test_random_larger_shapes_against_oracle = G.test_random_larger_shapes_against_o
 test_class_api_als_matches_oracle = G.test_class_api_als_matches_oracle
 test_class_api_reference_test_case = G.test_class_api_reference_test_case
 test_class_api_low_rank_optimizers = G.test_class_api_low_rank_optimizers
+test_class_api_low_rank_optimizers_randomsvd = G.test_class_api_low_rank_optimizers_randomsvd
 test_tensor_refill_while_session_alive = G.test_tensor_refill_while_session_alive
 test_bench_mode_matches_oracle = G.test_bench_mode_matches_oracle
 test_long_run_factor_parity = G.test_long_run_factor_parity

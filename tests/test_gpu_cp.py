@@ -866,8 +866,24 @@ def test_rank_above_64_non_spd_fallback(pp, monkeypatch):
                                              ([10, 8, 9], 4, 1, 2), ([6, 5, 4, 5, 4], 2, 1, 1),
                                              ([12, 10, 9, 11], 5, 0, 2)])
 def test_class_api_low_rank_optimizers(pp, ctx, lens, R, dtype, ur, kind, tmp_path):
+    _low_rank_case(pp, ctx, lens, R, dtype, ur, kind, tmp_path, 0)
+
+
+@pytest.mark.parametrize("kind", [3, 4])
+@pytest.mark.parametrize("lens,R,dtype,ur", [([8, 7, 6, 5], 3, 1, 1), ([8, 7, 6, 5], 3, 1, 3),
+                                             ([10, 8, 9], 4, 1, 2), ([12, 10, 9, 11], 5, 0, 2)])
+def test_class_api_low_rank_optimizers_randomsvd(pp, ctx, lens, R, dtype, ur, kind, tmp_path):
+    """the same with -randomsvd 1: get_rankR_update_cholesky through randomized_svd(X, r, 1)
+    (common.cxx:691-709, :780). The oracle follows the reference line by line on the tall matrix
+    (Householder QR, one-sided Jacobi SVD of X Q); the engine works on the R x R Gram (Gram-Schmidt,
+    eigenvectors of Q^T G Q) — the update U s VT they produce is the same projector X Q Q^T. Both
+    draw the start matrix from the counter generator (same seed, one block per update)."""
+    _low_rank_case(pp, ctx, lens, R, dtype, ur, kind, tmp_path, 1)
+
+
+def _low_rank_case(pp, ctx, lens, R, dtype, ur, kind, tmp_path, randomsvd):
     """CPD<double, CPDTLROptimizer>::als / CPD<double, CPMSDTLROptimizer>::als (run.cxx -pp 2 / 3,
-    -updaterank ur, randomsvd = 0; src/optimizer/cp_dt_lr_optimizer.cxx:170-236,
+    -updaterank ur, -randomsvd; src/optimizer/cp_dt_lr_optimizer.cxx:170-236,
     cp_msdt_lr_optimizer.cxx:163-205, get_rankR_update_cholesky common.cxx:768-786): same CSV rows
     (fractional sweep counter, gradnorm, residual), sweep and step counts and factors as the
     oracle's restatement; with ur = R the low-rank update IS the exact one, so the run must also
@@ -879,11 +895,11 @@ def test_class_api_low_rank_optimizers(pp, ctx, lens, R, dtype, ur, kind, tmp_pa
     kw = dict(tol=1e-9 * Vn, resprint=1)
     maxsweep = 12
     rc_ref, sw_ref, it_ref, W_ref, G_ref = O.cpd_als_lr(V, W, G, kind, ur, maxsweep=maxsweep,
-                                                        csv=c_ref, **kw)
+                                                        csv=c_ref, randomsvd=randomsvd, **kw)
     t = pp.Tensor(ctx, lens, dtype).upload(V)
     s = pp.CP(ctx, t, R)
     s.set_factors(W, G)
-    rc, sw, it = s.cpd_als_lr(kind, ur, maxiter=maxsweep, csv=c_got, **kw)
+    rc, sw, it = s.cpd_als_lr(kind, ur, randomsvd, maxiter=maxsweep, csv=c_got, **kw)
     assert (rc, it) == (rc_ref, it_ref) and abs(sw - sw_ref) < 1e-12
     ftol = FTOL[dtype] * 10
     W_got, G_got = s.get_factors(with_grad=True)
@@ -903,5 +919,7 @@ def test_class_api_low_rank_optimizers(pp, ctx, lens, R, dtype, ur, kind, tmp_pa
             assert relerr(a, b) < 1e-7, relerr(a, b)
     with pytest.raises(pp.PpalsError):
         s.cpd_als_lr(kind, R + 1, maxiter=2)
+    with pytest.raises(pp.PpalsError):
+        s.cpd_als_lr(kind, ur, 2, maxiter=2)
     s.close()
     t.close()

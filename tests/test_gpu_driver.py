@@ -155,8 +155,8 @@ def test_run_driver_class_api(BIN, tmp_path, pp, kind):
 @pytest.mark.parametrize("pp,kind,ur", [(2, 3, 2), (3, 4, 1)])
 def test_run_driver_low_rank_optimizers(BIN, tmp_path, pp, kind, ur):
     """bin/run -pp 2 / -pp 3 (run.cxx:401-411): CPD<double, CPDTLROptimizer / CPMSDTLROptimizer> with
-    -updaterank, CSV rows against the oracle's restatement; -randomsvd 1 (CTF's generator) and an
-    update rank above the CP rank are refused with exit code 2"""
+    -updaterank (and once more with -randomsvd 1), CSV rows against the oracle's restatement; an
+    update rank above the CP rank is refused with exit code 2"""
     s, R, N = 10, 3, 4
     csv = str(tmp_path / "out.csv")
     out = run([os.path.join(BIN, "run"), "-model", "CP", "-tensor", "r", "-dim", str(N), "-size",
@@ -177,7 +177,20 @@ def test_run_driver_low_rank_optimizers(BIN, tmp_path, pp, kind, ur):
         assert a[:2] == b[:2] and a[4] == b[4] == 0
         assert abs(a[2] - b[2]) <= 1e-4 * abs(a[2]) + 1e-7
         assert abs(a[5] - b[5]) <= 1e-4 * abs(a[5]) + 1e-7 * Vn
-    for extra, msg in ((["-randomsvd", "1"], "randomsvd"), (["-updaterank", "9"], "updaterank")):
+    csv2, ref2 = str(tmp_path / "out_rnd.csv"), str(tmp_path / "ref_rnd.csv")
+    out = run([os.path.join(BIN, "run"), "-model", "CP", "-tensor", "r", "-dim", str(N), "-size",
+               str(s), "-rank", str(R), "-pp", str(pp), "-updaterank", str(ur), "-randomsvd", "1",
+               "-maxiter", "8", "-resprint", "1", "-tol", "1e-9", "-filename", csv2, "-prec", "64"])
+    assert "  randomsvd=  1" in out.splitlines()
+    O.cpd_als_lr(V, W, G, kind, ur, tol=1e-9 * Vn, maxsweep=8, csv=ref2, resprint=1, randomsvd=1)
+    h1, r1 = O.read_csv(ref2)
+    h2, r2 = O.read_csv(csv2)
+    assert h1 == h2 and len(r1) == len(r2) >= 9
+    for a, b in zip(r1, r2):
+        assert a[:2] == b[:2] and a[4] == b[4] == 0
+        assert abs(a[2] - b[2]) <= 1e-4 * abs(a[2]) + 1e-7
+        assert abs(a[5] - b[5]) <= 1e-4 * abs(a[5]) + 1e-7 * Vn
+    for extra, msg in ((["-updaterank", "9"], "updaterank"),):
         p = subprocess.run([os.path.join(BIN, "run"), "-tensor", "r", "-dim", "4", "-size", "8",
                             "-rank", "3", "-pp", str(pp), "-filename", str(tmp_path / "o.csv")] + extra,
                            capture_output=True, text=True, timeout=120)
