@@ -577,7 +577,7 @@ def main():
             r["sweep_flops"] = sweep_flops(lens4, R4, cp4.schedule)
             r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
             if "roofline" in r:
-                r["roofline"]["kernel"] = "k_scan_suffix_fast<float,2,1> (two n-tiles)"
+                r["roofline"]["kernel"] = "k_scan_suffix_fast<float,2,5> (two n-tiles, non-temporal result stores)"
                 r["roofline"]["traffic"] = None
                 r["roofline"]["traffic_replayed"] = _replayed_traffic("cp4_s400_r20/f32/1")
             sub["cfg4_1gpu"] = r
