@@ -48,6 +48,28 @@ __device__ inline double block_sum(double v, double *lds /* >= 17 doubles */) {
   return lds[16];
 }
 
+// A workgroup barrier for phases that hand data over through LDS only: it does not wait for the
+// workgroup's outstanding GLOBAL stores, which a __syncthreads() does (its fence covers every address
+// space: ~1 us after a burst of stores, measured in k_cp_mode_update with tools/update_bench.hip).
+__device__ inline void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// block_sum with ONE such barrier (a barrier of 16 waves costs ~0.4 us: update_bench phase stamps):
+// every thread adds the waves' partial sums itself, in the same order. `slot` (16 doubles) must not
+// be written again before another barrier has been passed.
+__device__ inline double block_sum_lds(double v, double *slot /* 16 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  if (lane == 0) slot[wave] = v;
+  lds_barrier();
+  double s = 0;
+  for (int w = 0; w < nw; w++) s += slot[w];
+  return s;
+}
+
 __global__ void k_sum_partials(const double *__restrict__ part, int n, double *__restrict__ out) {
   __shared__ double lds[17];
   double s = 0;
@@ -1242,6 +1264,15 @@ struct NormArgs {
 // the lanes of a result register run along i: stores to grad / W are 128-byte segments.
 // presolved: S and S^-1 were prepared by the preceding contraction's launch (SysArgs) and are
 // read from S_out / Sinv_out instead of being computed here.
+// (tools/update_bench.hip defines PPALS_UPDATE_STAMPS: thread 0 writes the 100 MHz device clock at
+// the phase boundaries of the launch into g_update_stamps — where the microseconds go)
+#ifdef PPALS_UPDATE_STAMPS
+__device__ unsigned long long g_update_stamps[16];
+#define PPALS_STAMP(i) \
+  if (threadIdx.x == 0) g_update_stamps[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PPALS_STAMP(i)
+#endif
 template <bool STAGE, bool MF = false>
 __global__ __launch_bounds__(1024) void k_cp_mode_update(
     double *__restrict__ Gall, int N, int mode, int R, double lambda, const double *__restrict__ M,
@@ -1264,6 +1295,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   double *sW = sM + (STAGE ? rows * R : 0);
   const int64_t total = rows * R;
   const int rows_i = (int)rows, total_i = (int)total;  // launcher: rows * R < 2^31 (32-bit index math)
+  PPALS_STAMP(0);
 
   if (presolved) {
     // S, S^-1 come from the launch before this one; M and the pre-update W are staged by everybody
@@ -1308,6 +1340,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       }
   }
 
+  PPALS_STAMP(1);  // S, S^-1, M, W in LDS
   double gs = 0, dd = 0;
   if constexpr (STAGE && MF) {
     const int g4 = lane >> 4, l16 = lane & 15;
@@ -1354,8 +1387,12 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
         }
       }
       if (phase == 0) {
-        gs = block_sum(gs, red);  // also the barrier between reading W_old and writing W_new
+        PPALS_STAMP(2);  // gradient tiles done (this wave)
+        // (also the barrier between reading W_old and writing W_new in LDS; the gradient's global
+        // stores stay in flight across it)
+        gs = block_sum_lds(gs, red);
         if (tid == 0) *gradsq = gs;
+        PPALS_STAMP(3);
       }
     }
   } else {
@@ -1393,13 +1430,89 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
   }
   }
   if (dwsq) {  // ||dW||^2 for the restart test of the PP phase (block-uniform branch)
-    dd = block_sum(dd, red);
+    dd = (STAGE && MF) ? block_sum_lds(dd, red + 16) : block_sum(dd, red);
     if (tid == 0) *dwsq = dd;
   }
-  __syncthreads();  // W_new visible to the whole workgroup (LDS, or same CU's L1)
-  // G_mode = W^T W: one wave per (p <= q) pair
+  PPALS_STAMP(4);  // solve tiles done (this wave)
+  if constexpr (STAGE && MF)
+    lds_barrier();  // W_new complete in LDS (its global stores need not have landed)
+  else
+    __syncthreads();  // W_new visible to the whole workgroup (LDS, or same CU's L1)
+  PPALS_STAMP(5);
   double *G = Gall + (int64_t)mode * R * R;
   const int nw = blockDim.x >> 6;
+  if constexpr (STAGE && MF) {
+    // G_mode = W^T W on the matrix cores out of LDS: the row range is split over `nks` waves, each
+    // accumulates the 16 x 16 tiles of the upper triangle over its rows, the partial tiles meet in
+    // the LDS area of M (dead by now) and are added in a fixed order. (One wave per column pair and a
+    // 64-lane dot product each took 2.6 us of a 8.6 us kernel at R = 10 and 12 of 29 us at R = 20:
+    // tools/update_bench.hip, profiles/r03ah_update_phases.txt.)
+    const int g4 = lane >> 4, l16 = lane & 15;
+    const int ntg = (R + 15) / 16, ntile = ntg * (ntg + 1) / 2;
+    const int cap = (int)((rows * R) / (ntile * 256));  // partial tiles that fit into sM
+    const int nks = cap < 1 ? 0 : (cap < nw ? cap : nw);
+    if (nks > 0) {
+      const int ksteps = (rows_i + 3) / 4, spw = (ksteps + nks - 1) / nks;
+      if (wave < nks) {
+        const int s0 = wave * spw, s1 = (s0 + spw < ksteps) ? s0 + spw : ksteps;
+        int t = 0;
+        for (int tp = 0; tp < ntg; tp++)
+          for (int tq = tp; tq < ntg; tq++, t++) {
+            const int ca = 16 * tp + l16, cb = 16 * tq + l16;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};  // two chains in flight
+            for (int ks = s0; ks < s1; ks += 2) {
+              const int k = 4 * ks + g4, k2 = k + 4;
+              const bool kin = k < rows_i, kin2 = (ks + 1 < s1) && k2 < rows_i;
+              const double a = (kin && ca < R) ? sW[k + rows_i * ca] : 0.0;
+              const double b = (kin && cb < R) ? sW[k + rows_i * cb] : 0.0;
+              const double a2 = (kin2 && ca < R) ? sW[k2 + rows_i * ca] : 0.0;
+              const double b2 = (kin2 && cb < R) ? sW[k2 + rows_i * cb] : 0.0;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) sM[((wave * ntile + t) * 4 + r) * 64 + lane] = acc[r] + acc2[r];
+          }
+      }
+      lds_barrier();
+      // element (tile t, reg r, lane) = G[16 tp + g4 + 4 r][16 tq + l16]
+      for (int e = tid; e < ntile * 256; e += (int)blockDim.x) {
+        const int t = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        int tp = 0, rem = t;
+        while (rem >= ntg - tp) {
+          rem -= ntg - tp;
+          tp++;
+        }
+        const int tq = tp + rem;
+        const int i = 16 * tp + (ln >> 4) + 4 * r, j = 16 * tq + (ln & 15);
+        if (i < R && j < R && i <= j) {
+          double v = 0;
+          for (int w = 0; w < nks; w++) v += sM[((w * ntile + t) * 4 + r) * 64 + ln];
+          G[i + R * j] = v;
+          G[j + R * i] = v;
+        }
+      }
+    }
+    if (nks == 0) {  // (no room for a single partial tile: the pair loop below)
+      const int npairs0 = R * (R + 1) / 2;
+      for (int e = wave; e < npairs0; e += nw) {
+        int p = 0, rem = e;
+        while (rem >= R - p) {
+          rem -= R - p;
+          p++;
+        }
+        const int q = p + rem;
+        double sacc = 0;
+        for (int i = lane; i < rows_i; i += 64) sacc += sW[i + rows_i * p] * sW[i + rows_i * q];
+        sacc = wave_sum(sacc);
+        if (lane == 0) {
+          G[p + R * q] = sacc;
+          G[q + R * p] = sacc;
+        }
+      }
+    }
+  } else {
+  // G_mode = W^T W: one wave per (p <= q) pair
   const int npairs = R * (R + 1) / 2;
   for (int e = wave; e < npairs; e += nw) {
     int p = 0, rem = e;
@@ -1418,6 +1531,8 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
       G[q + R * p] = sacc;
     }
   }
+  }
+  PPALS_STAMP(6);  // Gram pairs of this wave done
   if constexpr (STAGE) {
     if (nrm.on) {  // (block-uniform) Normalize, common.cxx:644-689, on all N factors
       __threadfence();

@@ -116,7 +116,11 @@ def test_cfg3_pp_phase_pattern_and_factors_full_size(pp, ctx, dtype, tmp_path):
     floor = (2e-5 if dtype == 0 else 1e-9) * Vn
     for got, ref in zip(rows, rows_ref):
         if ref[2] > 100 * floor:
-            assert abs(got[2] - ref[2]) < 2e-3 * ref[2], (got, ref)
+            # (the same absolute term as for diffV below: within a factor of a few of the cut the
+            # gradient norm of an fp32-stored tensor moves by a fraction of the storage floor with
+            # the order of the fp64 sums alone — 0.25 at 119 when the Gram of the mode update went
+            # to the matrix cores)
+            assert abs(got[2] - ref[2]) < 2e-3 * ref[2] + floor, (got, ref)
         if ref[3] > floor:
             assert abs(got[5] - ref[3]) < 2e-3 * ref[3] + floor, (got, ref)
     for a, b in zip(s.get_factors(), W_ref):

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 
+#define PPALS_UPDATE_STAMPS 1
 #include "../pairwise-perturbation_amd/csrc/ops.h"
 #include "../pairwise-perturbation_amd/csrc/kernels_small.hip.h"
 using namespace ppals;
@@ -51,7 +52,7 @@ int main() {
     // variants: 0 = no LDS staging, 1 = staged VALU loops (round 2), 2 = staged + the two row
     // products on the matrix cores, 3 = 2 + S / S^-1 handed in (prepared by the previous launch)
     for (int var = 3; var >= 0; var--)
-      for (int bs : {512, 1024}) {
+      for (int bs : {256, 512, 1024}) {
         // one launch at a time from pristine inputs (repeating the update on its own output
         // drives the Grams out of range and into the Jacobi fallback): median of 40
         std::vector<float> ts;
@@ -85,6 +86,14 @@ int main() {
           float ms;
           CK(hipEventElapsedTime(&ms, e0, e1));
           ts.push_back(ms);
+          if (it == 39 && var == 3) {  // the phase stamps of the last launch (100 MHz clock: 10 ns ticks)
+            unsigned long long st[16];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_update_stamps), sizeof(st)));
+            printf("  phases of thread 0 (us since kernel entry): staged %.2f | grad tiles %.2f | block sum %.2f | "
+                   "solve tiles %.2f | barrier %.2f | Gram %.2f\n",
+                   (st[1] - st[0]) * 0.01, (st[2] - st[0]) * 0.01, (st[3] - st[0]) * 0.01, (st[4] - st[0]) * 0.01,
+                   (st[5] - st[0]) * 0.01, (st[6] - st[0]) * 0.01);
+          }
         }
         std::sort(ts.begin(), ts.end());
         printf("R=%d rows=%lld variant=%d block=%4d: %.2f us per launch (single launch between events, median)\n",
