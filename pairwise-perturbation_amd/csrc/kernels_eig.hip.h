@@ -755,6 +755,10 @@ __global__ void k_tn_two(const double *__restrict__ Z, const double *__restrict_
 // safely positive (numerically rank deficient), 2 = pivots spread by more than 4 (one Cholesky-QR
 // pass leaves an orthogonality error of eps * cond), else 0.
 // dynamic LDS: 2 buffers of n x 2n | T[max(m,1) x cols] | sc[8]
+// Everything the threads exchange goes through LDS, so the barriers are lds_barrier (no wait for the
+// copy of Q_D into Z). 17.7 us at n = 20: twenty dependent pivots of a barrier (~0.4 us with 16 waves)
+// plus the update; a 256-thread workgroup (cheaper barriers, 3 elements per thread) was measured
+// slower, 22.3 us (tools/runs/r03_ai.sh).
 __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const double *__restrict__ QD,
                                                  int64_t J, int cols, int m,
                                                  const double *__restrict__ C, double *__restrict__ M,
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const d
   for (int64_t e = tid; e < J * m; e += nthr) Z[e] = QD[e];
   const double *tg = C + cols * cols;
   for (int e = tid; e < m * cols; e += nthr) T[e] = tg[e];
-  __syncthreads();
+  lds_barrier();
   for (int e = tid; e < n * w2; e += nthr) {
     const int i = e / w2, j = e - i * w2;
     double v;
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const d
     }
     E0[e] = v;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) {
     double dmax = 0;
     for (int k = 0; k < n; k++) dmax = fmax(dmax, E0[k * w2 + k]);
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const d
     sc[1] = dmax;
     sc[2] = 0.0;
   }
-  __syncthreads();
+  lds_barrier();
   double *src = E0, *dst = E1;
   for (int k = 0; k < n; k++) {
     const double d = src[k * w2 + k];
@@ -804,12 +808,12 @@ __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const d
       if (i > k) v -= (src[i * w2 + k] * dinv) * src[k * w2 + j];
       dst[e] = v;
     }
-    __syncthreads();
+    lds_barrier();
     double *t0 = src;
     src = dst;
     dst = t0;
   }
-  __syncthreads();
+  lds_barrier();
   const bool bad = sc[2] != 0.0;
   if (tid == 0) *status = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
   if (bad) return;
