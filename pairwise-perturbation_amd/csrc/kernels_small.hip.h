@@ -517,6 +517,9 @@ struct PPTerms {
 // block = 16 consecutive x for one r, 256 threads. Both storage orders are read with 16 lanes along
 // the contiguous index (128-byte segments) and every thread keeps 4 independent partial sums, so a
 // block has ~64 loads per thread in flight instead of a dependent chain: the launch is latency.
+// (Measured and rejected, tools/runs/r03_ak.sh: all terms advancing together in one loop — four
+// terms' loads in flight at once, per-term state in small arrays: 9.5 -> 17.1 us per launch,
+// `[PPsecond]` 102 -> 138 us.)
 __global__ __launch_bounds__(256) void k_pp_correct(const double *__restrict__ M0, int64_t rows,
                                                     int R, PPTerms tm, double *__restrict__ M,
                                                     SysArgs sys) {
