@@ -1,0 +1,48 @@
+"""CPU checks of the measurement helpers under tools/ (no GPU, no reference)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_trace_timed_launches_picks_the_region(tmp_path):
+    """tools/trace_timed_launches.py: of the scan launches in a rocprofv3 kernel trace only those
+    inside the bench line's timed region (clock domain found by containment) are averaged"""
+    line = {"metric": "m", "roofline": {"launches": 2, "avg_launch_ms": 1.1},
+            "timed_region_ns": {"realtime": [10, 20], "monotonic": [1000, 5000]}}
+    bench = tmp_path / "bench.json"
+    bench.write_text("noise\n" + json.dumps(line) + "\n")
+    trace = tmp_path / "trace.csv"
+    rows = ["Kind,Kernel_Name,Start_Timestamp,End_Timestamp",
+            'K,"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*, long)",100,900',     # set-up
+            'K,"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*, long)",1200,2200',   # timed
+            'K,"void ppals::k_mttv_vec<float>(float const*)",2300,2400',
+            'K,"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*, long)",3000,4200',   # timed
+            'K,"void ppals::k_scan_suffix_buf<float, 1, 1>(float const*, long)",6000,7000']   # after
+    trace.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_timed_launches.py"),
+                          str(bench), str(trace)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "clock monotonic: 2 launches" in out.stdout and "avg 1.10 us" in out.stdout, out.stdout
+    assert "bench.py by HIP events: 2 launches, avg 1100.00 us" in out.stdout
+
+
+def test_pmc_traffic_applies_the_fetch_correction(tmp_path):
+    """tools/pmc_traffic.py: FETCH_SIZE (KiB) is doubled on gfx950, WRITE_SIZE taken as is"""
+    d = tmp_path / "pmc"
+    d.mkdir()
+    (d / "x_counter_collection.csv").write_text(
+        "Kernel_Name,Counter_Name,Counter_Value\n"
+        '"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*)",FETCH_SIZE,1000\n'
+        '"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*)",FETCH_SIZE,3000\n'
+        '"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*)",WRITE_SIZE,500\n')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), str(d)],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if "k_scan_suffix_buf" in ln]
+    fetch = [ln for ln in lines if "FETCH_SIZE" in ln][0].split()
+    write = [ln for ln in lines if "WRITE_SIZE" in ln][0].split()
+    assert float(fetch[-1]) == 2000 * 1024 * 2.0 and int(fetch[-3]) == 2
+    assert float(write[-1]) == 500 * 1024.0
