@@ -1547,18 +1547,23 @@ class HipOps : public Ops {
     double *B = src;  // (rounds == 1: Z2, rounds == 2: Z)
     double *GB = GZ;
     gemm_nn(G, J, B, J, nullptr, 0, GB, J, Ji, cols, Ji, 1.0, 0.0);
-    hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H);
+    double *Hd2 = nullptr;
+    if (lazy) {
+      // (the Jacobi on the second stream works on its own copy of H — the workspace copy is
+      // overwritten by the next step — which the Gram kernel writes beside H; a Jacobi of this slot
+      // that is still in flight — a step that was not accepted — must be through with the buffers
+      // first)
+      EigState &es = *lazy;
+      lazy_prepare(es);
+      if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
+      Hd2 = es.Hd;
+    }
+    hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H, Hd2);
     double *resp = chk + 16 + 64 + 4 + 64;
     if (lazy) {
       // the basis itself goes out, checked as a subspace; the Jacobi of H moves to the second stream
       EigState &es = *lazy;
-      lazy_prepare(es);
-      // (H is copied for the Jacobi: the workspace copy is overwritten by the next step; a Jacobi
-      // of this slot that is still in flight — a step that was not accepted — must be through with
-      // the buffers first)
-      if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
       es.jacobi_launched = true;
-      HIP_CHECK(hipMemcpyAsync(es.Hd, H, sizeof(double) * cols * cols, hipMemcpyDeviceToDevice, st_));
       HIP_CHECK(hipEventRecord(es.ev_h, st_));
       HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
       const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
@@ -1602,7 +1607,6 @@ class HipOps : public Ops {
     int *status = (int *)(evW + 64);
     double *lamD = evW + 64 + 4;
     constexpr size_t kReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
-    HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
     double sigma = 0.5 * (es.lamR + es.lamR1);
     if (eig_sigma_scale_ > 0) sigma = eig_sigma_scale_ * es.lamR1;  // tests: a shift that is too low
     // ---- dominant eigenpairs (a relative gap >= 20 above the rest of the wanted ones): refined
@@ -1617,6 +1621,10 @@ class HipOps : public Ops {
         ratio = es.evh[d] / es.evh[d - 1];
       }
     double tau = 0;
+    // the step's status words: cleared by the kernel that sets up the iteration (k_ns_prepare /
+    // k_deflate_shift) unless block deflation writes some of them before that (m > 1)
+    int *zero8 = m <= 1 ? status : nullptr;
+    if (!zero8) HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
     // Fused form of a warm step (PPALS_EIG_FUSED=0: the round-2 launch sequence, kept for A/B and as
     // the route of block deflation / cold starts): the scale of the iteration comes from what the
     // slot knows about the spectrum instead of a Frobenius norm measured on the device (G is a Gram
@@ -1685,10 +1693,10 @@ class HipOps : public Ops {
       rho = es.head * std::max(sigma, next - sigma);
       if (!(rho > 0) || !std::isfinite(rho)) return false;
       hipLaunchKernelGGL(k_ns_prepare, dim3(gdef), dim3(256), 0, st_, G, J, pow_y, pow_p, pow_n, m, tau,
-                         sigma, 1.0 / rho, X, QD, lamD);
+                         sigma, 1.0 / rho, X, QD, lamD, zero8);
     } else {
       hipLaunchKernelGGL(k_deflate_shift, dim3(gdef), dim3(256), 0, st_, G, J, QD, m, lamD, tau, sigma,
-                         X, part);
+                         X, part, zero8);
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st_, part, gdef, fro2_d);
       if (!(rho > 0)) {  // first projector step of the slot: read the norm
         double fro2 = 0;

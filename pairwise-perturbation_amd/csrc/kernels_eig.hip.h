@@ -380,8 +380,11 @@ __global__ __launch_bounds__(256) void k_ns_prepare(const double *__restrict__ G
                                                     double tau, double sigma, double inv_rho,
                                                     double *__restrict__ X,
                                                     double *__restrict__ q_out,
-                                                    double *__restrict__ lam_out) {
+                                                    double *__restrict__ lam_out,
+                                                    int *__restrict__ zero8 = nullptr) {
   __shared__ double lds[17];
+  // (the step's status words are cleared here instead of by a memset launch of their own)
+  if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
   double inv = 0, lam = 0;
   if (m > 0) {
     double n2 = 0, rq = 0;
@@ -413,8 +416,10 @@ __global__ __launch_bounds__(256) void k_deflate_shift(const double *__restrict_
                                                        const double *__restrict__ Q, int m,
                                                        const double *__restrict__ lam, double tau,
                                                        double sigma, double *__restrict__ X,
-                                                       double *__restrict__ partial) {
+                                                       double *__restrict__ partial,
+                                                       int *__restrict__ zero8 = nullptr) {
   __shared__ double lds[17];
+  if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
   double s = 0;
   const int64_t total = J * J;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -588,7 +593,7 @@ __global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double 
 
 // C = A^T B for two tall matrices (rows x r, column-major, ld = rows): one wave per entry (p, q)
 __global__ void k_tn_small(const double *__restrict__ A, const double *__restrict__ B, int64_t rows,
-                           int r, double *__restrict__ C) {
+                           int r, double *__restrict__ C, double *__restrict__ C2 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
@@ -598,7 +603,10 @@ __global__ void k_tn_small(const double *__restrict__ A, const double *__restric
     double s = 0;
     for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
     s = wave_sum(s);
-    if (lane == 0) C[p + r * q] = s;
+    if (lane == 0) {
+      C[p + r * q] = s;
+      if (C2) C2[p + r * q] = s;  // (a second copy for a consumer on another stream: no blit launch)
+    }
   }
 }
 
