@@ -1643,8 +1643,11 @@ class HipOps : public Ops {
       // one dominant eigenpair (a tensor with a mean component): power steps on one vector. The
       // previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
       // Rayleigh quotient left by the last step is that of its input: second order in its error.
-      // (k steps leave an error of 1e-2 * ratio^k in the vector and its square in the quotient)
-      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-14) / std::log(ratio))));
+      // (k steps leave an error of 1e-2 * ratio^k in the vector and its square in the quotient: the
+      // target 1e-14 needs ratio^k <= 1e-12 — two steps at the 1e-6 of a tensor with a mean component,
+      // where counting from 1e-14 itself took three; a vector that was further off shows in the
+      // residual of the step, which is then repeated cold)
+      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-12) / std::log(ratio))));
       const int nb = (int)((J + 7) / 8);
       double *pw = (double *)ensure(ws_pow_, ws_pow_sz_, sizeof(double) * 4 * (size_t)nb);
       double *pbuf[2] = {pw, pw + 2 * (size_t)nb};
