@@ -802,24 +802,49 @@ __global__ __launch_bounds__(1024) void k_chol_m(double *__restrict__ Z, const d
   }
   lds_barrier();
   double *src = E0, *dst = E1;
-  for (int k = 0; k < n; k++) {
+  // TWO pivots per barrier: every element applies the row operations of pivots k and k + 1 from the
+  // same source buffer, in the order and with the roundings of one pivot after the other (the
+  // second pivot row and its multipliers are re-derived per thread from rows k and k + 1) — half
+  // the barriers of a launch that is twenty dependent barrier + update rounds at n = 20.
+  for (int k = 0; k < n; k += 2) {
     const double d = src[k * w2 + k];
     if (!(d > 1e-14 * sc[0])) {  // (uniform)
       if (tid == 0) sc[2] = 1.0;
       break;
     }
-    if (tid == 0) sc[1] = fmin(sc[1], d);
     const double dinv = 1.0 / d;
+    const bool two = k + 1 < n;
+    double d1 = d, d1inv = 0.0, lk1 = 0.0;
+    bool bad1 = false;
+    if (two) {
+      lk1 = src[(k + 1) * w2 + k] * dinv;                          // multiplier of row k+1, pivot k
+      d1 = src[(k + 1) * w2 + (k + 1)] - lk1 * src[k * w2 + (k + 1)];  // second pivot, after step k
+      bad1 = !(d1 > 1e-14 * sc[0]);
+      d1inv = bad1 ? 0.0 : 1.0 / d1;
+    }
+    if (tid == 0) sc[1] = fmin(sc[1], (two && !bad1) ? fmin(d, d1) : d);
     for (int e = tid; e < n * w2; e += nthr) {
       const int i = e / w2, j = e - i * w2;
       double v = src[e];
-      if (i > k) v -= (src[i * w2 + k] * dinv) * src[k * w2 + j];
+      const double akj = src[k * w2 + j];
+      if (i > k) v -= (src[i * w2 + k] * dinv) * akj;  // pivot k
+      if (two && !bad1 && i > k + 1) {
+        // pivot k+1 on the matrix after step k: a'_{i,k+1} = a_{i,k+1} - l_ik a_{k,k+1},
+        // a'_{k+1,j} = a_{k+1,j} - l_{k+1,k} a_kj
+        const double aik1 = src[i * w2 + (k + 1)] - (src[i * w2 + k] * dinv) * src[k * w2 + (k + 1)];
+        const double ak1j = src[(k + 1) * w2 + j] - lk1 * akj;
+        v -= (aik1 * d1inv) * ak1j;
+      }
       dst[e] = v;
     }
     lds_barrier();
     double *t0 = src;
     src = dst;
     dst = t0;
+    if (two && bad1) {  // (uniform: the second pivot of the pair is not safely positive)
+      if (tid == 0) sc[2] = 1.0;
+      break;
+    }
   }
   lds_barrier();
   const bool bad = sc[2] != 0.0;
