@@ -272,8 +272,6 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   if (const char *e = std::getenv("PPALS_PLACE_TUNE")) ms_tune_enabled_ = std::atoi(e) != 0;
   // (off unless asked for: on this stack the replay costs more than the nine launches it replaces,
   // DESIGN.md section 8)
-  pp_graph_enabled_ = false;
-  if (const char *e = std::getenv("PPALS_GRAPH")) pp_graph_enabled_ = std::atoi(e) != 0;
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
     ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
@@ -349,7 +347,6 @@ CpEngine::~CpEngine() {
   for (auto p : dM_) ops_.free(p);
   for (auto p : Mm_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
-  pp_graph_drop();
   lr_release();
   pp_clear();
   for (auto &kv : pp_pool_) ops_.free(kv.second.buf);
@@ -1085,7 +1082,8 @@ void CpEngine::ms_start_step(int first) {
   // before the scan is planned (big_alloc may give a resident layout back)
   const size_t xbytes = ms_X_bytes(first, k);
   const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;
-  if (ms_X_cap_ < xbytes + slack) {
+  // (an override — the LR optimizers' per-root caches — receives the scan's result itself: no block)
+  if (!ms_X_override_ && ms_X_cap_ < xbytes + slack) {
     ops_.free(ms_X_base_);
     ms_X_base_ = nullptr;
     ms_X_cap_ = 0;
@@ -1663,6 +1661,16 @@ int CpEngine::run_class(int kind, const CpOpts &o, double *sweeps_out, int *iter
           lr_left1 = N_ - 1;
           lr_left2 = N_ - 2;
         }
+        // the reference keeps two cached first contractions (cached_tensor1 / cached_tensor2,
+        // cp_dt_lr_optimizer.cxx:21-35): the roots that just left the pair give theirs back
+        // (s^(N-1) R each — at order 5-6 holding all N of them runs the device out of memory)
+        for (int m = 0; m < N_; m++)
+          if (m != lr_left1 && m != lr_left2 && lr_cache_[m]) {
+            ops_.sync();
+            ops_.free(lr_cache_[m]);
+            lr_cache_[m] = nullptr;
+            lr_have_[m] = false;
+          }
       }
       lr_first = !lr_first;
       return 0.5;
@@ -2006,9 +2014,16 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   pp_clear();
   // (never the borrowed multi-sweep intermediate here: it carries a Normalize factor that only the
   // contractions below it apply — this entry point hands the operator itself to the caller)
+  struct Restore {  // (pp_get may throw: the flags must not outlive the call)
+    CpEngine &e;
+    bool fast;
+    ~Restore() {
+      e.pp_fast_ = fast;
+      e.pp_no_borrow_ = false;
+    }
+  } restore{*this, pp_fast_};
   pp_no_borrow_ = true;
   const PPOp *op = &pp_get(contracted);
-  const bool saved = pp_fast_;
   if (op->dt != F64 || !std::is_sorted(op->modes.begin(), op->modes.end())) {
     // the entry point returns fp64 with the remaining modes ascending: rebuild on the plain route
     pp_clear();
@@ -2018,77 +2033,13 @@ int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   if (out_host) ops_.d2h(out_host, op->buf, sizeof(double) * (size_t)op->elems * R_);
   int64_t n = op->elems * R_;
   pp_clear();
-  pp_fast_ = saved;
-  pp_no_borrow_ = false;
   return n;
 }
 
 // one approximate sweep: als_CP.cxx:754-825. Per mode: ONE launch for M = M_i^0 + the N-1
 // first-order corrections, ONE for the whole mode update (which also leaves ||dW_i||^2); the
 // Normalize launch leaves ||W_i||^2: the restart test of the next iteration costs no launch.
-std::vector<const void *> CpEngine::pp_graph_signature() const {
-  std::vector<const void *> sig;
-  for (const auto &kv : pp_) sig.push_back(kv.second.buf);
-  for (int i = 0; i < N_; i++) {
-    sig.push_back(W_[i]);
-    sig.push_back(gradW_[i]);
-    sig.push_back(Winit_[i]);
-    sig.push_back(dW_[i]);
-  }
-  sig.push_back(Mbuf_);
-  sig.push_back(pp_norms_);
-  sig.push_back(G_);
-  return sig;
-}
-void CpEngine::pp_graph_drop() {
-  if (pp_graph_) ops_.graph_destroy(pp_graph_);
-  pp_graph_ = nullptr;
-  pp_graph_sig_.clear();
-}
-// called when the operators of a PP phase have been built (part of the phase's set-up time, like
-// the operators themselves: [PPfirst] of the reference's timer)
-void CpEngine::pp_graph_prepare(double lambda, double ratio) {
-  if (!pp_graph_enabled_ || dist_) return;
-  if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
-  if (!pp_norms_) {
-    pp_norms_ = (double *)ops_.alloc(sizeof(double) * 2 * MAX_ORDER);
-    ops_.zero(pp_norms_, sizeof(double) * 2 * MAX_ORDER);
-  }
-  const auto sig = pp_graph_signature();
-  if (pp_graph_ && sig == pp_graph_sig_ && lambda == pp_graph_lambda_ && ratio == pp_graph_ratio_)
-    return;  // the recording of an earlier phase names the same buffers: still good
-  pp_graph_drop();
-  if (!ops_.graph_capture_begin()) return;
-  bool ok = true;
-  try {
-    sweep_pp_body(lambda, ratio);
-  } catch (...) {
-    ok = false;  // something inside wanted to allocate or synchronise: no graph for this session
-  }
-  void *g = ops_.graph_capture_end();
-  if (!ok || !g) {
-    if (g) ops_.graph_destroy(g);
-    pp_graph_enabled_ = false;
-    return;
-  }
-  pp_graph_ = g;
-  pp_graph_sig_ = sig;
-  pp_graph_lambda_ = lambda;
-  pp_graph_ratio_ = ratio;
-}
-
 void CpEngine::sweep_pp(double lambda, double ratio) {
-  if (pp_graph_ && lambda == pp_graph_lambda_ && ratio == pp_graph_ratio_ &&
-      pp_graph_signature() == pp_graph_sig_) {
-    ms_invalidate();
-    ops_.graph_launch(pp_graph_);
-    grad_from_sweep_ = true;
-    return;
-  }
-  sweep_pp_body(lambda, ratio);
-}
-
-void CpEngine::sweep_pp_body(double lambda, double ratio) {
   ms_invalidate();  // PP moves the factors without touching the multi-sweep cache
   if (!Mbuf_) Mbuf_ = (double *)ops_.alloc(sizeof(double) * (size_t)maxs_ * R_);
   if (!pp_norms_) {
@@ -2276,7 +2227,6 @@ double CpEngine::pp_sub(const CpOpts &o, double &projnorm, int &iter, std::ofstr
         ops_.zero(dW_[j], n);
       }
       pp_build_all();
-      pp_graph_prepare(o.lambda, o.ratio_step);
     }
     if (iter % o.resprint == 0 || iter == o.maxiter || iter == init_iter) {
       if (!o.bench) {

@@ -229,17 +229,6 @@ class CpEngine {
   void pp_clear();
   void pp_build_all();
   void sweep_pp(double lambda, double ratio);
-  void sweep_pp_body(double lambda, double ratio);
-  // the approximate sweep as a recorded launch graph (single GPU): nine latency-bound launches
-  // replayed with one call. Recorded when the PP operators are built, kept across phases while
-  // every buffer it names stays where it was (pp_graph_sig_).
-  void pp_graph_prepare(double lambda, double ratio);
-  void pp_graph_drop();
-  std::vector<const void *> pp_graph_signature() const;
-  void *pp_graph_ = nullptr;
-  std::vector<const void *> pp_graph_sig_;
-  double pp_graph_lambda_ = 0, pp_graph_ratio_ = 0;
-  bool pp_graph_enabled_ = true;
   double allreduce_scalar(double x);
   bool agree(bool local);
   void read_norms(bool dt_phase, std::vector<double> &nd, std::vector<double> &nw);

@@ -88,7 +88,6 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_UPDATE_STAGE")) stage_update_ = atoi(v);
-    if (const char *v = getenv("PPALS_GRAPH")) graphs_ = atoi(v);
     if (const char *v = getenv("PPALS_UPDATE_FUSE_NORM")) update_fuse_norm_ = atoi(v);
     if (const char *v = getenv("PPALS_UPDATE_MFMA")) update_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_UPDATE_PRESOLVE")) update_presolve_ = atoi(v);
@@ -110,6 +109,8 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_LAZY")) eig_lazy_ok_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_DEFER")) eig_defer_ok_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_small,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
@@ -1199,6 +1200,9 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_take_top, dim3(grid_for(J * rank, 256)), dim3(256), 0, st_, G, J, rank, U);
     HIP_CHECK(hipGetLastError());
   }
+  static constexpr int kTailBlocks = 64;
+  // the one read-back of a projector step: chk[16] | evW[64] | status (4 doubles) | lamD[64] | residual shares
+  static constexpr size_t kEigReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
   // ---- K12 inside a HOOI iteration: spectral projector by the scaled Newton-Schulz sign iteration
   // (kernels_eig.hip.h), warm-started per slot, verified by trace(P) == rank, else the full solver.
   struct EigState {
@@ -1222,6 +1226,20 @@ class HipOps : public Ops {
     double *Qn = nullptr;                 // spare buffer of the same size (the step's result lands here)
     double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
     int fast = 0, full = 0;
+    // deferred acceptance (eig_defer / eig_verify): the step's read-back lands in the slot's own
+    // pinned block behind ev_chk; what the checks need from the time of the call is kept in `dp`
+    bool defer = false;     // the session allows it for this slot
+    int stable = 0;         // consecutive steps accepted at the first attempt, as scheduled
+    bool deferred = false;  // a step is waiting for eig_verify
+    double *chk_pinned = nullptr;
+    hipEvent_t ev_chk = nullptr;
+    double *GBd = nullptr, *chkd = nullptr;  // G*B (J x rank) and the checks' device block, the slot's own
+    size_t GBd_elems = 0;
+    struct {
+      double sigma = 0, rho = 0, ell0 = 0;
+      int m = 0, iters = 0;
+    } dp;
+    int n_deferred = 0, n_defer_failed = 0;
   };
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
@@ -1427,6 +1445,14 @@ class HipOps : public Ops {
     if (es.evd) hipFree(es.evd);
     if (es.ev_pinned) hipHostFree(es.ev_pinned);
     es.ev_pinned = nullptr;
+    if (es.chk_pinned) hipHostFree(es.chk_pinned);
+    es.chk_pinned = nullptr;
+    if (es.ev_chk) hipEventDestroy(es.ev_chk);
+    es.ev_chk = nullptr;
+    if (es.GBd) hipFree(es.GBd);
+    if (es.chkd) hipFree(es.chkd);
+    es.GBd = es.chkd = nullptr;
+    es.GBd_elems = 0;
     if (es.ev_h) hipEventDestroy(es.ev_h);
     if (es.ev_done) hipEventDestroy(es.ev_done);
     es.Hd = es.Yd = es.evd = nullptr;
@@ -1443,6 +1469,9 @@ class HipOps : public Ops {
       HIP_CHECK(hipHostMalloc(&es.ev_pinned, sizeof(double) * 64, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&es.ev_h, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&es.ev_done, hipEventDisableTiming));
+      HIP_CHECK(hipHostMalloc(&es.chk_pinned, kEigReadback, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&es.ev_chk, hipEventDisableTiming));
+      HIP_CHECK(hipMalloc(&es.chkd, kEigReadback));
     }
   }
   void eig_lazy(int slot, bool on) override {
@@ -1450,6 +1479,91 @@ class HipOps : public Ops {
     EigState &es = eig_state_[slot];
     es.lazy = on && eig_lazy_ok_ && eig_fused_;
     if (es.lazy) lazy_prepare(es);
+  }
+  void eig_defer(int slot, bool on) override {
+    if (slot < 0) return;
+    eig_state_[slot].defer = on && eig_defer_ok_;
+  }
+  // What decides whether a projector step's result is accepted, from its one read-back `hc`
+  // (chk[16] | evW[64] | status[8 ints] | lamD[64] | per-workgroup residual shares, already summed
+  // into hc[4]) and the quantities the step was scheduled with.
+  struct StepCheck {
+    bool converged = false, good = false;
+    double cnt = 0, res = 0, rho_now = 0, gap_now = 0, res_tol = 0;
+  };
+  StepCheck check_step(const double *hc, int64_t J, int rank, double sigma, double rho, bool strict,
+                       bool fused_tail, bool fused_scale, bool lazy_used) const {
+    StepCheck c;
+    const double *evn = hc + 16;
+    const int *hs = (const int *)(evn + 64);
+    c.cnt = 0.5 * (hc[1] + (double)J);
+    c.res = std::sqrt(hc[4]);
+    c.rho_now = fused_scale ? rho : 1.0001 * std::sqrt(hc[8]);
+    // (fused tail: hc[0] is ||E||_F^2 of the iterate BEFORE the last step, E = X^2 - I; the step
+    // squares it — E_new = (3 E^2 + E^3) / 4 — so ||E_new||_F <= ||E||_F^2 = hc[0])
+    c.converged = fused_tail ? hc[0] <= 1e-10 * std::sqrt((double)J) : hc[0] <= 1e-20 * (double)J;
+    // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
+    // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
+    // (from THIS step's quantities only: trace(P) == rank says that exactly `rank` eigenvalues
+    // lie above this step's shift, so the gap below the rank-th one is at least its distance to
+    // the shift; the slot's previous gap / eigenvalue scale only scheduled the iteration)
+    // (lazy tail: the Jacobi has not run yet — Gershgorin bounds of H's spectrum stand in for
+    // the smallest / largest eigenvalue of the subspace, and the residual is the subspace's)
+    const double ev_lo = lazy_used ? hc[5] : evn[rank - 1], ev_hi = lazy_used ? hc[6] : evn[0];
+    c.gap_now = std::max(0.0, ev_lo - sigma);
+    c.res_tol = (strict ? 1e-13 * ev_hi : std::max(1e-9 * c.gap_now, 1e-14 * ev_hi)) * std::sqrt((double)rank);
+    const bool chol_ok = hs[0] == 0;
+    c.good = c.converged && std::fabs(c.cnt - rank) < 1e-6 && chol_ok && hs[2] != 1 && hs[3] == 0 &&
+             c.res <= c.res_tol && std::isfinite(c.rho_now);
+    return c;
+  }
+  bool eig_deferred(int slot) override {
+    auto it = eig_state_.find(slot);
+    return it != eig_state_.end() && it->second.deferred;
+  }
+  int eig_verify(int slot, bool discard) override {
+    auto it = eig_state_.find(slot);
+    if (it == eig_state_.end() || !it->second.deferred) return -1;
+    EigState &es = it->second;
+    es.deferred = false;
+    HIP_CHECK(hipEventSynchronize(es.ev_chk));
+    double *hc = es.chk_pinned;
+    {
+      const double *rp = hc + 16 + 64 + 4 + 64;
+      double r2 = 0;
+      for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
+      hc[4] = r2;
+    }
+    const StepCheck c = check_step(hc, es.J, es.rank, es.dp.sigma, es.dp.rho, false, true, true, true);
+    bool ok = c.good && !discard;
+    if (ok && eig_defer_fail_ > 0 && ++eig_defer_count_ % eig_defer_fail_ == 0) ok = false;  // (tests)
+    if (eig_debug_) {
+      const int *hs = (const int *)(hc + 16 + 64);
+      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
+                      "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
+                      "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
+              slot, (long long)es.J, es.rank, es.lamR, es.lamR1, es.dp.m, es.dp.rho, c.rho_now, es.dp.ell0,
+              es.dp.iters, hc[0], c.cnt, c.res, c.gap_now, hs[0], hs[1], hs[2], hs[3],
+              ok ? "accepted (deferred check)" : (discard ? "dropped (its input was withdrawn)"
+                                                          : "NOT accepted (deferred check): the caller repeats the step"),
+              es.fast, es.full);
+    }
+    if (ok) {
+      // the eigenvalues arrive with the second stream's Jacobi: resolve_lazy() turns them into
+      // the slot's state when the slot is used next; the caller holds the basis, Y is owed to it
+      es.lazy_pending = true;
+      es.rot_pending = true;
+      es.lazy_m = es.dp.m;
+      es.lazy_strict = false;
+      es.rho_frob = c.rho_now;
+      es.fast++;
+      es.stable++;
+      return 0;
+    }
+    std::swap(es.Q, es.Qn);  // (the step had put its basis in front)
+    es.stable = 0;
+    es.n_defer_failed++;
+    return 1;
   }
   const double *eig_pending_rotation(int slot) override {
     auto it = eig_state_.find(slot);
@@ -1472,6 +1586,7 @@ class HipOps : public Ops {
     // (the Jacobi wrote them into pinned host memory itself: waiting for ITS event is all it takes —
     // a copy would queue behind the other slots' Jacobis on the second stream, or drain the main one)
     HIP_CHECK(hipEventSynchronize(es.ev_done));
+    es.jacobi_launched = false;  // (nothing of this slot is in flight on the second stream any more)
     for (int d = 0; d < es.rank; d++) evn[d] = es.ev_pinned[d];
     const int rank = es.rank, m = es.lazy_m;
     bool sane = true;
@@ -1521,17 +1636,20 @@ class HipOps : public Ops {
   // workgroup diagonalises H itself (block Jacobi in LDS) and forms its rows of U = B Y and of the
   // residual. `rounds` = 2 repeats the Gram / Cholesky / product on B (a basis far from
   // orthonormal: cold starts, wide tails).
-  static constexpr int kTailBlocks = 64;
   void fused_tail_launches(const double *G, const double *X, int64_t J, int cols, int rank,
                            const double *Omega, const double *QD, int m, double *Z, double *Z2,
                            double *GZ, double *C, double *H, double *Uout, double *evW, double *chk,
                            int *status, const double *pe2, const double *ptr_, int np, int rounds = 1,
-                           double *Uout2 = nullptr, EigState *lazy = nullptr) {
+                           double *Uout2 = nullptr, EigState *lazy = nullptr, double *host_chk = nullptr) {
     const int Ji = (int)J;
     gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
     const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
     const int rows_per = (int)((J + nblk - 1) / nblk);
-    double *src = Z, *dst = Z2;
+    // deferred acceptance (host_chk): the basis goes straight into the caller's buffer, and what the
+    // checks read lives in the slot's own buffers — they are finished on the second stream while
+    // the main stream has long moved on and reuses the workspace
+    const bool deferred = lazy && host_chk && rounds == 1;
+    double *src = Z, *dst = deferred ? Uout : Z2;
     for (int rd = 0; rd < rounds; rd++) {
       const int mm = rd == 0 ? m : 0;  // (the deflated columns are in place after the first round)
       hipLaunchKernelGGL(k_tn_two, dim3((cols * cols + mm * cols + 15) / 16), dim3(1024), 0, st_, src, QD,
@@ -1544,8 +1662,17 @@ class HipOps : public Ops {
       gemm_nn(src, J, H, cols, nullptr, 0, dst, J, Ji, cols, cols, 1.0, 0.0);
       std::swap(src, dst);
     }
-    double *B = src;  // (rounds == 1: Z2, rounds == 2: Z)
+    double *B = src;  // (rounds == 1: Z2 / the caller's buffer, rounds == 2: Z)
     double *GB = GZ;
+    if (deferred) {
+      EigState &es = *lazy;
+      if (es.GBd_elems < (size_t)J * cols) {
+        if (es.GBd) HIP_CHECK(hipFree(es.GBd));
+        HIP_CHECK(hipMalloc(&es.GBd, sizeof(double) * (size_t)J * cols));
+        es.GBd_elems = (size_t)J * cols;
+      }
+      GB = es.GBd;
+    }
     gemm_nn(G, J, B, J, nullptr, 0, GB, J, Ji, cols, Ji, 1.0, 0.0);
     double *Hd2 = nullptr;
     if (lazy) {
@@ -1557,6 +1684,24 @@ class HipOps : public Ops {
       lazy_prepare(es);
       if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
       Hd2 = es.Hd;
+    }
+    if (deferred) {
+      EigState &es = *lazy;
+      hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, B, GB, J, cols, H,
+                         Hd2, pe2, ptr_, np, chk, es.chkd);
+      es.jacobi_launched = true;
+      HIP_CHECK(hipEventRecord(es.ev_h, st_));
+      HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
+      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
+                         sizeof(double) * ((size_t)cols * cols + 17 + 128), st2_, B, GB, J, cols, es.Hd, rows_per,
+                         (const double *)nullptr, (const double *)nullptr, -1, (double *)nullptr, Uout2,
+                         es.chkd, es.chkd + 16 + 64 + 4 + 64, host_chk);
+      HIP_CHECK(hipEventRecord(es.ev_chk, st2_));
+      const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
+      hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
+                         es.Hd, cols, es.Yd, es.evd, es.ev_pinned);
+      HIP_CHECK(hipEventRecord(es.ev_done, st2_));
+      return;
     }
     hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H, Hd2);
     double *resp = chk + 16 + 64 + 4 + 64;
@@ -1758,6 +1903,10 @@ class HipOps : public Ops {
       // QR, Rayleigh-Ritz on cols x cols; the leading `rank` eigenvectors land in Uout (ld J), their
       // residual in chk[4], all `cols` eigenvalues in evW; then the one read-back of the step
       bool lazy_used = false;
+      // deferred acceptance: a slot whose last steps went through as scheduled hands out the basis
+      // without waiting for its checks (Ops::eig_defer / eig_verify)
+      const bool defer_now = attempt == 0 && es.lazy && es.defer && es.stable >= 2 && fused_tail &&
+                             fused_scale && !strict && !eig_frob_once_;
       auto tail = [&](int cols, const double *Omega, double *Uout, int npass) {
         if (fused_tail) {
           // (the leading eigenvectors also go to the slot's spare basis buffer: accepted = a swap)
@@ -1765,7 +1914,14 @@ class HipOps : public Ops {
           lazy_used = lazy_now;
           fused_tail_launches(G, X, J, cols, rank, Omega, QD, m, Z, Z2, GZ, C, H, Uout, evW, chk, status,
                               pe2, ptr_, (int)ntri, npass, Uout == U ? es.Qn : nullptr,
-                              lazy_now ? &es : nullptr);
+                              lazy_now ? &es : nullptr, (defer_now && lazy_now) ? es.chk_pinned : nullptr);
+          if (defer_now && lazy_now) {
+            // no wait and no copy: the checks are finished on the second stream, whose kernel writes
+            // them into the slot's pinned block (ev_chk); eig_verify() reads them when the caller
+            // comes back to the slot
+            HIP_CHECK(hipGetLastError());
+            return;
+          }
           if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
           HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
           HIP_CHECK(hipStreamSynchronize(st_));
@@ -1802,27 +1958,22 @@ class HipOps : public Ops {
         HIP_CHECK(hipGetLastError());
       };
       tail(rank, es.Q, U, 1);
+      if (defer_now && lazy_used) {
+        es.deferred = true;
+        es.n_deferred++;
+        es.dp.sigma = sigma;
+        es.dp.rho = rho;
+        es.dp.ell0 = ell0;
+        es.dp.m = m;
+        es.dp.iters = iters;
+        std::swap(es.Q, es.Qn);  // (eig_verify swaps back when the step is not accepted)
+        return true;
+      }
       const double *hc = (const double *)eig_host_, *evn = hc + 16;
       const int *hs = (const int *)(evn + 64);
-      const double cnt = 0.5 * (hc[1] + (double)J), res = std::sqrt(hc[4]);
-      const double rho_now = fused_scale ? rho : 1.0001 * std::sqrt(hc[8]);
-      // (fused tail: hc[0] is ||E||_F^2 of the iterate BEFORE the last step, E = X^2 - I; the step
-      // squares it — E_new = (3 E^2 + E^3) / 4 — so ||E_new||_F <= ||E||_F^2 = hc[0])
-      const bool converged = fused_tail ? hc[0] <= 1e-10 * std::sqrt((double)J) : hc[0] <= 1e-20 * (double)J;
-      // accepted when the eigenpair residual is at the level the full solver reaches: 1e-9 of the
-      // gap (projector error <= 1e-9), or the rounding floor eps * lambda_1 of any method
-      // (from THIS step's quantities only: trace(P) == rank says that exactly `rank` eigenvalues
-      // lie above this step's shift, so the gap below the rank-th one is at least its distance to
-      // the shift; the slot's previous gap / eigenvalue scale only scheduled the iteration)
-      // (lazy tail: the Jacobi has not run yet — Gershgorin bounds of H's spectrum stand in for
-      // the smallest / largest eigenvalue of the subspace, and the residual is the subspace's)
-      const double ev_lo = lazy_used ? hc[5] : evn[rank - 1], ev_hi = lazy_used ? hc[6] : evn[0];
-      const double gap_now = std::max(0.0, ev_lo - sigma);
-      const double res_tol = (strict ? 1e-13 * ev_hi : std::max(1e-9 * gap_now, 1e-14 * ev_hi)) *
-                             std::sqrt((double)rank);
-      const bool chol_ok = hs[0] == 0;
-      const bool good = converged && std::fabs(cnt - rank) < 1e-6 && chol_ok && hs[2] != 1 && hs[3] == 0 &&
-                        res <= res_tol && std::isfinite(rho_now);
+      const StepCheck sc = check_step(hc, J, rank, sigma, rho, strict, fused_tail, fused_scale, lazy_used);
+      const double cnt = sc.cnt, res = sc.res, rho_now = sc.rho_now, gap_now = sc.gap_now, res_tol = sc.res_tol;
+      const bool converged = sc.converged, good = sc.good;
       if (eig_debug_)
         fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
                         "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
@@ -1830,6 +1981,7 @@ class HipOps : public Ops {
                 slot, (long long)J, rank, es.lamR, es.lamR1, m, rho, rho_now, ell0, iters, hc[0], cnt,
                 res, gap_now, hs[0], hs[1], hs[2], hs[3],
                 good ? "accepted" : (converged ? "not accepted as it is" : "more steps"), es.fast, es.full);
+      es.stable = (good && attempt == 0) ? es.stable + 1 : 0;
       if (good && lazy_used) {
         // the eigenvalues arrive with the second stream's Jacobi: resolve_lazy() turns them into
         // the slot's state when the slot is used next; U holds the basis, Y is owed to the caller
@@ -2243,38 +2395,6 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
 
-  // ------------------------------------------------------------------ launch graphs
-  bool graph_capture_begin() override {
-    if (profiling_ || !graphs_) return false;
-    if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    return true;
-  }
-  void *graph_capture_end() override {
-    hipGraph_t g = nullptr;
-    if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    hipGraphExec_t ex = nullptr;
-    const hipError_t rc = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
-    if (rc != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    return (void *)ex;
-  }
-  void graph_launch(void *graph) override { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph, st_)); }
-  void graph_destroy(void *graph) override {
-    if (graph) {
-      hipStreamSynchronize(st_);
-      hipGraphExecDestroy((hipGraphExec_t)graph);
-    }
-  }
-
   // ------------------------------------------------------------------ profiling
   void profile_enable(int level) override { profiling_ = level; }
   void profile_collect() override {
@@ -2358,9 +2478,10 @@ class HipOps : public Ops {
   const double *norm_G_ = nullptr;
   bool norm_armed_ = false;
   int update_fuse_norm_ = 1;  // PPALS_UPDATE_FUSE_NORM=0: Normalize always a launch of its own
-  int graphs_ = 0;          // PPALS_GRAPH=1: replay the approximate sweep as a recorded launch graph
-                            // (A/B: 9 launches take 103 us one by one, 114-122 us as a graph)
   bool eig_frob_once_ = false;
+  int eig_defer_ok_ = 1;    // PPALS_EIG_DEFER=0: every projector step waits for its own checks
+  int eig_defer_fail_ = 0;  // PPALS_EIG_DEFER_FAIL=n (tests): every n-th deferred check is reported as failed
+  int eig_defer_count_ = 0;
   int eig_fused_ = 1;  // PPALS_EIG_FUSED=0: the multi-launch tail and the Frobenius scale (A/B, tests)
   int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
   void *ws_cold_ = nullptr;

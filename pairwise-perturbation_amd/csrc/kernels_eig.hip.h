@@ -592,11 +592,37 @@ __global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double 
 }
 
 // C = A^T B for two tall matrices (rows x r, column-major, ld = rows): one wave per entry (p, q)
+// chk_out != nullptr (deferred acceptance: the checks are finished on the second stream, which must
+// not read the shared workspace): ONE extra workgroup — the last — adds up the sign iteration's
+// per-tile check sums (np each) into chk_out[0], chk_out[1] and copies the step's norm word [8] and
+// status words [80..84) from the workspace block chk_src into the slot's own block.
 __global__ void k_tn_small(const double *__restrict__ A, const double *__restrict__ B, int64_t rows,
-                           int r, double *__restrict__ C, double *__restrict__ C2 = nullptr) {
+                           int r, double *__restrict__ C, double *__restrict__ C2 = nullptr,
+                           const double *__restrict__ part_e2 = nullptr,
+                           const double *__restrict__ part_tr = nullptr, int np = 0,
+                           const double *__restrict__ chk_src = nullptr,
+                           double *__restrict__ chk_out = nullptr) {
+  if (chk_out && blockIdx.x == gridDim.x - 1) {
+    __shared__ double red[17];
+    double e2 = 0, tr = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+      e2 += part_e2[i];
+      tr += part_tr[i];
+    }
+    e2 = block_sum(e2, red);
+    tr = block_sum(tr, red);
+    if (threadIdx.x == 0) {
+      chk_out[0] = e2;
+      chk_out[1] = tr;
+      chk_out[8] = chk_src[8];
+    }
+    if (threadIdx.x < 4) chk_out[16 + 64 + threadIdx.x] = chk_src[16 + 64 + threadIdx.x];
+    return;
+  }
+  const int nblocks = chk_out ? gridDim.x - 1 : gridDim.x;
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int nw = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int nw = (int)(((int64_t)nblocks * blockDim.x) >> 6);
   for (int e = wid; e < r * r; e += nw) {
     const int p = e % r, q = e / r;
     const double *a = A + rows * p, *b = B + rows * q;
@@ -965,7 +991,11 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
                                                       const double *__restrict__ part_tr, int np,
                                                       double *__restrict__ U, double *__restrict__ U2,
                                                       double *__restrict__ chk,
-                                                      double *__restrict__ resp) {
+                                                      double *__restrict__ resp,
+                                                      double *__restrict__ host = nullptr) {
+  // host != nullptr (deferred acceptance): everything the step's checks read — the sums, the
+  // Gershgorin bounds, the status words of the Cholesky kernel, the residual shares — is ALSO
+  // written straight into that pinned block of the slot (same layout as chk: no copy launch)
   extern __shared__ double sH[];  // cols x cols | red[17] | lo[64] | hi[64]
   double *red = sH + cols * cols;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -983,15 +1013,23 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
     double bh = 0;
     for (int p = 0; p < cols; p++) bh += Bm[i + J * p] * sH[p + cols * k];
     const double b = Bm[i + J * k];
-    U[i + J * k] = b;
+    if (U) U[i + J * k] = b;
     if (U2) U2[i + J * k] = b;
     const double d = GB[i + J * k] - bh;
     res += d * d;
   }
   res = block_sum(res, red);
-  if (tid == 0) resp[blockIdx.x] = res;
+  double *hresp = host ? host + (resp - chk) : nullptr;
+  if (tid == 0) {
+    resp[blockIdx.x] = res;
+    if (hresp) hresp[blockIdx.x] = res;
+  }
   if (blockIdx.x == 0) {
-    for (int b = gridDim.x + tid; b < 64; b += nthr) resp[b] = 0.0;
+    for (int b = gridDim.x + tid; b < 64; b += nthr) {
+      resp[b] = 0.0;
+      if (hresp) hresp[b] = 0.0;
+    }
+    if (host && tid < 4) host[16 + 64 + tid] = chk[16 + 64 + tid];  // status words (8 ints)
     double e2 = 0, tr = 0;
     for (int i = tid; i < np; i += nthr) {
       e2 += part_e2[i];
@@ -999,6 +1037,10 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
     }
     e2 = block_sum(e2, red);
     tr = block_sum(tr, red);
+    if (np < 0) {  // (the producer of H left the sums in place: k_tn_small with chk_out)
+      e2 = chk[0];
+      tr = chk[1];
+    }
     double *lo = red + 17, *hi = lo + 64;
     if (tid < cols) {
       double off = 0;
@@ -1018,6 +1060,13 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
       chk[1] = tr;
       chk[5] = l;
       chk[6] = h;
+      if (host) {
+        host[0] = e2;
+        host[1] = tr;
+        host[5] = l;
+        host[6] = h;
+        host[8] = chk[8];
+      }
     }
   }
 }

@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_rank_split(TV *__restrict__ V, int64_t 
     }
   double acc = 0.0;
   const TV *__restrict__ vp = V + m_ld;
-  vec cv;
+  vec cv = {};
   double ca[MAXRBW];
 #define PPALS_SPLIT_LOAD(kb_, vv_, aa_)                                                   \
   {                                                                                       \
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_rank_split(TV *__restrict__ V, int64_t 
   }
   if (kb0 < kb1) PPALS_SPLIT_LOAD(kb0, cv, ca);
   for (int kb = kb0; kb < kb1; kb++) {
-    vec nv;
+    vec nv = {};  // (read only when MODE == 1)
     double na[MAXRBW];
     const int kn = min(kb + 1, kb1 - 1);
     PPALS_SPLIT_LOAD(kn, nv, na);

@@ -278,6 +278,19 @@ class Ops {
   // applies Y (to the factor and to whatever it derived from it) when it needs eigenvectors and
   // says so with eig_rotation_done(slot).
   virtual void eig_lazy(int /*slot*/, bool /*on*/) {}
+  // Deferred acceptance. With eig_defer(slot, true) a lazy warm step of a slot whose recent steps
+  // were all accepted at the first attempt may RETURN BEFORE ITS CHECKS HAVE BEEN READ: nothing
+  // inside a HOOI sweep then waits for the device, and the host enqueues ahead of it. The caller
+  // asks with eig_verify(slot) before it uses the slot again and before it publishes anything that
+  // was derived from the returned factor:
+  //   -1  nothing pending,  0  the pending step has been accepted,
+  //    1  it has NOT: the factor it returned is to be thrown away — the caller restores what it
+  //       had before that call and repeats the work from there (the slot is back in the state it
+  //       had before the step and takes the checked route next time).
+  // discard = true: the pending step is dropped whatever its checks say (its input was wrong).
+  virtual void eig_defer(int /*slot*/, bool /*on*/) {}
+  virtual bool eig_deferred(int /*slot*/) { return false; }  // a step of the slot awaits eig_verify
+  virtual int eig_verify(int /*slot*/, bool /*discard*/ = false) { return -1; }
   virtual const double *eig_pending_rotation(int /*slot*/) { return nullptr; }
   virtual void eig_rotation_done(int /*slot*/) {}
   // A session's block of 64 warm-start slots [base, base + 64) (what a back end remembers under a
@@ -304,15 +317,6 @@ class Ops {
   // W[:,k] *= (<W[:,k], Wref[:,k]> > 0 ? +1 : -1)   (als_Tucker.cxx:632-643, :874-885)
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
 
-  // ---- launch graphs: record the launches a piece of host code enqueues instead of running them,
-  // then replay the recording with one call (latency-bound sweeps: nine ~10 us launches). Between
-  // begin and end nothing may allocate, free or synchronise. begin returns false when the back end
-  // cannot record right now (no support, profiling on); end returns nullptr when the recording
-  // failed — the caller then runs the code normally.
-  virtual bool graph_capture_begin() { return false; }
-  virtual void *graph_capture_end() { return nullptr; }
-  virtual void graph_launch(void * /*graph*/) {}
-  virtual void graph_destroy(void * /*graph*/) {}
 
   // profiling of the scan kernels (HIP events on the launch stream)
   virtual void profile_enable(int /*level*/) {}

@@ -317,7 +317,7 @@ int ppals_cp_set_schedule(ppals_cp *s, int schedule) {
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }
-int ppals_cp_get_schedule(const ppals_cp *s) { return s ? s->eng->schedule() : PPALS_ERR_ARG; }
+int ppals_cp_get_schedule(const ppals_cp *s) { return s && s->eng ? s->eng->schedule() : PPALS_ERR_ARG; }
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda) {
   if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
@@ -492,6 +492,7 @@ int ppals_tucker_sweeps_dt(ppals_tucker *s, int n) {
   if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN
   for (int i = 0; i < n; i++) s->eng->sweep_dt();
+  s->eng->settle();
   return PPALS_OK;
   API_END(PPALS_ERR_HIP)
 }

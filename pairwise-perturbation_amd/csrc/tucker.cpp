@@ -52,6 +52,7 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   ops_.zero(core_prev_, sizeof(double) * ncore_);
   G_ = (double *)ops_.alloc(sizeof(double) * maxs * maxs);
   if (const char *e = std::getenv("PPALS_TUCKER_THIN")) thin_enabled_ = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PPALS_TUCKER_DEFER")) defer_enabled_ = std::atoi(e) != 0;
   scal_ = (double *)ops_.alloc(sizeof(double) * 64);
   yend_elems_ = ncore_ / r_[N_ - 1] * V_.glens[N_ - 1];
   Yend_ = (double *)ops_.alloc(sizeof(double) * yend_elems_);
@@ -99,6 +100,7 @@ TuckerEngine::~TuckerEngine() {
   } catch (...) {
   }
   for (auto p : W_) ops_.free(p);
+  for (auto p : Wsave_) ops_.free(p);
   for (auto &n : nodes_) ops_.free(n.buf);
   ops_.free(core_);
   ops_.free(core_prev_);
@@ -347,6 +349,7 @@ double *TuckerEngine::ttmc_chain(int skip, int64_t *elems) {
 }
 
 int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
+  settle_all();
   int64_t e;
   double *Y = ttmc_chain(skip, &e);
   // sharded: skip == 0 returns the local rows, every other result is summed over the ranks
@@ -355,7 +358,15 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
   return e;
 }
 
+void TuckerEngine::ensure_core() {
+  if (!core_owed_) return;
+  core_owed_ = false;
+  int64_t Lc = ncore_ / r_[N_ - 1];
+  ops_.ttm_keep(yend_src_, F64, Lc, V_.glens[N_ - 1], 1, W_[N_ - 1], V_.glens[N_ - 1], r_[N_ - 1], core_);
+}
+
 void TuckerEngine::compute_core_full() {
+  core_owed_ = false;
   int64_t e;
   double *Y = ttmc_chain(-1, &e);
   if (dist_) comm_.allreduce_sum(Y, ncore_);
@@ -367,6 +378,8 @@ void TuckerEngine::compute_core_full() {
 // W_i W_i^T only. Whoever needs the eigenvectors one by one, sorted — the caller reading the
 // factors, the PP phases that difference them — asks here: W_i <- W_i Y_i, core <- core x_i Y_i.
 void TuckerEngine::finalize_rotations() {
+  settle_all();  // (no factor is read, rotated or published with an unchecked step behind it)
+  ensure_core();
   for (int i = 0; i < N_; i++) {
     const double *Y = ops_.eig_pending_rotation(eig_base_ + i);
     if (!Y) continue;
@@ -384,6 +397,7 @@ void TuckerEngine::finalize_rotations() {
   }
 }
 void TuckerEngine::drop_rotations() {
+  settle_all();
   for (int i = 0; i < N_; i++) ops_.eig_rotation_done(eig_base_ + i);
 }
 
@@ -400,9 +414,10 @@ void TuckerEngine::set_factors(const double *Wflat) {
 // becomes the `core` argument (and the initial core_prev) of the next alsTucker_DT / _PP call
 void TuckerEngine::set_core(const double *core) {
   finalize_rotations();
-  if (core)
+  if (core) {
+    core_owed_ = false;
     ops_.h2d(core_, core, sizeof(double) * ncore_);
-  else
+  } else
     compute_core_full();
 }
 void TuckerEngine::get_factors(double *Wflat, double *core) {
@@ -421,6 +436,7 @@ void TuckerEngine::get_factors(double *Wflat, double *core) {
 // hosvd (als_Tucker.cxx:12-70): W_i = leading eigenvectors of the Gram of the mode-i unfolding of
 // V (K13), then core = V x_i W_i^T
 void TuckerEngine::hosvd() {
+  settle_all();
   for (int i = 0; i < N_; i++) {
     int64_t L = 1, T = 1;
     for (int q = 0; q < i; q++) L *= ext(q);
@@ -493,23 +509,102 @@ void TuckerEngine::sweep_dt() { sweep_body(nullptr); }
 // one HOOI sweep; align_ref != nullptr: column signs aligned with that factor set after every
 // eigen-step (alsTucker_DT_sub, als_Tucker.cxx:632-643)
 void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
+  const bool may_defer = defer_enabled_ && align_ref == nullptr && !dist_;
+  if (!may_defer) settle_all();
   for (auto &n : nodes_) n.valid = false;  // ttmc_map.clear(), als_Tucker.cxx:340
   for (int i = 0; i < N_; i++) {
-    compute_node(leaf_[i]);
-    const Node &lf = nodes_[leaf_[i]];
-    int64_t L = 1, T = 1;
-    for (int q = 0; q < i; q++) L *= r_[q];
-    for (int q = i + 1; q < N_; q++) T *= r_[q];
-    double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
-    if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);  // als_Tucker.cxx:395
-    ops_.eig_lazy(eig_base_ + i, align_ref == nullptr && !dist_);
-    factor_update(i, Y, L, T);  // K12
-    if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
+    if (may_defer) settle_mode(i);
+    mode_step(i, align_ref, may_defer);
   }
-  // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408)
-  int64_t L = ncore_ / r_[N_ - 1];
-  ops_.ttm_keep(Yend_, F64, L, V_.glens[N_ - 1], 1, W_[N_ - 1], V_.glens[N_ - 1], r_[N_ - 1],
-                core_);
+}
+
+void TuckerEngine::mode_step(int i, const std::vector<double *> *align_ref, bool may_defer) {
+  compute_node(leaf_[i]);
+  const Node &lf = nodes_[leaf_[i]];
+  int64_t L = 1, T = 1;
+  for (int q = 0; q < i; q++) L *= r_[q];
+  for (int q = i + 1; q < N_; q++) T *= r_[q];
+  double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
+  if (i == N_ - 1) {  // als_Tucker.cxx:395
+    // (one GPU: the leaf's own buffer stays as it is until this mode is stepped again — no copy)
+    if (dist_) {
+      ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
+      yend_src_ = Yend_;
+    } else {
+      yend_src_ = Y;
+    }
+  }
+  ops_.eig_lazy(eig_base_ + i, align_ref == nullptr && !dist_);
+  ops_.eig_defer(eig_base_ + i, may_defer);
+  if (may_defer) {
+    // the step writes the new factor into the spare buffer; the one it replaces stays intact
+    if (Wsave_.empty()) Wsave_.assign(N_, nullptr);
+    if (!Wsave_[i]) Wsave_[i] = (double *)ops_.alloc(sizeof(double) * V_.glens[i] * r_[i]);
+    std::swap(W_[i], Wsave_[i]);
+  }
+  factor_update(i, Y, L, T);  // K12
+  ops_.eig_defer(eig_base_ + i, false);
+  if (align_ref) ops_.sign_align(W_[i], (*align_ref)[i], V_.glens[i], r_[i]);
+  // core = Y_end x_{N-1} W[N-1]  (als_Tucker.cxx:408): owed until somebody reads it (ensure_core) —
+  // the print blocks recompute the core from the tensor anyway (als_Tucker.cxx:290), so inside a run
+  // of sweeps this product (a launch-bound 30 us at cfg5) served nobody
+  if (i == N_ - 1) core_owed_ = true;
+  if (may_defer && (!defer_log_.empty() || ops_.eig_deferred(eig_base_ + i))) defer_log_.push_back(i);
+}
+
+void TuckerEngine::settle_mode(int i) {
+  if (defer_log_.empty()) return;
+  const int v = ops_.eig_verify(eig_base_ + i);
+  if (v < 0) return;  // nothing of this mode is waiting
+  if (defer_log_.front() != i) throw std::logic_error("ppals: deferred eigen-steps out of order");
+  if (v == 1) {
+    rollback_and_redo();
+    return;
+  }
+  defer_log_.erase(defer_log_.begin());
+  while (!defer_log_.empty() && !ops_.eig_deferred(eig_base_ + defer_log_.front()))
+    defer_log_.erase(defer_log_.begin());  // (steps that were checked on the spot)
+}
+
+void TuckerEngine::settle_all() {
+  while (!defer_log_.empty()) {
+    const int i = defer_log_.front();
+    if (ops_.eig_verify(eig_base_ + i) == 1) {
+      rollback_and_redo();
+      return;
+    }
+    defer_log_.erase(defer_log_.begin());
+  }
+}
+
+// The oldest step of the log was not accepted: its factor and everything computed from it since
+// is void. Every mode stepped since then gets back the factor that step replaced (a basis of the
+// right subspace is all the sweep needs of it), unchecked steps among them are dropped, and the
+// same steps are made again in the same order, each checked before the next one starts.
+void TuckerEngine::rollback_and_redo() {
+  const std::vector<int> steps = defer_log_;
+  defer_log_.clear();
+  defer_rollbacks_++;
+  if (std::getenv("PPALS_TUCKER_DEFER_DEBUG")) {
+    fprintf(stderr, "[ppals tucker] eigen-step of mode %d not accepted: repeating %d step(s):", steps[0],
+            (int)steps.size());
+    for (int j : steps) fprintf(stderr, " %d", j);
+    fprintf(stderr, "\n");
+  }
+  ops_.sync();
+  for (size_t k = 0; k < steps.size(); k++) {
+    const int j = steps[k];
+    if (k > 0) ops_.eig_verify(eig_base_ + j, true);
+    std::swap(W_[j], Wsave_[j]);
+    ops_.eig_rotation_done(eig_base_ + j);  // (the rotation owed belonged to the discarded factor)
+  }
+  for (int j : steps) {
+    for (auto &n : nodes_) n.valid = false;
+    mode_step(j, nullptr, false);
+  }
+  // (whatever the sweep in progress needs of the tree is rebuilt from the factors as they are now:
+  // a leaf left valid here would be taken for this sweep's by the step that comes to it)
+  for (auto &n : nodes_) n.valid = false;
 }
 
 // rank-agreed stop decision (see CpEngine::agree): the time limit reads a rank-local clock
@@ -523,6 +618,7 @@ bool TuckerEngine::agree(bool local) {
 }
 
 double TuckerEngine::core_norm() {
+  ensure_core();
   ops_.sumsq(core_, ncore_, scal_);
   ops_.sumsq(core_prev_, ncore_, scal_ + 1);
   double h[2];
@@ -533,6 +629,7 @@ double TuckerEngine::core_norm() {
 // ||core x_i W_i - V||_F (als_Tucker.cxx:296-310) without materialising the model tensor: expand
 // every mode but the last into Q (prod s_0..s_{N-2} x r_{N-1}), then V^ = Q W_{N-1}^T is streamed.
 double TuckerEngine::residual() {
+  ensure_core();
   std::vector<int64_t> dims(N_);
   for (int m = 0; m < N_; m++) dims[m] = r_[m];
   const double *cur = core_;
@@ -579,11 +676,13 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
   }
   const bool talk = o.verbose && rank_ == 0;
   double st_time = now();
+  ensure_core();
   ops_.d2d(core_prev_, core_, sizeof(double) * ncore_);  // Tensor<> core_prev(core)
   double diffnorm = 1000, diffnorm_V = 1000;
   int iter;
   for (iter = 0; iter <= o.maxiter; iter++) {
     if ((iter % o.resprint == 0 && iter != 0) || iter == 1 || iter == o.maxiter) {
+      settle_all();
       ops_.sync();
       const double st_time1 = now();
       compute_core_full();  // TTMc(core, V, W, -1)
@@ -613,6 +712,7 @@ int TuckerEngine::run_dt(const CpOpts &o, int *iters) {
     sweep_dt();
     if (iter % 10 == 0 && talk) printf(".");
   }
+  settle_all();
   ops_.sync();
   if (talk) {
     printf("\nIter = %d Final Diff norm %E \n", iter, diffnorm);
@@ -716,6 +816,9 @@ void TuckerEngine::sweep_pp() {
       }
     }
     if (i == N_ - 1) ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
+    // (the PP phase differences the eigenvectors one by one: never "any basis of the subspace",
+    // whatever the slot's last exact sweep allowed — pp_bench enters here without a dt_sub)
+    ops_.eig_lazy(eig_base_ + i, false);
     factor_update(i, Y, L, T);  // K12
     ops_.sign_align(W_[i], Winit_[i], V_.glens[i], r_[i]);  // als_Tucker.cxx:874-885
     double *A[1] = {W_[i]}, *B[1] = {Winit_[i]}, *D[1] = {dW_[i]};
@@ -723,6 +826,7 @@ void TuckerEngine::sweep_pp() {
     ops_.diff_norms(A, B, n, 1, 1, D, 0, scal_ + 4);  // dW = W - W_init (als_Tucker.cxx:887)
   }
   int64_t L = ncore_ / r_[N_ - 1];
+  core_owed_ = false;
   ops_.ttm_keep(Yend_, F64, L, V_.glens[N_ - 1], 1, W_[N_ - 1], V_.glens[N_ - 1], r_[N_ - 1],
                 core_);
 }
@@ -730,6 +834,7 @@ void TuckerEngine::sweep_pp() {
 bool TuckerEngine::print_block(const CpOpts &o, int iter, int pp_flag, double &diffnorm,
                                double &diffV, std::ofstream *csv, double &st_time,
                                bool stop_at_maxiter) {
+  settle_all();
   ops_.sync();
   const double st_time1 = now();
   compute_core_full();
@@ -859,6 +964,7 @@ void TuckerEngine::pp_sub(const CpOpts &o, double tol_init, double &diffnorm, in
 
 int TuckerEngine::run_pp(const CpOpts &o, int *iters) {
   finalize_rotations();  // the PP phases difference the eigenvectors themselves
+  for (int i = 0; i < N_; i++) ops_.eig_lazy(eig_base_ + i, false);
   std::ofstream csv;
   std::ofstream *pcsv = nullptr;
   if (rank_ == 0 && !o.csv_path.empty()) {

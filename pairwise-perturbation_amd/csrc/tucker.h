@@ -19,6 +19,8 @@ class TuckerEngine {
   void hosvd();                          // als_Tucker.cxx:12-70
   int64_t ttmc(int skip, double *Yhost);  // als_Tucker.cxx:76-110
   void sweep_dt();                       // als_Tucker.cxx:340-408
+  void settle() { settle_all(); }        // every eigen-step behind the current factors is a checked one
+  int rollbacks() const { return defer_rollbacks_; }
   int run_dt(const CpOpts &o, int *iters);  // alsTucker_DT, als_Tucker.cxx:240-424
   int run_pp(const CpOpts &o, int *iters);  // alsTucker_PP, als_Tucker.cxx:906-962
 
@@ -42,6 +44,9 @@ class TuckerEngine {
   // W_i = the r_i leading left singular vectors of the mode-i unfolding of Y = [L, s_i, T]
   void factor_update(int i, const double *Y, int64_t L, int64_t T);
   void compute_core_full();
+  void ensure_core();  // the core the last exact sweep owes: Y_end x_{N-1} W_{N-1}
+  bool core_owed_ = false;
+  const double *yend_src_ = nullptr;
   double core_norm();
   bool agree(bool local);
   double residual();
@@ -84,6 +89,21 @@ class TuckerEngine {
   const PPOp &pp_get(const std::string &args);
   void pp_clear();
   void sweep_body(const std::vector<double *> *align_ref);
+  // one mode of a HOOI sweep: leaf tensor, eigen-step, (last mode) the core
+  void mode_step(int i, const std::vector<double *> *align_ref, bool may_defer);
+  // Deferred acceptance of eigen-steps (Ops::eig_defer / eig_verify): inside plain sweeps the host
+  // does not wait for a step's checks — it enqueues ahead of the device — and asks for them when it
+  // comes back to the mode (or before anything is published: print blocks, get_factors, the PP
+  // phases). `defer_log_` = the modes stepped since the oldest unchecked step, in order; Wsave_[m] =
+  // the factor the latest step of mode m replaced. A step that was NOT accepted: every factor
+  // stepped since goes back to what it was and those steps are repeated, checked one by one.
+  std::vector<int> defer_log_;
+  std::vector<double *> Wsave_;
+  bool defer_enabled_ = true;  // PPALS_TUCKER_DEFER=0: off
+  int defer_rollbacks_ = 0;
+  void settle_mode(int i);  // before mode i is stepped again
+  void settle_all();        // before anything derived from the factors is read
+  void rollback_and_redo();
   void sweep_pp();
   bool print_block(const CpOpts &o, int iter, int pp_flag, double &diffnorm, double &diffV,
                    std::ofstream *csv, double &st_time, bool stop_at_maxiter);

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 #include <vector>
@@ -79,6 +80,10 @@ void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, std::vect
 
 class HostOps : public Ops {
  public:
+  HostOps() {
+    if (const char *e = std::getenv("PPALS_HOSTSIM_DEFER")) sim_defer_ = std::atoi(e);
+    if (const char *e = std::getenv("PPALS_HOSTSIM_DEFER_FAIL")) sim_fail_every_ = std::atoi(e);
+  }
   void *alloc(size_t bytes) override { return std::calloc(1, bytes ? bytes : 8); }
   void free(void *p) override { std::free(p); }
   void h2d(void *d, const void *s, size_t n) override { std::memcpy(d, s, n); }
@@ -406,6 +411,41 @@ class HostOps : public Ops {
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return w[a] > w[b]; });
     for (int k = 0; k < rank; k++)
       for (int64_t i = 0; i < J; i++) U[i + J * k] = Q[i + (size_t)J * ord[k]];
+  }
+  // Deferred acceptance, simulated (Ops::eig_defer / eig_verify): with PPALS_HOSTSIM_DEFER=1 every
+  // warm step of a slot that allows it returns "unchecked"; PPALS_HOSTSIM_DEFER_FAIL=n makes every
+  // n-th of them hand out a WRONG basis (unit vectors) that eig_verify then reports as not accepted —
+  // the engine has to notice, roll back every factor stepped since and repeat the work.
+  struct SimSlot {
+    bool defer = false, pending = false, bad = false;
+  };
+  std::map<int, SimSlot> sim_slots_;
+  int sim_defer_ = 0, sim_fail_every_ = 0, sim_count_ = 0, sim_failed_ = 0;
+  void top_eigvecs_warm(double *G, int64_t J, int rank, double *U, int slot) override {
+    top_eigvecs(G, J, rank, U);
+    if (!sim_defer_ || slot < 0) return;
+    SimSlot &sl = sim_slots_[slot];
+    if (!sl.defer) return;
+    if (sl.pending) throw std::logic_error("hostsim: slot stepped again with an unchecked step behind it");
+    sl.pending = true;
+    sl.bad = sim_fail_every_ > 0 && ++sim_count_ % sim_fail_every_ == 0;
+    if (sl.bad)
+      for (int k = 0; k < rank; k++)
+        for (int64_t i = 0; i < J; i++) U[i + J * k] = (i == (k * 7 + 3) % J) ? 1.0 : 0.0;
+  }
+  void eig_defer(int slot, bool on) override {
+    if (slot >= 0) sim_slots_[slot].defer = on;
+  }
+  bool eig_deferred(int slot) override {
+    auto it = sim_slots_.find(slot);
+    return it != sim_slots_.end() && it->second.pending;
+  }
+  int eig_verify(int slot, bool discard) override {
+    auto it = sim_slots_.find(slot);
+    if (it == sim_slots_.end() || !it->second.pending) return -1;
+    it->second.pending = false;
+    if (it->second.bad) sim_failed_++;
+    return (it->second.bad || discard) ? 1 : 0;
   }
   bool orthonormalize(double *U, int64_t rows, int r) override {  // modified Gram-Schmidt, twice
     double nmax = 0;

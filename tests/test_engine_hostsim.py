@@ -118,3 +118,53 @@ def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
                  "PPALS_PLACE_LAYOUTS": "2", "PPALS_PLACE_PREFER_BLOCK": "2"})   # odd roots elsewhere
     for a, b, c_, d in zip(plain, tuned, one, mixed):
         assert (a == b).all() and (a == c_).all() and (a == d).all()
+
+
+@pytest.mark.parametrize("lens,ranks", [([12, 10, 9], [3, 4, 2]), ([9, 8, 7, 6], [3, 2, 3, 2])])
+@pytest.mark.parametrize("fail_every", [0, 1, 2, 3, 7])
+def test_tucker_deferred_eigen_steps_roll_back(pp, lens, ranks, fail_every, monkeypatch, tmp_path):
+    """Deferred acceptance of eigen-steps (Ops::eig_defer / eig_verify, tucker.cpp settle_mode /
+    rollback_and_redo): the stand-in returns every warm step of a plain sweep UNCHECKED and, every
+    n-th time, with a wrong basis that the later check reports. The engine must notice before it
+    steps the mode again or prints a row, put back every factor stepped since and repeat the work:
+    CSV rows, projectors and ||core|| equal to the oracle's whatever the failure pattern."""
+    import numpy as np
+    import oracle_lib as O
+    monkeypatch.setenv("PPALS_HOSTSIM_DEFER", "1")
+    monkeypatch.setenv("PPALS_HOSTSIM_DEFER_FAIL", str(fail_every))
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
+    V = O.fill_uniform(int(np.prod(lens)), 4, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W0, c0 = O.hosvd(V, ranks)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    kw = dict(tol=0.0, maxiter=7, resprint=3)
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, csv=c_ref, **kw)
+    c = pp.Context(0)
+    t = pp.Tensor(c, lens, 1).upload(V)
+    s = pp.Tucker(c, t, ranks)
+    s.hosvd()
+    s.set_factors(W0)
+    rc, it = s.run_dt(csv=c_got, **kw)
+    assert it == it_ref
+    W, core = s.get_factors()
+    for a, b in zip(W, W_ref):
+        assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-10 * np.linalg.norm(core_ref)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert len(r1) == len(r2)
+    for a, b in zip(r1, r2):
+        assert a[1] == b[1] and abs(a[2] - b[2]) < 1e-9 and abs(a[5] - b[5]) < 1e-9 * np.linalg.norm(V)
+    # the sweep entry point: every step behind the factors it returns has been checked
+    # (one session, call after call: the failure pattern walks over every mode and sweep position —
+    # this is where a leaf left valid by a repeated step was once taken for the next sweep's)
+    for n in (2, 5, 6, 7):
+        s.set_factors(W0)
+        s.set_core(None)
+        s.sweeps_dt(n)
+        Wn, _ = s.get_factors()
+        _, _, Wn_ref, _ = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=n - 1, resprint=10 ** 9)
+        for a, b in zip(Wn, Wn_ref):
+            assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9, (n, fail_every)
+    s.close()
+    t.close()
+    c.close()

@@ -179,6 +179,91 @@ def _decaying_tensor(lens, inner, seed, noise):
     return np.asfortranarray(V + noise * np.linalg.norm(V) / np.linalg.norm(E) * E)
 
 
+@pytest.mark.parametrize("fail_every", [0, 2, 5])
+def test_deferred_eigen_step_checks(pp, fail_every, tmp_path, monkeypatch, capfd):
+    """Deferred acceptance (Ops::eig_defer / eig_verify, hip_ops.hip; TuckerEngine::settle_mode /
+    rollback_and_redo): once a slot's steps go through as scheduled, a plain HOOI sweep no longer
+    waits for their checks — they are read when the engine comes back to the mode, or before a row
+    is printed. 14 sweeps on mode extents above 64 against the oracle's full eigen-decompositions
+    (projectors, ||core||, CSV rows), with PPALS_EIG_DEFER_FAIL=n turning every n-th deferred check
+    into a failure: the engine must put back every factor stepped since and repeat those steps. The
+    step log must show deferred checks (and the forced failures)."""
+    lens, ranks = [96, 80, 72], [5, 6, 4]
+    V = _decaying_tensor(lens, [10, 9, 8], 5, 0.05)
+    W0, c0 = O.hosvd(V, ranks)
+    c_ref, c_got = str(tmp_path / "r.csv"), str(tmp_path / "g.csv")
+    kw = dict(tol=0.0, maxiter=13, resprint=5)
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, csv=c_ref, **kw)
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    if fail_every:
+        monkeypatch.setenv("PPALS_EIG_DEFER_FAIL", str(fail_every))
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    s.set_factors(W0)
+    s.set_core(c0)
+    capfd.readouterr()
+    rc, it = s.run_dt(csv=c_got, **kw)
+    assert it == it_ref
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+        assert relerr(proj(a), proj(b)) < 1e-7, (fail_every, relerr(proj(a), proj(b)))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    _, r1 = O.read_csv(c_ref)
+    _, r2 = O.read_csv(c_got)
+    assert len(r1) == len(r2)
+    for a, b in zip(r1, r2):
+        assert a[1] == b[1] and abs(a[5] - b[5]) < 1e-8 * np.linalg.norm(V)
+    ndef = err.count("accepted (deferred check)")
+    nfail = err.count("NOT accepted (deferred check)")
+    assert ndef >= 6, err[-3000:]
+    assert (nfail >= 2) if fail_every else (nfail == 0), (fail_every, nfail, err[-3000:])
+    s.close()
+    t.close()
+    c2.close()
+
+
+def test_tucker_bench_pp_after_dt_large_mode(pp, ctx, tmp_path, monkeypatch):
+    """pp_bench's call order on ONE session with a mode extent above 64 (advisor, round 3): run_dt
+    leaves the slots in 'any basis of the subspace' mode, and run_pp(bench=1) skips the DT_sub that
+    used to switch it off — the PP sweeps must still difference sorted eigenvectors. Compared with the
+    oracle's alsTucker_DT + alsTucker_PP(bench) from the same factors: projectors, ||core||, and dW
+    small enough that the PP corrections are corrections (the factors stay orthonormal)."""
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")  # the s x s route is the one with lazy eigenvectors
+    lens, ranks = [96, 20, 18], [4, 3, 3]
+    V = _decaying_tensor(lens, [8, 7, 6], 11, 0.02)
+    W0, c0 = O.hosvd(V, ranks)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    s.set_factors(W0)
+    kw = dict(tol=1e-14, maxiter=3, resprint=1)
+    c_ref, c_got = str(tmp_path / "ref.csv"), str(tmp_path / "got.csv")
+    for c in (c_ref, c_got):
+        open(c, "w").write("[timetype],[dtime]\n")
+    rc_ref, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, csv=c_ref, bench=1, **kw)
+    rc, it = s.run_dt(csv=c_got, csv_append=1, bench=1, **kw)
+    assert (rc, it) == (rc_ref, it_ref)
+    # NO get_factors() here: it would finalise the rotations and hide the bug
+    rc_ref, it_ref, W_ref, core_ref = O.als_tucker_pp(V, W_ref, core_ref, tol_init=0.05, csv=c_ref,
+                                                      bench=1, **kw)
+    rc, it = s.run_pp(tol_init=0.05, csv=c_got, csv_append=1, bench=1, **kw)
+    assert (rc, it) == (rc_ref, it_ref)
+    W_got, core_got = s.get_factors()
+    for a, b, r in zip(W_got, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-6
+    assert abs(np.linalg.norm(core_got) - np.linalg.norm(core_ref)) < 1e-8 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("lens,ranks", [([96, 80, 72], [5, 6, 4]), ([130, 70, 66], [8, 3, 5])])
 def test_eigen_step_projector_route_matches_oracle(pp, ctx, lens, ranks, tmp_path, monkeypatch):
     """mode extents above 64: from the second HOOI sweep on, the eigen-step is the spectral
