@@ -109,8 +109,11 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_LAZY")) eig_lazy_ok_ = atoi(v);
+    if (const char *v = getenv("PPALS_SYM_LDS_MIN")) sym_lds_min_ = std::max(32, atoi(v));
     if (const char *v = getenv("PPALS_EIG_DEFER")) eig_defer_ok_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_jacobi_onesided,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_small,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
@@ -134,6 +137,7 @@ class HipOps : public Ops {
     if (ws_orth_) hipFree(ws_orth_);
     if (ws_pow_) hipFree(ws_pow_);
     if (ws_cold_) hipFree(ws_cold_);
+    if (ws_jac_) hipFree(ws_jac_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
     for (auto &kv : eig_state_) {
@@ -1115,10 +1119,8 @@ class HipOps : public Ops {
         transpose_batched(X, F64, L, J, T, Ym);
         A = Ym;
       }
-      const int nt = (int)((J + 15) / 16);
       prof_begin(1, (double)C * J * 8.0);
-      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(512), 0, st_, A, J,
-                         A, J, (const double *)nullptr, (int64_t)0, G, J, (int)J, (int)C, 1.0, 0.0);
+      sym_product(A, J, A, J, nullptr, 0, G, J, (int)J, (int)C, 1.0, 0.0);
       prof_end();
       HIP_CHECK(hipGetLastError());
       return;
@@ -1190,6 +1192,21 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       return;
     }
+    if (J <= kJacobiBigMax) {
+      // 64 < J <= 128 (the small side of a tall unfolding at core ranks 70-100, a short mode): the
+      // whole eigen-decomposition by the one-workgroup one-sided Jacobi, no vendor library
+      double *w = (double *)ensure(ws_jac_, ws_jac_sz_, sizeof(double) * (2 * (size_t)J * J + 2 * J));
+      double *Vt = w, *Y = Vt + J * J, *evd = Y + J * J, *D = evd + J;
+      const size_t lds = sizeof(double) * ((size_t)J * (J + 1) + 256) + sizeof(int) * 256;
+      hipLaunchKernelGGL(k_jacobi_onesided, dim3(1), dim3(1024), lds, st_, G, (int)J, Vt, Y, evd, (double *)nullptr);
+      HIP_CHECK(hipMemcpyAsync(U, Y, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
+      // (eig_bootstrap reads the eigenvalues ASCENDING from the start of ws_krp_, as dsyevd leaves them)
+      double *Dk = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * (2 * J + 2));
+      hipLaunchKernelGGL(k_reverse_copy, dim3(1), dim3(256), 0, st_, evd, (int)J, Dk);
+      (void)D;
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     RocSolver &rs = rocsolver();
     double *D = (double *)ensure(ws_krp_, ws_krp_sz_, sizeof(double) * (2 * J + 2));
     double *E = D + J;
@@ -1201,8 +1218,10 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
   static constexpr int kTailBlocks = 64;
-  // the one read-back of a projector step: chk[16] | evW[64] | status (4 doubles) | lamD[64] | residual shares
-  static constexpr size_t kEigReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
+  // the one read-back of a projector step (layout: kernels_eig.hip.h, kEigOff*)
+  static_assert(kTailBlocks == 64, "residual shares: 64 words");
+  static constexpr size_t kEE = (size_t)kEigEvMax * kEigEvMax;  // a (rank + wide)^2 scratch matrix
+  static constexpr size_t kEigReadback = sizeof(double) * kEigChkDoubles;
   // ---- K12 inside a HOOI iteration: spectral projector by the scaled Newton-Schulz sign iteration
   // (kernels_eig.hip.h), warm-started per slot, verified by trace(P) == rank, else the full solver.
   struct EigState {
@@ -1224,7 +1243,7 @@ class HipOps : public Ops {
     hipEvent_t ev_h = nullptr, ev_done = nullptr;
     double *Q = nullptr;                  // previous basis (J x rank)
     double *Qn = nullptr;                 // spare buffer of the same size (the step's result lands here)
-    double evh[64] = {0};                 // eigenvalues of the last accepted step (descending)
+    double evh[kEigEvMax] = {0};          // eigenvalues of the last accepted step (descending)
     int fast = 0, full = 0;
     // deferred acceptance (eig_defer / eig_verify): the step's read-back lands in the slot's own
     // pinned block behind ev_chk; what the checks need from the time of the call is kept in `dp`
@@ -1241,6 +1260,26 @@ class HipOps : public Ops {
     } dp;
     int n_deferred = 0, n_defer_failed = 0;
   };
+  // The symmetric product C = alpha A Bt^T + beta D of the sign iteration (and of the leaf Grams),
+  // by size: a few hundred rows are a latency problem — one 16 x 16 tile per workgroup, eight waves
+  // splitting K — from sym_lds_min_ rows on (PPALS_SYM_LDS_MIN, 768: tools/nsprod_bench.hip,
+  // profiles/r04d_nsprod_*.txt: 640 rows 18.6 vs 21.3 us, 896 rows 35.6 vs 30.8, 1344 rows 88.6 vs
+  // 68.1) it is 2 J^3 flops — 32 x 32 tiles staged through LDS. sym_tiles() = workgroups = check-sum
+  // partials per product.
+  unsigned sym_tiles(int M) const {
+    const unsigned nt = (unsigned)((M + (M >= sym_lds_min_ ? 31 : 15)) / (M >= sym_lds_min_ ? 32 : 16));
+    return nt * (nt + 1) / 2;
+  }
+  void sym_product(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D, int64_t ldd,
+                   double *C, int64_t ldc, int M, int K, double alpha, double beta, int chk_mode = 0,
+                   double *chk_part = nullptr) {
+    if (M >= sym_lds_min_)
+      hipLaunchKernelGGL(k_dgemm_nt_sym_lds<32>, dim3(sym_tiles(M)), dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C,
+                         ldc, M, K, alpha, beta, chk_mode, chk_part);
+    else
+      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(sym_tiles(M)), dim3(512), 0, st_, A, lda, Bt, ldb, D, ldd, C, ldc,
+                         M, K, alpha, beta, chk_mode, chk_part);
+  }
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
@@ -1267,12 +1306,12 @@ class HipOps : public Ops {
     // ||G||_F^2 = sum of squared eigenvalues: taken before dsyevd overwrites G
     top_eigvecs(G, J, rank, U);
     es.full++;
-    if (J <= 64 || rank >= J || rank > 64) {
+    if (J <= 64 || rank >= J || rank + 16 > kEigEvMax) {
       es.valid = false;
       return;
     }
     // dsyevd left the ascending eigenvalues in ws_krp_ (D)
-    double lam[65];
+    double lam[kEigEvMax + 1];
     const double *D = (const double *)ws_krp_;
     HIP_CHECK(hipMemcpyAsync(lam, D + (J - rank - 1), (rank + 1) * sizeof(double),
                              hipMemcpyDeviceToHost, st_));
@@ -1300,6 +1339,14 @@ class HipOps : public Ops {
   // non-zero status as a failure then.
   double *chol_qr2(double *cur, double *nxt, int64_t J, int r, double *C, int *status,
                    int npass = 2) {
+    if (r > 64) {
+      // more columns than the one-wave Cholesky holds (core ranks above 48, test_ALS.cxx:366-379):
+      // block Gram-Schmidt, 64 columns at a time, in place — its own read-back says whether it held
+      const int st[2] = {orthonormalize(cur, J, r) ? 0 : 1, 0};
+      HIP_CHECK(hipMemcpyAsync(status, st, sizeof(int) * std::min(npass, 2), hipMemcpyHostToDevice, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      return cur;
+    }
     const size_t lds_chol = sizeof(double) * 2 * (size_t)r * r;
     for (int pass = 0; pass < npass; pass++) {
       hipLaunchKernelGGL(k_tn_small, dim3((r * r + 15) / 16), dim3(1024), 0, st_, cur, cur, J, r, C);
@@ -1347,6 +1394,18 @@ class HipOps : public Ops {
                      double *H, double *Yr, double *U, double *ev, double *GU) {
     transpose2d(B, F64, J, r, Bt);
     gemm_nt(G, J, Bt, r, nullptr, 0, GB, J, (int)J, r, (int)J, 1.0, 0.0);
+    if (r > 64) {
+      // above the in-LDS two-sided Jacobi: H = B^T (G B) and the products with Y on the matrix
+      // cores, the eigen-decomposition of H by the one-workgroup one-sided Jacobi (r <= 128)
+      if (r > kJacobiBigMax) throw std::runtime_error("ppals: Rayleigh-Ritz supports at most 128 columns");
+      gemm_nn(Bt, r, GB, J, nullptr, 0, H, r, r, r, (int)J, 1.0, 0.0);
+      double *Vt = (double *)ensure(ws_jac_, ws_jac_sz_, sizeof(double) * (size_t)r * r);
+      const size_t lds = sizeof(double) * ((size_t)r * (r + 1) + 256) + sizeof(int) * 256;
+      hipLaunchKernelGGL(k_jacobi_onesided, dim3(1), dim3(1024), lds, st_, H, r, Vt, Yr, ev, (double *)nullptr);
+      gemm_nn(B, J, Yr, r, nullptr, 0, U, J, (int)J, r, r, 1.0, 0.0);
+      if (GU) gemm_nn(GB, J, Yr, r, nullptr, 0, GU, J, (int)J, r, r, 1.0, 0.0);
+      return;
+    }
     hipLaunchKernelGGL(k_tn_small, dim3((r * r + 15) / 16), dim3(1024), 0, st_, B, GB, J, r, H);
     launch_top_eig_small(H, r, r, Yr, ev);
     hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * r, 256)), dim3(256),
@@ -1402,7 +1461,8 @@ class HipOps : public Ops {
       top_eigvecs_small_warm(G, J, rank, U, slot);
       return;
     }
-    if (J <= 64 || rank > 64 || rank >= J || slot < 0 || !eig_fast_) {
+    // (up to core rank 112: rank + 16 columns of a wide tail / cold start must fit kEigEvMax)
+    if (J <= 64 || rank + 16 > kEigEvMax || rank + 16 >= J || slot < 0 || !eig_fast_) {
       top_eigvecs(G, J, rank, U);
       return;
     }
@@ -1432,7 +1492,8 @@ class HipOps : public Ops {
     }
     es.valid = false;
     if (eig_debug_)
-      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: full solver (dsyevd)\n", slot, (long long)J, rank);
+      fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: full solver (%s)\n", slot, (long long)J, rank,
+              J <= kJacobiBigMax ? "one-sided Jacobi, one workgroup" : "dsyevd");
     eig_bootstrap(es, G, J, rank, U);
   }
   // Warm-start state belongs to the SESSION that made it: a session draws a block of 64 slots
@@ -1495,7 +1556,7 @@ class HipOps : public Ops {
                        bool fused_tail, bool fused_scale, bool lazy_used) const {
     StepCheck c;
     const double *evn = hc + 16;
-    const int *hs = (const int *)(evn + 64);
+    const int *hs = (const int *)(hc + kEigOffStatus);
     c.cnt = 0.5 * (hc[1] + (double)J);
     c.res = std::sqrt(hc[4]);
     c.rho_now = fused_scale ? rho : 1.0001 * std::sqrt(hc[8]);
@@ -1529,7 +1590,7 @@ class HipOps : public Ops {
     HIP_CHECK(hipEventSynchronize(es.ev_chk));
     double *hc = es.chk_pinned;
     {
-      const double *rp = hc + 16 + 64 + 4 + 64;
+      const double *rp = hc + kEigOffResp;
       double r2 = 0;
       for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
       hc[4] = r2;
@@ -1538,7 +1599,7 @@ class HipOps : public Ops {
     bool ok = c.good && !discard;
     if (ok && eig_defer_fail_ > 0 && ++eig_defer_count_ % eig_defer_fail_ == 0) ok = false;  // (tests)
     if (eig_debug_) {
-      const int *hs = (const int *)(hc + 16 + 64);
+      const int *hs = (const int *)(hc + kEigOffStatus);
       fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
                       "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
                       "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
@@ -1582,7 +1643,7 @@ class HipOps : public Ops {
   void resolve_lazy(EigState &es) {
     if (!es.lazy_pending) return;
     es.lazy_pending = false;
-    double evn[64];
+    double evn[kEigEvMax];
     // (the Jacobi wrote them into pinned host memory itself: waiting for ITS event is all it takes —
     // a copy would queue behind the other slots' Jacobis on the second stream, or drain the main one)
     HIP_CHECK(hipEventSynchronize(es.ev_done));
@@ -1695,7 +1756,7 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
                          sizeof(double) * ((size_t)cols * cols + 17 + 128), st2_, B, GB, J, cols, es.Hd, rows_per,
                          (const double *)nullptr, (const double *)nullptr, -1, (double *)nullptr, Uout2,
-                         es.chkd, es.chkd + 16 + 64 + 4 + 64, host_chk);
+                         es.chkd, es.chkd + kEigOffResp, host_chk);
       HIP_CHECK(hipEventRecord(es.ev_chk, st2_));
       const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
       hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
@@ -1704,7 +1765,7 @@ class HipOps : public Ops {
       return;
     }
     hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H, Hd2);
-    double *resp = chk + 16 + 64 + 4 + 64;
+    double *resp = chk + kEigOffResp;
     if (lazy) {
       // the basis itself goes out, checked as a subspace; the Jacobi of H moves to the second stream
       EigState &es = *lazy;
@@ -1725,6 +1786,34 @@ class HipOps : public Ops {
     hipLaunchKernelGGL(k_rr_apply, dim3(nblk), dim3(nthr_rr), top_eig_small_lds(cols) + sizeof(int) * 64, st_, B,
                        GB, J, cols, rank, H, rows_per, pe2, ptr_, np, Uout, Uout2, evW, chk, resp);
   }
+  // The tail of a projector step by plain launches, for any number of columns up to kEigEvMax
+  // (PPALS_EIG_FUSED=0, block deflation, and every step of a core rank above 48: rank + 16 columns
+  // no longer fit the one-workgroup kernels of the fused tail): Z = (Omega + X Omega) / 2 | the
+  // deflated directions projected out and put in front | orthonormal basis (Cholesky QR, block
+  // Gram-Schmidt above 64 columns) | Rayleigh-Ritz | residual of the leading `rank` pairs -> chk[4].
+  void plain_tail(const double *G, const double *X, int64_t J, int cols, int rank, const double *Omega,
+                  const double *QD, int m, double *Ot, double *Z, double *Z2, double *GZ, double *Ut, double *GU,
+                  double *C, double *H, double *Yr, double *Uout, double *evW, double *chk, int *status,
+                  int npass) {
+    const int Ji = (int)J;
+    transpose2d(Omega, F64, J, cols, Ot);  // Omega^T (cols x J): coalesced B operand
+    gemm_nt(X, J, Ot, cols, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
+    if (m > 0) {
+      double *Zr = Z + (size_t)J * m;
+      const int nz = cols - m;
+      for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL(k_tn_rect, dim3((m * nz + 15) / 16), dim3(1024), 0, st_, QD, m, Zr, nz, J, H);
+        hipLaunchKernelGGL(k_sub_mult, dim3(grid_for((int64_t)J * nz, 256)), dim3(256), 0, st_, Zr, J, nz, QD,
+                           m, H);
+      }
+      HIP_CHECK(hipMemcpyAsync(Z, QD, sizeof(double) * J * m, hipMemcpyDeviceToDevice, st_));
+    }
+    // (P Omega is within a HOOI sweep's change of orthonormal: one pass, verified by status;
+    // the unit vectors of the wide tail are not: two)
+    double *B = chol_qr2(Z, Z2, J, cols, C, status, npass);
+    rayleigh_ritz(G, B, J, cols, Ut, GZ, H, Yr, Uout, evW, GU);
+    hipLaunchKernelGGL(k_eig_residual, dim3(1), dim3(1024), 0, st_, GU, Uout, evW, J, rank, chk + 4);
+  }
   // One projector step from the state of the slot; false: not accepted (the caller falls back).
   // strict: the state is a rough estimate (cold start) — accept only residuals at the rounding
   // floor eps * lambda_1, whatever the estimated gap says.
@@ -1740,18 +1829,18 @@ class HipOps : public Ops {
     constexpr int kWide = 16;
     const size_t nJW = (size_t)J * (rank + kWide);
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
-                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 512));
+                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * kEE + 512));
     double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
     double *Ot = Y + nJJ, *Z = Ot + nJW, *Z2 = Z + nJW, *GZ = Z2 + nJW, *Ut = GZ + nJW,
            *GU = Ut + nJW, *QD = GU + nJW, *QD2 = QD + nJW, *Om = QD2 + nJW, *Uw = Om + nJW;
     const size_t nJR_end = 10 * nJW;  // (columns of the workspace behind Y)
     // the tail of the workspace is what the one read-back fetches in a single copy:
     //   chk[16] (0,1: sign check, 4: residual, 8: ||.||_F^2) | evW[64] | status[8 ints] | lamD[64]
-    double *C = Ot + nJR_end, *H = C + 64 * 64, *Yr = H + 64 * 64, *chk = Yr + 64 * 64,
+    double *C = Ot + nJR_end, *H = C + kEE, *Yr = H + kEE, *chk = Yr + kEE,
            *evW = chk + 16;
-    int *status = (int *)(evW + 64);
-    double *lamD = evW + 64 + 4;
-    constexpr size_t kReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
+    int *status = (int *)(chk + kEigOffStatus);
+    double *lamD = chk + kEigOffLamD;
+    constexpr size_t kReadback = kEigReadback;
     double sigma = 0.5 * (es.lamR + es.lamR1);
     if (eig_sigma_scale_ > 0) sigma = eig_sigma_scale_ * es.lamR1;  // tests: a shift that is too low
     // ---- dominant eigenpairs (a relative gap >= 20 above the rest of the wanted ones): refined
@@ -1862,7 +1951,7 @@ class HipOps : public Ops {
     if (strict) ell0 = std::min(ell0, 2e-5);
     double ell = std::max(ell0, eig_sigma_scale_ > 0 ? 1e-4 : 1e-14);
     int iters = 0;
-    const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
+    const unsigned ntri = sym_tiles(Ji);
     // fused tail: the check sums ride on the LAST step's two products (per-tile partial sums of
     // ||X_prev^2 - I||_F^2 and of trace(X_new), added up by the tail's last kernel)
     const bool fused_tail = eig_fused_ && m <= 1 && rank + kWide <= 64;
@@ -1870,10 +1959,8 @@ class HipOps : public Ops {
     double *ptr_ = pe2 + ntri;
     auto ns_step = [&](double mu, bool last = false) {
       // Y = X^2, X <- X (a I + b X^2): symmetric products, stored symmetric bit for bit
-      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
-                         (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
-      hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, Y, J, X, J, Xn, J, Ji, Ji,
-                         -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
+      sym_product(X, J, X, J, nullptr, 0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
+      sym_product(X, J, Y, J, X, J, Xn, J, Ji, Ji, -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
       std::swap(X, Xn);
       iters++;
     };
@@ -1887,8 +1974,7 @@ class HipOps : public Ops {
     for (int attempt = 0;; attempt++) {
       // ---- check of the sign iteration: ||X^2 - I||_F^2 and trace(X) (-> chk[0], chk[1])
       if (!fused_tail) {
-        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
-                           (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0);
+        sym_product(X, J, X, J, nullptr, 0, Y, J, Ji, Ji, 1.0, 0.0);
         const int gc = 256;
         double *pc = ptr_ + ntri;
         hipLaunchKernelGGL(k_sign_check, dim3(gc), dim3(256), 0, st_, Y, X, J, pc);
@@ -1928,30 +2014,15 @@ class HipOps : public Ops {
           HIP_CHECK(hipGetLastError());
           {  // the residual's per-workgroup shares are added up here
             double *hcw = (double *)eig_host_;
-            const double *rp = hcw + 16 + 64 + 4 + 64;
+            const double *rp = hcw + kEigOffResp;
             double r2 = 0;
             for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
             hcw[4] = r2;
           }
           return;
         }
-        transpose2d(Omega, F64, J, cols, Ot);  // Omega^T (cols x J): coalesced B operand
-        gemm_nt(X, J, Ot, cols, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
-        if (m > 0) {
-          double *Zr = Z + (size_t)J * m;
-          const int nz = cols - m;
-          for (int pass = 0; pass < 2; pass++) {
-            hipLaunchKernelGGL(k_tn_rect, dim3((m * nz + 15) / 16), dim3(1024), 0, st_, QD, m, Zr, nz, J, H);
-            hipLaunchKernelGGL(k_sub_mult, dim3(grid_for((int64_t)J * nz, 256)), dim3(256), 0, st_, Zr, J,
-                               nz, QD, m, H);
-          }
-          HIP_CHECK(hipMemcpyAsync(Z, QD, sizeof(double) * J * m, hipMemcpyDeviceToDevice, st_));
-        }
-        // (P Omega is within a HOOI sweep's change of orthonormal: one pass, verified by status;
-        // the unit vectors of the wide tail are not: two)
-        double *B = chol_qr2(Z, Z2, J, cols, C, status, npass);
-        rayleigh_ritz(G, B, J, cols, Ut, GZ, H, Yr, Uout, evW, GU);
-        hipLaunchKernelGGL(k_eig_residual, dim3(1), dim3(1024), 0, st_, GU, Uout, evW, J, rank, chk + 4);
+        plain_tail(G, X, J, cols, rank, Omega, QD, m, Ot, Z, Z2, GZ, Ut, GU, C, H, Yr, Uout, evW, chk, status,
+                   npass);
         if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
         HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
         HIP_CHECK(hipStreamSynchronize(st_));
@@ -1970,7 +2041,7 @@ class HipOps : public Ops {
         return true;
       }
       const double *hc = (const double *)eig_host_, *evn = hc + 16;
-      const int *hs = (const int *)(evn + 64);
+      const int *hs = (const int *)(hc + kEigOffStatus);
       const StepCheck sc = check_step(hc, J, rank, sigma, rho, strict, fused_tail, fused_scale, lazy_used);
       const double cnt = sc.cnt, res = sc.res, rho_now = sc.rho_now, gap_now = sc.gap_now, res_tol = sc.res_tol;
       const bool converged = sc.converged, good = sc.good;
@@ -2020,7 +2091,7 @@ class HipOps : public Ops {
       }
       const int cwide = (int)std::lround(cnt);
       if (converged && std::fabs(cnt - cwide) < 1e-6 && cwide > rank && cwide <= rank + kWide &&
-          cwide <= 64 && cwide < Ji && hs[2] != 1 && hs[3] == 0 && std::isfinite(rho_now)) {
+          cwide <= kEigEvMax && cwide < Ji && hs[2] != 1 && hs[3] == 0 && std::isfinite(rho_now)) {
         // The shift fell a few eigenvalues too low: P projects onto an invariant subspace of
         // cwide > rank dimensions — still exact. Rayleigh-Ritz on a basis of THAT many columns
         // (the previous basis plus P applied to a few unit vectors) yields its eigenpairs one by
@@ -2071,21 +2142,21 @@ class HipOps : public Ops {
   // (a flat spectrum) or the block lost rank — the caller goes to the full solver.
   bool cold_ritz_state(EigState &es, double *G, int64_t J, int rank, int slot) {
     cold_ok_ = false;
-    const int b = std::min(64, rank + 16);
+    const int b = std::min(kEigEvMax, rank + 16);
     if (b >= J || rank + 4 >= b) return false;
     const int Ji = (int)J;
     const size_t nJB = (size_t)J * b;
-    double *w = (double *)ensure(ws_cold_, ws_cold_sz_, sizeof(double) * (5 * nJB + 3 * 64 * 64 + 128));
+    double *w = (double *)ensure(ws_cold_, ws_cold_sz_, sizeof(double) * (5 * nJB + 3 * kEE + kEigEvMax + 64));
     double *Z = w, *Z2 = Z + nJB, *Zt = Z2 + nJB, *GB = Zt + nJB, *Uo = GB + nJB;
-    double *C = Uo + nJB, *H = C + 64 * 64, *Yr = H + 64 * 64, *ev = Yr + 64 * 64;
-    int *status = (int *)(ev + 64);
+    double *C = Uo + nJB, *H = C + kEE, *Yr = H + kEE, *ev = Yr + kEE;
+    int *status = (int *)(ev + kEigEvMax);
     HIP_CHECK(hipMemsetAsync(status, 0, 4 * sizeof(int), st_));
     hipLaunchKernelGGL(k_fill_hash, dim3(grid_for((int64_t)nJB, 256)), dim3(256), 0, st_, Z, (int64_t)nJB,
                        (uint64_t)(0x5eed + slot));
     double *cur = Z, *oth = Z2;
     for (int it = 0; it < 4; it++) {
       gemm_nn(G, J, cur, J, nullptr, 0, oth, J, Ji, b, Ji, 1.0, 0.0);  // G * block
-      if (eig_fused_) {
+      if (eig_fused_ && b <= 64) {
         // Cholesky QR twice: Gram (one wave per entry) | M = R^-1 by one workgroup | thin product
         double *src = oth, *dst = cur;
         for (int pass = 0; pass < 2; pass++) {
@@ -2104,7 +2175,7 @@ class HipOps : public Ops {
       std::swap(cur, oth);
     }
     rayleigh_ritz(G, cur, J, b, Zt, GB, H, Yr, Uo, ev, nullptr);
-    double th[64];
+    double th[kEigEvMax];
     int hs[4];
     HIP_CHECK(hipMemcpyAsync(th, ev, sizeof(double) * b, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipMemcpyAsync(hs, status, sizeof(int) * 4, hipMemcpyDeviceToHost, st_));
@@ -2157,23 +2228,23 @@ class HipOps : public Ops {
     const int Ji = (int)J, b = cold_b_;
     const size_t nJJ = (size_t)J * J, nJR = (size_t)J * rank, nJW = (size_t)J * (rank + kWide);
     if (rank + kWide > b || rank + kWide >= Ji) return false;
-    if (rank + kWide > 64) return false;
+    const bool big = rank + kWide > 64;  // (the counting is the same; the tail is made of plain launches)
     const double *th = cold_th_;
     int m = 0;
     for (int d = 1; d < rank; d++)
       if (th[d] > 0 && th[d - 1] / th[d] >= 20.0) m = d;
     if (m > 1) return false;
-    const unsigned ntri = (unsigned)(((Ji + 15) / 16) * (((Ji + 15) / 16) + 1) / 2);
+    const unsigned ntri = sym_tiles(Ji);
     double *w = (double *)ensure(ws_eig_, ws_eig_sz_,
-                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * 64 * 64 + 512));
+                                 sizeof(double) * (3 * nJJ + 10 * nJW + 4 * kEE + 512));
     double *X = w, *Xn = X + nJJ, *Y = Xn + nJJ;
     double *Z = Y + nJJ, *Z2 = Z + nJW, *GZ = Z2 + nJW, *QD = GZ + nJW, *y0 = QD + nJW, *y1 = y0 + nJW,
-           *Uw = y1 + nJW;
-    double *Cw = Y + nJJ + 10 * nJW, *Hw = Cw + 64 * 64;
-    double *chk = Y + nJJ + 10 * nJW + 3 * 64 * 64, *evW = chk + 16;
-    int *status = (int *)(evW + 64);
-    double *lamD = evW + 64 + 4;
-    constexpr size_t kReadback = sizeof(double) * (16 + 64 + 4 + 64 + kTailBlocks);
+           *Uw = y1 + nJW, *Ot = Uw + nJW, *Ut = Ot + nJW, *GU = Ut + nJW;
+    double *Cw = Y + nJJ + 10 * nJW, *Hw = Cw + kEE;
+    double *chk = Y + nJJ + 10 * nJW + 3 * kEE, *evW = chk + 16;
+    int *status = (int *)(chk + kEigOffStatus);
+    double *lamD = chk + kEigOffLamD;
+    constexpr size_t kReadback = kEigReadback;
     double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
     double *ptr_ = pe2 + ntri;
     if (!eig_host_) HIP_CHECK(hipHostMalloc(&eig_host_, kReadback, hipHostMallocDefault));
@@ -2206,10 +2277,8 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_ns_prepare, dim3(gdef), dim3(256), 0, st_, G, J, pow_y, pow_p, pow_n, m,
                          2.0 * sigma, sigma, 1.0 / rho, X, QD, lamD);
       auto ns_step = [&](double mu, bool last) {
-        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, X, J, nullptr,
-                           (int64_t)0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
-        hipLaunchKernelGGL(k_dgemm_nt_sym<8>, dim3(ntri), dim3(512), 0, st_, X, J, Y, J, X, J, Xn, J, Ji,
-                           Ji, -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
+        sym_product(X, J, X, J, nullptr, 0, Y, J, Ji, Ji, 1.0, 0.0, last ? 1 : 0, pe2);
+        sym_product(X, J, Y, J, X, J, Xn, J, Ji, Ji, -0.5 * mu * mu * mu, 1.5 * mu, last ? 2 : 0, ptr_);
         std::swap(X, Xn);
         products += 2;
       };
@@ -2298,20 +2367,25 @@ class HipOps : public Ops {
     // ---- the tail on `cols` columns: P applied to the Ritz block (a generic basis), two Cholesky-QR
     // passes, Rayleigh-Ritz; the deflated eigenvector takes the place of the first column
     HIP_CHECK(hipMemsetAsync(status, 0, 8 * sizeof(int), st_));
-    fused_tail_launches(G, X, J, cols, rank, Om, QD, m, Z, Z2, GZ, Cw, Hw, Uw, evW, chk, status, pe2, ptr_,
-                        (int)ntri, 2);
+    if (big) {
+      HIP_CHECK(hipMemsetAsync(chk + kEigOffResp, 0, sizeof(double) * kTailBlocks, st_));
+      plain_tail(G, X, J, cols, rank, Om, QD, m, Ot, Z, Z2, GZ, Ut, GU, Cw, Hw, Hw + kEE, Uw, evW, chk, status, 2);
+    } else {
+      fused_tail_launches(G, X, J, cols, rank, Om, QD, m, Z, Z2, GZ, Cw, Hw, Uw, evW, chk, status, pe2, ptr_,
+                          (int)ntri, 2);
+    }
     HIP_CHECK(hipMemcpyAsync(eig_host_, chk, kReadback, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipGetLastError());
-    {
+    if (!big) {  // (the fused tail leaves per-workgroup shares of the residual; the plain one the sum)
       double *hcw = (double *)eig_host_;
-      const double *rp = hcw + 16 + 64 + 4 + 64;
+      const double *rp = hcw + kEigOffResp;
       double r2 = 0;
       for (int b2 = 0; b2 < kTailBlocks; b2++) r2 += rp[b2];
       hcw[4] = r2;
     }
     const double *hc = (const double *)eig_host_, *evn = hc + 16;
-    const int *hs = (const int *)(evn + 64);
+    const int *hs = (const int *)(hc + kEigOffStatus);
     const double res = std::sqrt(hc[4]);
     const double res_tol = 1e-13 * evn[0] * std::sqrt((double)rank);
     const bool good = hs[0] != 1 && hs[1] == 0 && res <= res_tol && std::isfinite(res) &&
@@ -2345,7 +2419,7 @@ class HipOps : public Ops {
   bool cold_ok_ = false;
   int cold_b_ = 0;
   const double *cold_Uo_ = nullptr;
-  double cold_th_[64] = {0};
+  double cold_th_[kEigEvMax] = {0};
   double frob_shifted(const double *G, int64_t J, double sigma) {
     const int g = grid_for(J * J, 256, 1024);
     double *part = (double *)ensure(ws_part_, ws_part_sz_, sizeof(double) * (g + 1));
@@ -2479,6 +2553,9 @@ class HipOps : public Ops {
   bool norm_armed_ = false;
   int update_fuse_norm_ = 1;  // PPALS_UPDATE_FUSE_NORM=0: Normalize always a launch of its own
   bool eig_frob_once_ = false;
+  void *ws_jac_ = nullptr;  // rotation product of the one-sided Jacobi (r x r)
+  size_t ws_jac_sz_ = 0;
+  int sym_lds_min_ = 768;   // PPALS_SYM_LDS_MIN: rows from which the symmetric product is LDS-tiled
   int eig_defer_ok_ = 1;    // PPALS_EIG_DEFER=0: every projector step waits for its own checks
   int eig_defer_fail_ = 0;  // PPALS_EIG_DEFER_FAIL=n (tests): every n-th deferred check is reported as failed
   int eig_defer_count_ = 0;

@@ -21,6 +21,13 @@
 
 namespace ppals {
 
+// Layout of the block a projector step leaves for its one read-back (device workspace, the slot's
+// pinned copy): check words | eigenvalues (rank + wide columns) | status | deflated eigenvalues |
+// per-workgroup residual shares.
+constexpr int kEigEvMax = 128;  // eigenvalues a step can return: core rank + 16 <= 128
+constexpr int kEigOffEv = 16, kEigOffStatus = kEigOffEv + kEigEvMax, kEigOffLamD = kEigOffStatus + 4,
+              kEigOffResp = kEigOffLamD + 64, kEigChkDoubles = kEigOffResp + 64;
+
 // C[M x N] = alpha * A[M x K] * B[K x N] + beta * D[M x N]   (fp64, column-major, ld = rows)
 // B is handed over as Bt = B^T (N x K, column-major, ldb): element B[k][j] = Bt[j + ldb*k], so the
 // 16 lanes of an MFMA column group read 128 contiguous bytes for both operands. For the symmetric
@@ -169,6 +176,133 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
   if (chk_mode) {  // (wave 0 only is left: a wave-level sum in a fixed order)
     chk = wave_sum(chk);
     if (lane == 0) chk_part[blockIdx.x] = chk;
+  }
+}
+
+// The symmetric product for LARGE matrices (J of many hundreds: the Tucker modes of the reference's
+// own data sets, 1344 rows at rank 100, test_ALS.cxx:366-379), where a product is no longer a
+// latency problem but 2 J^3 flops: TS x TS output tile per workgroup (TS = 64: four waves of
+// 32 x 32 = 2 x 2 MFMA tiles each, one LDS read per MFMA; TS = 32: four waves of 16 x 16), both
+// operand panels staged through LDS 16 reduction indices at a time, the next chunk's global loads
+// (16-byte, two per thread and panel) in flight while the current one is multiplied. Row stride of
+// the panels = TS + 16 doubles: the four k-groups of an operand read fall into different bank
+// halves. Same contract as k_dgemm_nt_sym: upper-triangle tiles only, every value stored at (i, j)
+// and (j, i), the optional check sums per workgroup. 231 workgroups at J = 1344.
+template <int TS>
+__global__ __launch_bounds__(256) void k_dgemm_nt_sym_lds(const double *__restrict__ A, int64_t lda,
+                                                          const double *__restrict__ Bt, int64_t ldb,
+                                                          const double *__restrict__ D, int64_t ldd,
+                                                          double *__restrict__ C, int64_t ldc, int M,
+                                                          int K, double alpha, double beta,
+                                                          int chk_mode = 0,
+                                                          double *__restrict__ chk_part = nullptr) {
+  constexpr int KC = 16, LD = TS + 16, NT = TS / 32;  // NT x NT MFMA tiles per wave
+  constexpr int PT = TS * KC / 256 / 2;               // double2 loads per thread and panel (2 or 1)
+  __shared__ double As[KC][LD];
+  __shared__ double Bs[KC][LD];
+  __shared__ double red[17];
+  const int nt = (M + TS - 1) / TS;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ti++;
+  }
+  const int tj = ti + rem;
+  const bool diag = (ti == tj) && (A == Bt) && (lda == ldb);
+  const int p0 = ti * TS, q0 = tj * TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int wi = (wave & 1) * (TS / 2), wj = (wave >> 1) * (TS / 2);
+  f64x4 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // a thread's slice of a TS x 16 panel: rows pr, pr + 1 of columns cc + (16 / PT) * h
+  constexpr int RT = TS / 2;  // threads along the rows
+  const int pr = (tid % RT) * 2, cc = tid / RT;
+  const bool vec_ok = ((lda | ldb) & 1) == 0 && (((uintptr_t)A | (uintptr_t)Bt) & 15) == 0;
+  double ra[2 * PT], rb[2 * PT];
+  auto fetch = [&](int k0, int r0, const double *__restrict__ X, int64_t ldx, double *r) {
+#pragma unroll
+    for (int h = 0; h < PT; h++) {
+      const int k = k0 + cc + (KC / PT) * h, row = r0 + pr;
+      double v0 = 0.0, v1 = 0.0;
+      if (k < K) {
+        if (vec_ok && row + 1 < M) {
+          const double2 v = *reinterpret_cast<const double2 *>(X + row + ldx * (int64_t)k);
+          v0 = v.x;
+          v1 = v.y;
+        } else {
+          if (row < M) v0 = X[row + ldx * (int64_t)k];
+          if (row + 1 < M) v1 = X[row + 1 + ldx * (int64_t)k];
+        }
+      }
+      r[2 * h] = v0;
+      r[2 * h + 1] = v1;
+    }
+  };
+  auto stash = [&](double (*S)[LD], const double *r) {
+#pragma unroll
+    for (int h = 0; h < PT; h++) {
+      S[cc + (KC / PT) * h][pr] = r[2 * h];
+      S[cc + (KC / PT) * h][pr + 1] = r[2 * h + 1];
+    }
+  };
+  fetch(0, p0, A, lda, ra);
+  if (!diag) fetch(0, q0, Bt, ldb, rb);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();  // the previous chunk's fragments have been read
+    stash(As, ra);
+    if (!diag) stash(Bs, rb);
+    __syncthreads();
+    if (k0 + KC < K) {  // next chunk on its way while this one is multiplied
+      fetch(k0 + KC, p0, A, lda, ra);
+      if (!diag) fetch(k0 + KC, q0, Bt, ldb, rb);
+    }
+    double (*Bp)[LD] = diag ? As : Bs;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ks++) {
+      double av[NT], bv[NT];
+#pragma unroll
+      for (int a = 0; a < NT; a++) av[a] = As[4 * ks + g][wi + 16 * a + l16];
+#pragma unroll
+      for (int b = 0; b < NT; b++) bv[b] = Bp[4 * ks + g][wj + 16 * b + l16];
+#pragma unroll
+      for (int a = 0; a < NT; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  double chk = 0.0;
+#pragma unroll
+  for (int a = 0; a < NT; a++)
+#pragma unroll
+    for (int b = 0; b < NT; b++) {
+      const int j = q0 + wj + 16 * b + l16;  // D map: lane holds column l16, rows g + 4 r
+      if (j < M) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = p0 + wi + 16 * a + g + 4 * r;
+          if (i < M && i <= j) {  // (tiles on the diagonal store their upper half only, mirrored)
+            double v = alpha * acc[a][b][r];
+            if (D) v += beta * D[i + ldd * (int64_t)j];
+            C[i + ldc * (int64_t)j] = v;
+            if (i != j) C[j + ldc * (int64_t)i] = v;
+            if (chk_mode == 1) {
+              const double d = v - (i == j ? 1.0 : 0.0);
+              chk += (i == j ? 1.0 : 2.0) * d * d;
+            } else if (chk_mode == 2 && i == j) {
+              chk += v;
+            }
+          }
+        }
+      }
+    }
+  if (chk_mode) {
+    chk = block_sum(chk, red);
+    if (tid == 0) chk_part[blockIdx.x] = chk;
   }
 }
 
@@ -595,7 +729,7 @@ __global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double 
 // chk_out != nullptr (deferred acceptance: the checks are finished on the second stream, which must
 // not read the shared workspace): ONE extra workgroup — the last — adds up the sign iteration's
 // per-tile check sums (np each) into chk_out[0], chk_out[1] and copies the step's norm word [8] and
-// status words [80..84) from the workspace block chk_src into the slot's own block.
+// status words from the workspace block chk_src into the slot's own block.
 __global__ void k_tn_small(const double *__restrict__ A, const double *__restrict__ B, int64_t rows,
                            int r, double *__restrict__ C, double *__restrict__ C2 = nullptr,
                            const double *__restrict__ part_e2 = nullptr,
@@ -616,7 +750,7 @@ __global__ void k_tn_small(const double *__restrict__ A, const double *__restric
       chk_out[1] = tr;
       chk_out[8] = chk_src[8];
     }
-    if (threadIdx.x < 4) chk_out[16 + 64 + threadIdx.x] = chk_src[16 + 64 + threadIdx.x];
+    if (threadIdx.x < 4) chk_out[kEigOffStatus + threadIdx.x] = chk_src[kEigOffStatus + threadIdx.x];
     return;
   }
   const int nblocks = chk_out ? gridDim.x - 1 : gridDim.x;
@@ -1029,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
       resp[b] = 0.0;
       if (hresp) hresp[b] = 0.0;
     }
-    if (host && tid < 4) host[16 + 64 + tid] = chk[16 + 64 + tid];  // status words (8 ints)
+    if (host && tid < 4) host[kEigOffStatus + tid] = chk[kEigOffStatus + tid];  // status words (8 ints)
     double e2 = 0, tr = 0;
     for (int i = tid; i < np; i += nthr) {
       e2 += part_e2[i];
@@ -1105,6 +1239,124 @@ __global__ __launch_bounds__(1024) void k_rr_small(const double *__restrict__ H,
   for (int e = tid; e < cols * cols; e += nthr) {
     const int p = e % cols, k = e / cols;
     Y[p + cols * k] = Q[p * ldA + ord[k]];
+  }
+}
+
+// Eigen-decomposition of a symmetric positive semi-definite H of 64 < n <= kJacobiBigMax rows (the
+// Rayleigh-Ritz matrix of a Tucker mode whose core rank exceeds 64: the reference's own data sets
+// run ranks 70 and 100, test_ALS.cxx:366-379) by ONE workgroup: one-sided (Hestenes) Jacobi. The
+// two-sided block Jacobi of the small modes keeps A and Q twice in LDS (4 n^2 doubles: 64 rows at
+// most); here only W = H V lives in LDS (n (n + 1) doubles, 129 KB at n = 128) and V — the product
+// of the rotations, L2-resident — in global memory: a round rotates n / 2 disjoint column pairs of
+// W (and V) so that the columns of W become orthogonal; at convergence W = V Lambda: the columns
+// of V are the eigenvectors, the column norms of W the eigenvalues. Sixteen threads per pair (their
+// three inner products meet by lane shuffles inside the 16-lane group), one barrier per round,
+// round-robin pairing (circle method), <= 40 sweeps; a sweep without a rotation ends it.
+//   Y (n x n) = eigenvectors, column k for the k-th largest eigenvalue; ev / ev_host: eigenvalues.
+// dynamic LDS: n (n + 1) doubles + 256 doubles + 256 ints.
+constexpr int kJacobiBigMax = 128;
+__global__ __launch_bounds__(1024) void k_jacobi_onesided(const double *__restrict__ H, int n,
+                                                          double *__restrict__ V, double *__restrict__ Y,
+                                                          double *__restrict__ ev,
+                                                          double *__restrict__ ev_host) {
+  extern __shared__ double lds[];
+  const int ld = n + 1;
+  double *W = lds;
+  double *nrm = W + (size_t)n * ld;  // 128 column norms
+  int *flag = (int *)(nrm + 256);    // [0]: rotations in this sweep
+  int *ord = flag + 8;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int e = tid; e < n * n; e += nthr) {
+    const int i = e % n, j = e / n;
+    W[j * ld + i] = 0.5 * (H[i + n * j] + H[j + n * i]);  // column j
+    V[i + n * j] = i == j ? 1.0 : 0.0;
+  }
+  if (tid == 0) flag[0] = 0;
+  __syncthreads();
+  const int ne = (n + 1) & ~1;  // players of the tournament (an odd n plays with a bye)
+  const int grp = tid >> 4, gl = tid & 15;  // 64 groups of 16 threads
+  for (int sweep = 0; sweep < 40; sweep++) {
+    for (int r = 0; r < ne - 1; r++) {
+      // pair of this group in round r (circle method): player ne - 1 stays, the others rotate
+      int p = -1, q = -1;
+      if (grp < ne / 2) {
+        if (grp == 0) {
+          p = ne - 1;
+          q = r;
+        } else {
+          p = (r + grp) % (ne - 1);
+          q = (r - grp + (ne - 1)) % (ne - 1);
+        }
+        if (p > q) {
+          const int t = p;
+          p = q;
+          q = t;
+        }
+        if (q >= n) p = -1;  // the bye
+      }
+      if (p >= 0) {
+        double *wp = W + p * ld, *wq = W + q * ld;
+        double a = 0, b = 0, c = 0;
+        for (int i = gl; i < n; i += 16) {
+          const double x = wp[i], y = wq[i];
+          a += x * x;
+          b += y * y;
+          c += x * y;
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+          a += __shfl_xor(a, o, 16);
+          b += __shfl_xor(b, o, 16);
+          c += __shfl_xor(c, o, 16);
+        }
+        if (fabs(c) > 1e-15 * sqrt(a * b) && a * b > 0.0) {
+          const double zeta = (b - a) / (2.0 * c);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+          for (int i = gl; i < n; i += 16) {
+            const double x = wp[i], y = wq[i];
+            wp[i] = cs * x - sn * y;
+            wq[i] = sn * x + cs * y;
+            const double vx = V[i + n * p], vy = V[i + n * q];
+            V[i + n * p] = cs * vx - sn * vy;
+            V[i + n * q] = sn * vx + cs * vy;
+          }
+          if (gl == 0) flag[0] = 1;  // (benign race: everybody writes 1)
+        }
+      }
+      __syncthreads();
+    }
+    const int rotated = flag[0];
+    __syncthreads();
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    if (!rotated) break;
+  }
+  // eigenvalues = column norms of W (H is positive semi-definite), ranked descending
+  for (int k = tid >> 4; k < n; k += nthr >> 4) {
+    double a = 0;
+    for (int i = gl; i < n; i += 16) a += W[k * ld + i] * W[k * ld + i];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) a += __shfl_xor(a, o, 16);
+    if (gl == 0) nrm[k] = sqrt(a);
+  }
+  __syncthreads();
+  if (tid < n) {
+    const double wk = nrm[tid];
+    int pos = 0;
+    for (int j = 0; j < n; j++) {
+      const double wj = nrm[j];
+      if (wj > wk || (wj == wk && j < tid)) pos++;
+    }
+    ord[pos] = tid;
+    ev[pos] = wk;
+    if (ev_host) ev_host[pos] = wk;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int e = tid; e < n * n; e += nthr) {
+    const int i = e % n, k = e / n;
+    Y[i + n * k] = V[i + n * ord[k]];
   }
 }
 

@@ -1800,6 +1800,11 @@ __global__ void k_take_top(const double *__restrict__ Z, int64_t J, int rank,
   }
 }
 
+// out[i] = in[n - 1 - i]
+__global__ void k_reverse_copy(const double *__restrict__ in, int n, double *__restrict__ out) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = in[n - 1 - i];
+}
+
 // one wave per column: sign of the dot product with the reference column, then rescale
 __global__ void k_sign_align(double *__restrict__ W, const double *__restrict__ Wref, int64_t rows,
                              int r) {

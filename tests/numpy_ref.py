@@ -149,3 +149,43 @@ def als_cp_pp(V, W, G, tol, tol_init, maxiter, lam=0.0, ratio_step=1.0, resprint
             W = _normalize(W)
             it += 1
     return it, W, G, rows
+
+
+# ---------------------------------------------------------------------------- Tucker (HOOI)
+def _ttmc(V, W, skip):
+    """TTMc (als_Tucker.cxx:76-110): V x_j W_j^T for every mode j != skip, mode positions kept"""
+    Y = V
+    for j, w in enumerate(W):
+        if j == skip:
+            continue
+        Y = np.moveaxis(np.tensordot(w.T, Y, axes=(1, j)), 0, j)
+    return Y
+
+
+def _top_eigvecs(Y, i, r):
+    """leading left singular vectors of the mode-i unfolding through its Gram (als_Tucker.cxx:399-406,
+    common.cxx:205-223), LAPACK's symmetric solver; columns sorted by descending eigenvalue"""
+    Yi = np.moveaxis(Y, i, 0).reshape(Y.shape[i], -1)
+    w, Q = np.linalg.eigh(Yi @ Yi.T)
+    return Q[:, ::-1][:, :r].copy()
+
+
+def tucker_hosvd(V, ranks):
+    """hosvd (als_Tucker.cxx:12-70)"""
+    W = [_top_eigvecs(V, i, r) for i, r in enumerate(ranks)]
+    return W, _ttmc(V, W, -1)
+
+
+def tucker_hooi(V, W, sweeps):
+    """`sweeps` sweeps of alsTucker_DT (als_Tucker.cxx:340-408): every mode in turn from the TTMc of
+    the others; returns the factors and the core of the last sweep (Y_end x W_{N-1}^T)"""
+    W = [w.copy() for w in W]
+    N = V.ndim
+    core = None
+    for _ in range(sweeps):
+        for i in range(N):
+            Y = _ttmc(V, W, i)
+            W[i] = _top_eigvecs(Y, i, W[i].shape[1])
+            if i == N - 1:
+                core = np.moveaxis(np.tensordot(W[i].T, Y, axes=(1, i)), 0, i)
+    return W, core

@@ -179,6 +179,98 @@ def _decaying_tensor(lens, inner, seed, noise):
     return np.asfortranarray(V + noise * np.linalg.norm(V) / np.linalg.norm(E) * E)
 
 
+def _slow_decay_tensor(lens, inner, decay, seed, noise):
+    """multilinear rank `inner`, singular values of mode m falling like decay[m]**k, plus relative noise"""
+    rng = np.random.default_rng(seed)
+    U = [np.linalg.qr(rng.standard_normal((s, r)))[0] for s, r in zip(lens, inner)]
+    core = rng.standard_normal(inner)
+    for m, r in enumerate(inner):
+        shape = [1] * len(inner)
+        shape[m] = r
+        core = core * (decay[m] ** np.arange(r)).reshape(shape)
+    V = core
+    for m, u in enumerate(U):
+        V = np.moveaxis(np.tensordot(u, V, axes=(1, m)), 0, m)
+    E = rng.standard_normal(lens)
+    return np.asfortranarray(V + noise * np.linalg.norm(V) / np.linalg.norm(E) * E)
+
+
+@pytest.mark.parametrize("lens,ranks,inner", [
+    ([300, 24, 20], [70, 20, 16], [110, 22, 18]),       # the coil-100 run's rank 70 (test_ALS.cxx:366-371)
+    ([1344, 40, 36], [100, 12, 10], [150, 20, 18]),   # the hyperspectral run's rank 100 on 1344 rows (:373-379)
+])
+def test_core_rank_above_64_stays_on_the_projector_route(pp, lens, ranks, inner, tmp_path, monkeypatch, capfd):
+    """Core ranks above 64 (the reference's own real-data runs use 70 and 100, test_ALS.cxx:366-379):
+    the eigen-step of such a mode — cold start by block subspace iteration, warm steps by the sign
+    iteration on the LDS-tiled symmetric product, tails by plain launches with the one-sided Jacobi
+    on rank + 16 columns — must not call the vendor eigensolver. hosvd + 5 HOOI sweeps against
+    numpy's LAPACK reading (tests/numpy_ref.py, pinned to the oracle in tests/test_oracle_cp.py):
+    projectors, ||core||; the step log must hold accepted projector steps and no full solver."""
+    import numpy_ref as NR
+    V = _slow_decay_tensor(lens, inner, [0.985, 0.8, 0.8], 21, 1e-4)
+    W0, c0 = NR.tucker_hosvd(V, ranks)
+    W_ref, core_ref = NR.tucker_hooi(V, W0, 5)
+    # (the long mode keeps its s x s Gram: the product of the other core ranks is not below its extent
+    # in the first case — as in the reference's runs — and the thin route is switched off in the second)
+    if lens[0] > np.prod(ranks[1:]):
+        monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    capfd.readouterr()
+    s.hosvd()
+    W_h, _ = s.get_factors()
+    for a, b in zip(W_h, W0):
+        assert relerr(proj(a), proj(b)) < 1e-7, relerr(proj(a), proj(b))
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.sweeps_dt(5)
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-6, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    log = [ln for ln in err.splitlines() if "[ppals eig]" in ln]
+    big = [ln for ln in log if f"rank {ranks[0]}:" in ln or "wide tail" in ln]
+    # (cold starts end in a wide tail of rank + 1 or 2 columns, warm steps are accepted as they are)
+    assert sum("-> accepted" in ln for ln in big) >= 5, "\n".join(big[-30:])
+    assert not any("full solver" in ln for ln in log), "\n".join(log)
+    s.close()
+    t.close()
+    c2.close()
+
+
+def test_thin_route_with_more_than_64_columns_needs_no_vendor_solver(pp, tmp_path, monkeypatch, capfd):
+    """A tall unfolding whose small side has 64 < c <= 128 columns (rank 70 of 90): the c x c
+    eigen-problem is solved whole by the one-workgroup one-sided Jacobi (k_jacobi_onesided), not by
+    rocSOLVER. hosvd + 3 sweeps against numpy's reading."""
+    import numpy_ref as NR
+    lens, ranks = [500, 12, 10], [70, 10, 9]
+    V = _slow_decay_tensor(lens, [100, 12, 10], [0.97, 0.9, 0.9], 5, 1e-4)
+    W0, c0 = NR.tucker_hosvd(V, ranks)
+    W_ref, core_ref = NR.tucker_hooi(V, W0, 3)
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    capfd.readouterr()
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.sweeps_dt(3)
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-6, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    assert "dsyevd" not in err, err[-2000:]
+    s.close()
+    t.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("fail_every", [0, 2, 5])
 def test_deferred_eigen_step_checks(pp, fail_every, tmp_path, monkeypatch, capfd):
     """Deferred acceptance (Ops::eig_defer / eig_verify, hip_ops.hip; TuckerEngine::settle_mode /

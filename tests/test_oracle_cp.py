@@ -182,3 +182,22 @@ def test_sort_indexes_matches_reference(golden_dir):
     assert len(cases) >= 40
     for c in cases:
         assert O.sort_indexes(c["v"]) == c["order"], c
+
+
+def test_numpy_tucker_reading_matches_the_oracle():
+    """tests/numpy_ref.py's HOOI (einsum + LAPACK eigh) against the C++ oracle (Jacobi SVD) on a small
+    problem: the large-mode GPU tests (rank 100 on 1344 rows) use the numpy reading, which the
+    oracle's O(J^3 sweeps) solver cannot serve in test time"""
+    import numpy_ref as NR
+    lens, ranks = [14, 11, 9], [4, 3, 2]
+    V = O.fill_uniform(int(np.prod(lens)), 7, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W0, c0 = O.hosvd(V, ranks)
+    Wn, cn = NR.tucker_hosvd(V, ranks)
+    for a, b in zip(W0, Wn):
+        assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9
+    assert abs(np.linalg.norm(c0) - np.linalg.norm(cn)) < 1e-10 * np.linalg.norm(c0)
+    _, _, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=4, resprint=10 ** 9)
+    W_np, core_np = NR.tucker_hooi(V, W0, 5)
+    for a, b in zip(W_ref, W_np):
+        assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9
+    assert abs(np.linalg.norm(core_ref) - np.linalg.norm(core_np)) < 1e-10 * np.linalg.norm(core_ref)
