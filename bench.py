@@ -27,6 +27,7 @@ WORKLOADS = {
     "cp4_s200_r10": ([200, 200, 200, 200], 10),
     "cp4_s400_r20": ([400, 400, 400, 400], 20),
     "cp4_s64_r10": ([64, 64, 64, 64], 10),  # smoke-sized
+    "cp4_s12_r3": ([12, 12, 12, 12], 3),    # the CPU rehearsal of the N > 1 path (tests/test_bench_hostsim.py)
     # diagnostics (not BASELINE configs): which of size and rank costs cfg4 its 8 % against cfg2
     "cp4_s400_r10": ([400, 400, 400, 400], 10),
     "cp4_s200_r20": ([200, 200, 200, 200], 20),
@@ -270,16 +271,23 @@ def cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir):
     # per-sweep split by [pp_update]: the same run with a row per iteration (each row costs a
     # stream sync, so these are upper bounds of the in-flight sweep times)
     cp.set_factors(W0, G0)
+    cp.pp_build_stats(+1)            # time the operator builds of this run (a sync on both sides)
     cp.run_pp(csv=pp1_csv, tol_init=0.01, tol=1e-10 * vnorm, maxiter=300, resprint=1)
+    n_builds, build_s = cp.pp_build_stats(-1)
     r1 = _csv_rows(pp1_csv)
-    split = {"dt": [], "pp": [], "pp_init": []}
+    split = {"exact": [], "exact_plus_build": [], "pp_first_sweep": [], "pp": []}
     # A row is printed BEFORE the sweep of its iteration, so the interval to the next row is the
-    # sweep of the row's own kind. The exact phase returns without counting its last sweep
-    # (als_CP.cxx:594-605) and the PP phase prints a row on entry (als_CP.cxx:697): (k,0) -> (k,1)
-    # is that exact sweep, (k,1) -> (k+1,1) the operator build (als_CP.cxx:667-695) + one PP sweep.
+    # sweep of the row's own kind. The exact phase returns WITHOUT counting its last sweep
+    # (als_CP.cxx:594-605), and the PP phase builds its operators BEFORE it prints its first row
+    # (als_CP.cxx:667-697; engine.cpp pp_sub): the interval (last exact row) -> (first PP row) is
+    # that exact sweep PLUS the operator build; every later interval that starts at a PP row is one
+    # approximate sweep (the first of a phase listed separately).
     for k in range(1, len(r1)):
         a, b = r1[k - 1], r1[k]
-        kind = "dt" if a[4] == 0 else ("pp_init" if (k >= 2 and r1[k - 2][4] == 0) else "pp")
+        if a[4] == 0:
+            kind = "exact" if b[4] == 0 else "exact_plus_build"
+        else:
+            kind = "pp_first_sweep" if (k >= 2 and r1[k - 2][4] == 0) else "pp"
         split[kind].append(b[6] - a[6])
     with open(b_csv, "w") as f:
         f.write("[timetype],[dtime]\n")
@@ -300,9 +308,19 @@ def cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir):
         "pp_rows_flagged_pp_update": sum(1 for r in pp if r[4] == 1), "rows": len(pp),
         "diffV_floor": floor, "dt_first_at_floor": first_at(dt), "pp_first_at_floor": first_at(pp),
         "final_gradnorm": {"dt": dt[-1][2], "pp": pp[-1][2]},
-        "sweeps_per_s_by_pp_update": {
+        "intervals_per_s_by_kind": {
             k: (len(v) / sum(v) if v and sum(v) > 0 else None) for k, v in split.items()},
-        "sweeps_counted_by_pp_update": {k: len(v) for k, v in split.items()},
+        "intervals_counted_by_kind": {k: len(v) for k, v in split.items()},
+        "interval_kinds": "row-per-iteration run (each row costs a stream sync: upper bounds). exact = one "
+                          "exact sweep; exact_plus_build = the uncounted last exact sweep of a DT phase + "
+                          "the PP operator build, which runs before the first PP row is printed; "
+                          "pp_first_sweep / pp = one approximate sweep",
+        "pp_builds": n_builds,
+        "pp_build_ms": (1e3 * build_s / n_builds) if n_builds else None,
+        "pp_build_note": "host-timed with the stream synchronised on both sides of every build "
+                         "(ppals_cp_pp_build_stats); inside a run one of the three level-1 tensors is the "
+                         "multi-sweep intermediate the exact sweep just left: 2 tensor scans + the pair / "
+                         "single operators",
         "bench_mode_ms": {"[DTtime]": 1e3 * _median(bl.get("[DTtime]", [])),
                           "[PPfirst]": 1e3 * _median(bl.get("[PPfirst]", [])),
                           "[PPsecond]": 1e3 * _median(bl.get("[PPsecond]", [])), "repetitions": reps,
@@ -371,6 +389,44 @@ def cfg5_tucker_record(ppals, ctx, tmpdir):
     return rec
 
 
+def shard_probe_record(ppals, torch, local_rank):
+    """Per-rank compute of the strong-scaled runs, measured on THIS one GPU: a [s/8, s, s, s] tensor is
+    what each of 8 ranks holds of configs[1] / configs[3] (leading-mode block). The session runs the
+    SHARDED code path — shard-aware multi-sweep schedule, packed partials, every collective issued on a
+    one-rank RCCL communicator — so its sweep time is the floor of the 8-GPU run before a byte crosses
+    xGMI (tools/shard_probe.py). A context of its own: PPALS_FORCE_COMM is read when sessions are made."""
+    old = os.environ.get("PPALS_FORCE_COMM")
+    os.environ["PPALS_FORCE_COMM"] = "1"
+    out = {"note": "one GPU, one-rank RCCL communicator, PPALS_FORCE_COMM=1: the rank-local sweep of a P = 8 "
+                   "run (no exchange partner); projected efficiency = (P=1 sweep / 8) / this"}
+    try:
+        ctx = ppals.Context(local_rank)
+        ctx.init_comm(0, 1, ppals.Context.unique_id())
+        for name, s, R, K in (("cfg2_P8", 200, 10, 24), ("cfg4_P8", 400, 20, 8)):
+            lens = [s // 8, s, s, s]
+            V = ppals.Tensor(ctx, lens, ppals.F32).fill_cp(ppals.init_factors(lens, R, 1000))
+            cp = ppals.CP(ctx, V, R)
+            cp.set_factors(ppals.init_factors(lens, R, 2000), ppals.init_factors(lens, R, 3000))
+            cp.sweeps_dt(4)
+            ctx.sync()
+            t0 = time.perf_counter()
+            cp.sweeps_dt(K)          # (a multiple of 2 sweeps: the sharded cycle is 3 scans / 2 sweeps)
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / K
+            out[name] = {"shard": lens, "rank": R, "ms_per_sweep_per_rank": 1e3 * dt, "sweeps": K,
+                         "schedule": cp.schedule, "rccl_ranks": ctx.nranks}
+            cp.close()
+            V.close()
+        ctx.close()
+    except Exception as e:  # reported, never required
+        out["error"] = str(e)
+    if old is None:
+        del os.environ["PPALS_FORCE_COMM"]
+    else:
+        os.environ["PPALS_FORCE_COMM"] = old
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -394,7 +450,17 @@ def main():
 
     import numpy as np
     import torch  # first: libppals.so then shares torch's libamdhip64 / librccl
-    import ppals
+    # PPALS_BENCH_BACKEND=hostsim (tests/test_bench_hostsim.py, CPU only): THIS script's N > 1 code path
+    # — process group, communicator id hand-over, init_comm, measure(), the reduce-scatter sub-record —
+    # over the engine's host stand-in and gloo. Test infrastructure: the line it prints says so and
+    # is never a measurement.
+    hostsim = os.environ.get("PPALS_BENCH_BACKEND") == "hostsim"
+    if hostsim:
+        import hostsim_util
+        ppals = hostsim_util.load()
+    else:
+        import ppals
+    dev = "cpu" if hostsim else "cuda"
     config_records = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_config_records
                       and args.workload == "cp4_s200_r10" and args.dtype == "f32"
                       and not args.schedule)
@@ -403,9 +469,10 @@ def main():
         # HIP runtime is up (include/ppals.h, ppals_preload_eigensolver)
         ppals.preload_eigensolver()
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if not hostsim:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
     dist = None
     # PPALS_FORCE_COMM=1 (tests): take the N > 1 route — process group, unique-id broadcast, RCCL
     # communicator, sharded engine paths — even with a single rank
@@ -414,27 +481,39 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if hostsim:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     lens, R = WORKLOADS[args.workload]
     dtype = ppals.F32 if args.dtype == "f32" else ppals.F64
-    ctx = ppals.Context(local_rank)
+    ctx = ppals.Context(0 if hostsim else local_rank)
+    comm_keepalive = None
     if use_comm:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(ppals.Context.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        ctx.init_comm(rank, world, bytes(uid.cpu().numpy().tobytes()))
+        dist.broadcast(uid, 0)   # every rank joins the communicator rank 0 named
+        if hostsim:
+            # (the stand-in's "id" is a set of callbacks into this process's gloo group: made locally)
+            local_uid, comm_keepalive, _ = hostsim_util.gloo_comm_uid(rank, world)
+            ctx.init_comm(rank, world, local_uid)
+        else:
+            ctx.init_comm(rank, world, bytes(uid.cpu().numpy().tobytes()))
 
-    nranks_seen = ctx.nranks   # read back from ppals_ctx_nranks: 1 without a communicator
+    # ppals_ctx_nranks: the communicator's own answer (RCCL: ncclCommCount, checked against the
+    # requested world size when the communicator is made, rccl_comm.cpp); 1 without a communicator
+    nranks_seen = ctx.nranks
     Wtrue = ppals.init_factors(lens, R, 1000)
     W0 = ppals.init_factors(lens, R, 2000)
     G0 = ppals.init_factors(lens, R, 3000)
 
     def barrier():
         ctx.sync()
-        torch.cuda.synchronize()
+        if not hostsim:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -457,12 +536,13 @@ def main():
         t0 = time.perf_counter()
         cp.sweeps_dt(steps)
         ctx.sync()
-        torch.cuda.synchronize()
+        if not hostsim:
+            torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         clk1 = _clocks_ns()
         ctx.profile_enable(0)
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         barrier()
@@ -472,7 +552,7 @@ def main():
                # host clocks at both ends of the timed region: tools/trace_timed_launches.py picks
                # this region's launches out of a rocprofv3 kernel trace of the same command
                "timed_region_ns": {k: [clk0[k], clk1[k]] for k in clk0}}
-        if launches > 0:
+        if launches > 0 and scan_ms > 0:
             avg_ms = scan_ms / launches
             achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9
             rec["roofline"] = {
@@ -483,11 +563,19 @@ def main():
         return rec
 
     V = ppals.Tensor(ctx, lens, dtype).fill_cp(Wtrue)
+    t_setup0 = time.perf_counter()
     cp = ppals.CP(ctx, V, R)
+    ctx.sync()
+    session_setup_s = time.perf_counter() - t_setup0
     if args.schedule:
         cp.set_schedule(args.schedule)
     schedule = cp.schedule
     head = measure(cp, args.steps, args.warmup)
+    try:
+        placement = cp.placement_report()
+        placement["session_setup_s"] = session_setup_s
+    except Exception as e:  # reported, never required
+        placement = {"error": str(e)}
     gradnorm = cp.gradnorm()
     resid = cp.residual()
     vnorm = V.norm()
@@ -516,6 +604,28 @@ def main():
         r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
         sub[f"{other}_schedule_{args.dtype}"] = r
         cp.set_schedule(schedule)
+    if world == 1 and not args.schedule and schedule == "msdt":
+        # the SAME measurement in this process with the placement measurement switched off
+        # (PPALS_PLACE_TUNE is read when a session is created): does the set-up's choice of result
+        # blocks / offsets / store kinds pay on THIS box?
+        old = os.environ.get("PPALS_PLACE_TUNE")
+        os.environ["PPALS_PLACE_TUNE"] = "0"
+        try:
+            t0 = time.perf_counter()
+            cpu_ = ppals.CP(ctx, V, R)
+            ctx.sync()
+            r = measure(cpu_, args.steps, args.warmup)
+            r["session_setup_s"] = time.perf_counter() - t0 - r["ms_per_step"] * 1e-3 * (args.steps + args.warmup)
+            r["note"] = ("PPALS_PLACE_TUNE=0: first-level intermediates at offset 0 of one block, store kind "
+                         "by size; same tensor, same process, measured right after the headline")
+            sub["untuned"] = r
+            cpu_.close()
+        except Exception as e:
+            sub["untuned"] = {"error": str(e)}
+        if old is None:
+            del os.environ["PPALS_PLACE_TUNE"]
+        else:
+            os.environ["PPALS_PLACE_TUNE"] = old
     if world > 1:
         # the plan north_star names (reduce-scatter of the s x R partials + row-block solve +
         # all-gather) beside the default for these message sizes (one all-reduce + redundant fused
@@ -585,6 +695,12 @@ def main():
             V4.close()
         except Exception as e:
             sub["cfg4_1gpu"] = {"error": str(e)}
+        sub["shard_probe"] = shard_probe_record(ppals, torch, local_rank)
+        for key, single in (("cfg2_P8", head["ms_per_step"]),
+                            ("cfg4_P8", sub.get("cfg4_1gpu", {}).get("ms_per_step"))):
+            ent = sub["shard_probe"].get(key)
+            if ent and single:
+                ent["projected_efficiency_at_8"] = (single / 8.0) / ent["ms_per_sweep_per_rank"]
 
     if rank == 0:
         ms_per_step = head["ms_per_step"]
@@ -604,7 +720,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "synthetic" if not hostsim else "synthetic — CPU REHEARSAL on the host stand-in, not a measurement",
             "config": {"workload": f"CP order-4 s={lens[0]} R={R} dense `-tensor r` (V=[[W_true]], "
                                    "U(0,1) factors), -pp 0 exact DT sweep incl. Normalize; tensor "
                                    f"stored {args.dtype} in HBM, factor/Gram/solve math fp64; "
@@ -651,6 +767,7 @@ def main():
                         f"launches per sweep: 2 (dt) or N/(N-1) (msdt: one first-level "
                         f"contraction serves N-1 mode updates)"})
             out["roofline"] = rl
+        out["placement"] = placement
         out["timed_region_ns"] = head.get("timed_region_ns")
         if sub:
             out["sub_records"] = sub

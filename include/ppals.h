@@ -134,6 +134,18 @@ int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat /*may be 
 #define PPALS_SCHEDULE_MSDT 1
 int ppals_cp_set_schedule(ppals_cp *s, int schedule);
 int ppals_cp_get_schedule(const ppals_cp *s);
+/* What the session's set-up measured when it placed the multi-sweep schedule's first-level
+ * intermediates (no counterpart in the reference: CTF places its own buffers): one JSON object
+ * {"measured", "setup_s", "roots": [{"root", "layout", "block", "offset_mb", "store", "candidates",
+ * "best_ms", "worst_ms"}]} written to buf (NUL-terminated). PPALS_PLACE_TUNE=0 switches the
+ * measurement off ("measured": false). */
+int ppals_cp_placement_report(const ppals_cp *s, char *buf, int cap);
+/* The operator builds of the PP phases (Build_mttkrp_map + the N full MTTKRPs, als_CP.cxx:678-694)
+ * since the last reset: their number and — while timing is on — their duration, the stream
+ * synchronised on both sides of each. mode 0: read only; +1: read, then reset and turn timing on;
+ * -1: read, then reset and turn it off. (The reference's [dtime] column counts a build inside the
+ * interval that ends at the first PP row, als_CP.cxx:667-697.) */
+int ppals_cp_pp_build_stats(ppals_cp *s, int mode, int64_t *builds, double *seconds);
 /* n exact dimension-tree sweeps (body of alsCP_DT's loop incl. Normalize, als_CP.cxx:215-303),
  * enqueued asynchronously on the engine stream; no print block, no host sync */
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda);

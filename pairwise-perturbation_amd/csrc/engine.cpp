@@ -314,8 +314,9 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ms_cand_.clear();
     ms_tuning_now_ = false;
     ops_.sync();
+    ms_place_setup_s_ = now() - t_tune0;
     if (getenv("PPALS_DEBUG_ADDR"))
-      fprintf(stderr, "[ppals] placement measured in %.2f s\n", now() - t_tune0);
+      fprintf(stderr, "[ppals] placement measured in %.2f s\n", ms_place_setup_s_);
     ms_invalidate();
     ms_X_.valid = false;
   }
@@ -1166,10 +1167,13 @@ void CpEngine::ms_start_step(int first) {
           if (verbose >= 2)
             fprintf(stderr, "[ppals] root %d: X %p +%lld MB %.3f ms\n", first, base, (long long)mb,
                     tmin * 1e3);
+          ms_place_worst_[first] = std::max(ms_place_worst_[first], tmin);
+          ms_place_ncand_[first]++;
           if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
             best = tmin;
             ms_X_off_[first] = off;
             ms_X_root_[first] = b == 0 ? nullptr : base;
+            ms_place_block_[first] = (int)b;
           }
           if ((int)ms_cand_.size() <= first) ms_cand_.resize(first + 1);
           if (ms_cand_[first].size() <= b) ms_cand_[first].resize(b + 1, {1e300, 0});
@@ -1978,6 +1982,26 @@ static std::string all_but(int N, int i, int j = -1) {
 }
 // als_CP.cxx:678-694: all pair operators, then all N full MTTKRPs
 void CpEngine::pp_build_all() {
+  struct Timer {  // (only while a caller asked for it: ppals_cp_pp_build_stats)
+    CpEngine &e;
+    double t0 = 0;
+    explicit Timer(CpEngine &eng) : e(eng) {
+      e.pp_builds_++;
+      if (e.pp_build_timed_) {
+        e.ops_.sync();
+        t0 = now();
+      }
+    }
+    ~Timer() {
+      if (e.pp_build_timed_) {
+        try {
+          e.ops_.sync();
+        } catch (...) {
+        }
+        e.pp_build_s_ += now() - t0;
+      }
+    }
+  } timer(*this);
   pp_clear();
   for (int ii = 0; ii < N_; ii++)
     for (int jj = ii + 1; jj < N_; jj++) pp_get(all_but(N_, ii, jj));
@@ -2005,6 +2029,30 @@ void CpEngine::pp_build_all() {
     }
   }
 }
+std::string CpEngine::placement_report() const {
+  char buf[256];
+  std::string out = "{\"measured\": ";
+  out += (ms_place_setup_s_ > 0 ? "true" : "false");
+  snprintf(buf, sizeof buf, ", \"setup_s\": %.4f, \"result_blocks_kept\": %d, \"roots\": [", ms_place_setup_s_,
+           (int)ms_X_alt_.size() + (ms_X_base_ ? 1 : 0));
+  out += buf;
+  bool firstrow = true;
+  for (int r = 0; r < N_; r++) {
+    if (!ms_tuned_[r] || ms_place_ncand_[r] == 0) continue;
+    snprintf(buf, sizeof buf,
+             "%s{\"root\": %d, \"layout\": \"%s\", \"block\": %d, \"offset_mb\": %lld, \"store\": \"%s\", "
+             "\"candidates\": %d, \"best_ms\": %.4f, \"worst_ms\": %.4f}",
+             firstrow ? "" : ", ", r, ms_root_layout_[r] == 1 ? "second (transposed) copy" : "tensor",
+             ms_place_block_[r], (long long)(ms_X_off_[r] >> 20),
+             ms_X_nt_[r] == 1 ? "non-temporal" : (ms_X_nt_[r] == 0 ? "ordinary" : "by size"), ms_place_ncand_[r],
+             ms_tuned_ms_[r] * 1e3, ms_place_worst_[r] * 1e3);
+    out += buf;
+    firstrow = false;
+  }
+  out += "]}";
+  return out;
+}
+
 int64_t CpEngine::pp_operator(const std::string &contracted, double *out_host) {
   for (size_t k = 0; k < contracted.size(); k++) {
     int m = contracted[k] - 'a';

@@ -73,6 +73,20 @@ class CpEngine {
   void set_factors(const double *Wflat, const double *gradWflat);
   void set_schedule(int schedule);
   int schedule() const { return schedule_; }
+  // one JSON object: what the set-up's placement measurement chose for every root of the
+  // multi-sweep schedule (block, offset, store kind, fastest / slowest candidate), and its cost
+  std::string placement_report() const;
+  // operator builds of the PP phases (Build_mttkrp_map, als_CP.cxx:678-694): how many, and — while
+  // timing is on (a stream synchronisation on both sides of a build) — how long they took
+  void pp_build_stats(int mode, int64_t *builds, double *seconds) {
+    if (builds) *builds = pp_builds_;
+    if (seconds) *seconds = pp_build_s_;
+    if (mode != 0) {
+      pp_builds_ = 0;
+      pp_build_s_ = 0;
+      pp_build_timed_ = mode > 0;
+    }
+  }
   void get_factors(double *Wflat, double *gradWflat);
 
   // body of the reference's sweep loop: als_CP.cxx:215-303 (clear cache, N mode updates,
@@ -180,6 +194,13 @@ class CpEngine {
   double ms_tuned_ms_[MAX_ORDER] = {0};   // the chosen placement's scan time, seconds
   int ms_root_layout_[MAX_ORDER] = {0};   // which resident layout the root's scan reads
   std::vector<std::vector<std::pair<double, int64_t>>> ms_cand_;  // [root][block] -> (ms, offset)
+  // what the measurement saw, for the caller's records (placement_report)
+  double ms_place_worst_[MAX_ORDER] = {0};  // slowest candidate of the root, seconds
+  int ms_place_ncand_[MAX_ORDER] = {0}, ms_place_block_[MAX_ORDER] = {0};
+  double ms_place_setup_s_ = 0;
+  int64_t pp_builds_ = 0;
+  double pp_build_s_ = 0;
+  bool pp_build_timed_ = false;
   bool ms_tuned_[MAX_ORDER] = {false};
   bool ms_tune_enabled_ = true;
   size_t ms_X_slack() const;

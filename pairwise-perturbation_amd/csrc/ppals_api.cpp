@@ -318,6 +318,22 @@ int ppals_cp_set_schedule(ppals_cp *s, int schedule) {
   API_END(PPALS_ERR_HIP)
 }
 int ppals_cp_get_schedule(const ppals_cp *s) { return s && s->eng ? s->eng->schedule() : PPALS_ERR_ARG; }
+int ppals_cp_placement_report(const ppals_cp *s, char *buf, int cap) {
+  if (!s || !s->eng || !buf || cap <= 0) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  const std::string r = s->eng->placement_report();
+  if ((int)r.size() + 1 > cap) return fail(PPALS_ERR_ARG, "buffer too small");
+  std::memcpy(buf, r.c_str(), r.size() + 1);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
+int ppals_cp_pp_build_stats(ppals_cp *s, int mode, int64_t *builds, double *seconds) {
+  if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
+  API_BEGIN
+  s->eng->pp_build_stats(mode, builds, seconds);
+  return PPALS_OK;
+  API_END(PPALS_ERR_HIP)
+}
 int ppals_cp_sweeps_dt(ppals_cp *s, int n, double lambda) {
   if (!s || !s->eng) return fail(PPALS_ERR_ARG, "NULL argument");
   API_BEGIN

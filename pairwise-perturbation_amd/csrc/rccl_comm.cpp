@@ -30,6 +30,8 @@ struct RcclApi {
   int (*GetUniqueId)(ncclUniqueId_t *) = nullptr;
   int (*CommInitRank)(ncclComm_h *, int, ncclUniqueId_t, int) = nullptr;
   int (*CommDestroy)(ncclComm_h) = nullptr;
+  int (*CommCount)(const ncclComm_h, int *) = nullptr;
+  int (*CommUserRank)(const ncclComm_h, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_h, void *) = nullptr;
   int (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_h, void *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_h, void *) = nullptr;
@@ -51,6 +53,8 @@ RcclApi &api() {
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
+  SYM(CommUserRank, "ncclCommUserRank");
   SYM(AllReduce, "ncclAllReduce");
   SYM(ReduceScatter, "ncclReduceScatter");
   SYM(AllGather, "ncclAllGather");
@@ -72,6 +76,20 @@ class RcclComm : public Comm {
     ncclUniqueId_t id;
     std::memcpy(id.internal, uid, 128);
     check(api().CommInitRank(&comm_, nranks, id, rank), "ncclCommInitRank");
+    // what RCCL itself says about the communicator it made: size() and rank() answer with ITS
+    // numbers from here on, and a disagreement with what the caller asked for ends the set-up
+    int cnt = -1, ur = -1;
+    check(api().CommCount(comm_, &cnt), "ncclCommCount");
+    check(api().CommUserRank(comm_, &ur), "ncclCommUserRank");
+    if (cnt != nranks || ur != rank) {
+      api().CommDestroy(comm_);
+      comm_ = nullptr;
+      throw std::runtime_error("ppals: RCCL communicator reports " + std::to_string(cnt) + " ranks / rank " +
+                               std::to_string(ur) + ", asked for " + std::to_string(nranks) + " / " +
+                               std::to_string(rank));
+    }
+    size_ = cnt;
+    rank_ = ur;
   }
   ~RcclComm() override {
     if (comm_) api().CommDestroy(comm_);

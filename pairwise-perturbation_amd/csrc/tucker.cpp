@@ -159,6 +159,17 @@ void TuckerEngine::compute_left_half_on_vt(Node &n) {
   const void *cur = VT_;
   int cur_dt = V_.dtype;
   int pp_slot = 0;
+  // A LEAF (one mode on the right: order 3) keeps the chain's own order [s_mode | left ranks]: that
+  // IS the unfolding with the mode in front which the Gram wants, so neither the transposition into
+  // the tree's order nor the one back (2 x 7 us at cfg5) happens; the last scan writes the node.
+  const bool front_leaf = (nr == 1) && !dist_;
+  int64_t node_elems_total = 1;
+  for (int m = 0; m < N_; m++) node_elems_total *= (m >= nl ? ext(m) : r_[m]);
+  if (front_leaf && n.cap < node_elems_total) {
+    ops_.free(n.buf);
+    n.buf = (double *)ops_.alloc(sizeof(double) * node_elems_total);
+    n.cap = node_elems_total;
+  }
   for (int m = n.shi; m >= 0; m--) {
     const int p = nr + m;  // storage position of mode m
     int64_t L = 1, T = 1;
@@ -167,13 +178,18 @@ void TuckerEngine::compute_left_half_on_vt(Node &n) {
     const bool last = (m == 0);
     const int dst_dt = last ? F64 : V_.dtype;
     const size_t need = dtype_size(dst_dt) * (size_t)(L * r_[m] * T);
-    if (chain_cap_[pp_slot] < need) {
-      ops_.free(chain_[pp_slot]);
-      chain_[pp_slot] = ops_.alloc(need);
-      chain_cap_[pp_slot] = need;
+    void *dst;
+    if (last && front_leaf) {
+      dst = n.buf;
+    } else {
+      if (chain_cap_[pp_slot] < need) {
+        ops_.free(chain_[pp_slot]);
+        chain_[pp_slot] = ops_.alloc(need);
+        chain_cap_[pp_slot] = need;
+      }
+      dst = chain_[pp_slot];
+      pp_slot ^= 1;
     }
-    void *dst = chain_[pp_slot];
-    pp_slot ^= 1;
     FactorRef f;
     f.ptr = wptr(m);
     f.rows = dims[p];
@@ -182,6 +198,11 @@ void TuckerEngine::compute_left_half_on_vt(Node &n) {
     cur = dst;
     cur_dt = dst_dt;
     dims[p] = r_[m];
+  }
+  n.front = front_leaf;
+  if (front_leaf) {
+    n.valid = true;
+    return;
   }
   int64_t rows = 1, cols = 1;
   for (int q = 0; q < nr; q++) rows *= dims[q];
@@ -204,6 +225,7 @@ void TuckerEngine::compute_node(int idx) {
     compute_left_half_on_vt(n);
     return;
   }
+  n.front = false;
   std::vector<int64_t> dims(N_);
   const void *src;
   int dt;
@@ -361,8 +383,18 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
 void TuckerEngine::ensure_core() {
   if (!core_owed_) return;
   core_owed_ = false;
-  int64_t Lc = ncore_ / r_[N_ - 1];
-  ops_.ttm_keep(yend_src_, F64, Lc, V_.glens[N_ - 1], 1, W_[N_ - 1], V_.glens[N_ - 1], r_[N_ - 1], core_);
+  const int64_t Lc = ncore_ / r_[N_ - 1], sN = V_.glens[N_ - 1];
+  const int rN = r_[N_ - 1];
+  if (yend_T_ == 1) {  // the tree's order [ranks before | s_{N-1}]
+    ops_.ttm_keep(yend_src_, F64, Lc, sN, 1, W_[N_ - 1], sN, rN, core_);
+  } else {
+    // the last leaf kept the mode in front, [s_{N-1} | ranks]: core^T first, then its order
+    double *tmp = (double *)ops_.alloc(sizeof(double) * ncore_);
+    ops_.ttm_keep(yend_src_, F64, 1, sN, Lc, W_[N_ - 1], sN, rN, tmp);  // [r_{N-1}, ranks before]
+    ops_.transpose2d(tmp, F64, rN, Lc, core_);
+    ops_.sync();
+    ops_.free(tmp);
+  }
 }
 
 void TuckerEngine::compute_core_full() {
@@ -524,8 +556,13 @@ void TuckerEngine::mode_step(int i, const std::vector<double *> *align_ref, bool
   int64_t L = 1, T = 1;
   for (int q = 0; q < i; q++) L *= r_[q];
   for (int q = i + 1; q < N_; q++) T *= r_[q];
+  if (lf.front) {  // [s_i | ranks of the other modes] (compute_left_half_on_vt)
+    T = L * T;
+    L = 1;
+  }
   double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
   if (i == N_ - 1) {  // als_Tucker.cxx:395
+    yend_T_ = T;
     // (one GPU: the leaf's own buffer stays as it is until this mode is stepped again — no copy)
     if (dist_) {
       ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);

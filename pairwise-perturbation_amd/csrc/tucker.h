@@ -30,6 +30,7 @@ class TuckerEngine {
     double *buf = nullptr;
     int64_t cap = 0;
     bool valid = false;
+    bool front = false;  // a leaf stored [s_mode | ranks of the other modes] instead of the tree's order
   };
   void build_tree(int lo, int hi, int parent);
   // dims of a node's tensor: ranks on the contracted modes, full extent elsewhere
@@ -47,6 +48,7 @@ class TuckerEngine {
   void ensure_core();  // the core the last exact sweep owes: Y_end x_{N-1} W_{N-1}
   bool core_owed_ = false;
   const double *yend_src_ = nullptr;
+  int64_t yend_T_ = 1;  // layout of yend_src_: [ranks before, s_{N-1}] (1) or [s_{N-1} | ranks] (their product)
   double core_norm();
   bool agree(bool local);
   double residual();

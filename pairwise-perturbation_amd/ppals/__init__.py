@@ -49,7 +49,7 @@ EXPORTS = [
     "ppals_pp_operator", "ppals_cp_residual", "ppals_cp_gram_system", "ppals_cp_create",
     "ppals_cp_destroy", "ppals_cp_set_factors", "ppals_cp_get_factors", "ppals_cp_sweeps_dt",
     "ppals_cp_gradnorm", "ppals_cp_dt", "ppals_cp_pp", "ppals_cp_pp_partupdate",
-    "ppals_cpd_als", "ppals_cpd_als_lr", "ppals_cp_set_schedule", "ppals_cp_get_schedule",
+    "ppals_cpd_als", "ppals_cpd_als_lr", "ppals_cp_set_schedule", "ppals_cp_get_schedule", "ppals_cp_placement_report", "ppals_cp_pp_build_stats",
     "ppals_tucker_create",
     "ppals_tucker_destroy", "ppals_tucker_set_factors", "ppals_tucker_get_factors",
     "ppals_tucker_set_core",
@@ -286,6 +286,20 @@ class CP:
     @property
     def schedule(self):
         return {0: "dt", 1: "msdt"}[_check(lib().ppals_cp_get_schedule(self._h))]
+
+    def placement_report(self):
+        """what the set-up's placement measurement chose per root of the multi-sweep schedule (dict)"""
+        import json
+        buf = C.create_string_buffer(8192)
+        _check(lib().ppals_cp_placement_report(self._h, buf, 8192))
+        return json.loads(buf.value.decode())
+
+    def pp_build_stats(self, mode=0):
+        """(number, seconds) of the PP operator builds since the last reset; mode +1 / -1: reset and
+        turn their timing on / off"""
+        n, sec = C.c_int64(0), C.c_double(0)
+        _check(lib().ppals_cp_pp_build_stats(self._h, mode, C.byref(n), C.byref(sec)))
+        return n.value, sec.value
 
     def sweeps_dt(self, n, lam=0.0):
         _check(lib().ppals_cp_sweeps_dt(self._h, n, C.c_double(lam)))

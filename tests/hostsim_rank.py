@@ -22,39 +22,19 @@ def main():
     pp = hostsim_util.load()
     ctx = pp.Context(0)
 
-    AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64)
-    RS = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
-    AG = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
-    calls = {"ar": 0, "rs": 0, "ag": 0}
-
-    def allreduce(buf, n):
-        calls["ar"] += 1
-        t = torch.from_numpy(np.ctypeslib.as_array(buf, (n,)))
-        dist.all_reduce(t)
-
-    def reduce_scatter(send, recv, n):  # gloo has no reduce_scatter: all_reduce + slice
-        calls["rs"] += 1
-        t = torch.from_numpy(np.ctypeslib.as_array(send, (n * world,)).copy())
-        dist.all_reduce(t)
-        np.ctypeslib.as_array(recv, (n,))[:] = t.numpy()[rank * n:(rank + 1) * n]
-
-    def allgather(send, recv, n):
-        calls["ag"] += 1
-        mine = torch.from_numpy(np.ctypeslib.as_array(send, (n,)).copy())
-        outs = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(outs, mine)
-        np.ctypeslib.as_array(recv, (n * world,))[:] = torch.cat(outs).numpy()
-
-    cbs = (AR(allreduce), RS(reduce_scatter), AG(allgather))
-    uid = C.create_string_buffer(128)
-    for i, cb in enumerate(cbs):
-        C.memmove(C.byref(uid, 8 * i), C.byref(C.cast(cb, C.c_void_p)), 8)
+    uid, cbs, calls = hostsim_util.gloo_comm_uid(rank, world)  # (cbs: kept alive with the context)
     ctx.init_comm(rank, world, uid)
     assert ctx.nranks == world and ctx.rank == rank
 
     def relerr(a, b):
         return np.linalg.norm(a - b) / np.linalg.norm(b)
 
+    if os.environ.get("PPALS_RANK_MODE") == "rs_unequal":
+        rs_unequal_cases(pp, ctx, rank, world, calls, relerr)
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"rank {rank}: OK", calls)
+        return
     if os.environ.get("PPALS_RANK_MODE") == "rs_plan":
         rs_plan_cases(pp, ctx, rank, world, calls, relerr)
         dist.barrier()
@@ -270,6 +250,47 @@ def rs_plan_cases(pp, ctx, rank, world, calls, relerr):
             assert it == it_ref
             for a, b in zip(s.get_factors(), W_pp_ref):
                 assert relerr(a, b) < 1e-6, relerr(a, b)
+            s.close()
+        t.close()
+    assert calls["rs"] > 0 and calls["ag"] > 0
+
+
+def rs_unequal_cases(pp, ctx, rank, world, calls, relerr):
+    """the reduce-scatter / all-gather plan for every mode with UNEQUAL shards: the leading extent is
+    not a multiple of the world size, so the last rank holds fewer rows and the row blocks of every
+    other mode's s x R partials are padded to a uniform height — the case a one-rank communicator on
+    the GPU box can never reach. fp64 storage, both schedules, factors and gradients against the
+    unsharded oracle, collective counts per sweep."""
+    os.environ["PPALS_COMM_SMALL_BYTES"] = "0"
+    for lens, R in [([2 * world + 1, 2 * world + 1, world + 2, world + 1], 3),
+                    ([3 * world - 1, 2 * world + 1, 2 * world + 3], 2)]:
+        N = len(lens)
+        V = O.build_V(O.init_factors(lens, R, 1234))
+        W = O.init_factors(lens, R, 4321)
+        G = O.init_factors(lens, R, 99)
+        t = pp.Tensor(ctx, lens, 1).upload(V)
+        lo, n = t.local_rows()
+        blk = -(-lens[0] // world)
+        assert lo == rank * blk and n == min(blk, lens[0] - lo)
+        assert lens[0] % world != 0 and (rank < world - 1 or n < blk)      # the last rank is short
+        K = 3
+        _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
+        for schedule in ("msdt", "dt"):
+            s = pp.CP(ctx, t, R)
+            s.set_schedule(schedule)
+            s.set_factors(W, G)
+            before = dict(calls)
+            s.sweeps_dt(K)
+            assert calls["rs"] - before["rs"] == K * (N - 1), (calls, before)
+            assert calls["ag"] - before["ag"] == K * N, (calls, before)
+            W_got, G_got = s.get_factors(with_grad=True)
+            for a, b in zip(W_got, W_ref):
+                assert relerr(a, b) < 1e-8, (schedule, relerr(a, b))
+            for a, b in zip(G_got, G_ref):
+                assert np.linalg.norm(a - b) < 1e-7 * (1 + np.linalg.norm(b))
+            gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
+            assert abs(s.gradnorm() - gn_ref) < 1e-8 * gn_ref
+            assert abs(s.residual() - O.residual(V, W_ref)) < 1e-8 * np.linalg.norm(V)
             s.close()
         t.close()
     assert calls["rs"] > 0 and calls["ag"] > 0

@@ -33,3 +33,18 @@ test_cfg1_cli_matches_oracle = D.test_cfg1_cli_matches_oracle
 test_file_exchange_and_o_path = D.test_file_exchange_and_o_path
 test_o_path_rejects_short_file = D.test_o_path_rejects_short_file
 test_pp_bench_tucker_lines = D.test_pp_bench_tucker_lines
+
+# the plug-in point for reference-made fixtures (tests/test_ctf_fixtures.py), on the host stand-in
+import test_ctf_fixtures as CF  # noqa: E402
+
+
+@pytest.mark.parametrize("d", CF._dirs("ctf_selftest"), ids=os.path.basename)
+def test_selftest_fixture(BIN, d, tmp_path):
+    CF.check_fixture(BIN, d, tmp_path)
+
+
+@pytest.mark.parametrize("d", CF._dirs("ctf") or [None], ids=lambda d: os.path.basename(d) if d else "none")
+def test_ctf_made_fixture(BIN, d, tmp_path):
+    if d is None:
+        pytest.skip("no reference-made fixture under tests/golden/ctf/ (tools/make_ctf_fixture.md)")
+    CF.check_fixture(BIN, d, tmp_path)

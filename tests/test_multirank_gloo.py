@@ -78,3 +78,31 @@ def test_reduce_scatter_plan_every_mode(world):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
         assert "OK" in out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_plan_with_unequal_shards(world):
+    """s not divisible by the world size, every mode through reduce-scatter + all-gather
+    (hostsim_rank.rs_unequal_cases): the padding of the row blocks and the short last shard"""
+    import hostsim_util
+    hostsim_util.load()
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", PPALS_RANK_MODE="rs_unequal")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "hostsim_rank.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert "OK" in out
