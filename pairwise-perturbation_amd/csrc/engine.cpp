@@ -266,12 +266,8 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ops_.zero(gatherbuf_, n);
   }
   if (const char *e = std::getenv("PPALS_COMM_SMALL_BYTES")) small_msg_bytes_ = std::atoll(e);
-  if (const char *e = std::getenv("PPALS_DT_SCHEDULE")) schedule_ = (std::string(e) == "dt") ? 0 : 1;
   if (N_ < 3) schedule_ = 0;
-  if (const char *e = std::getenv("PPALS_PP_FAST")) pp_fast_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("PPALS_PLACE_TUNE")) ms_tune_enabled_ = std::atoi(e) != 0;
-  // (off unless asked for: on this stack the replay costs more than the nine launches it replaces,
-  // DESIGN.md section 8)
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
     ms_set_roots(ms_choose_roots());
     ms_scales_ = (double *)ops_.alloc(sizeof(double) * 32);
@@ -308,15 +304,12 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;
       ms_start_step(r);
     }
-    ms_choose_common_block();
     ms_release_unchosen();
     ms_tune_second_layout();
     ms_cand_.clear();
     ms_tuning_now_ = false;
     ops_.sync();
     ms_place_setup_s_ = now() - t_tune0;
-    if (getenv("PPALS_DEBUG_ADDR"))
-      fprintf(stderr, "[ppals] placement measured in %.2f s\n", ms_place_setup_s_);
     ms_invalidate();
     ms_X_.valid = false;
   }
@@ -411,8 +404,7 @@ void CpEngine::ensure_transposed() {
   const int64_t line = 128 / (int64_t)esz;  // elements per 128 B
   int pad_mode = -1;                         // auto
   if (const char *e = std::getenv("PPALS_PAD_LAYOUT")) pad_mode = std::atoi(e);
-  double max_waste = 0.03;
-  if (const char *e = std::getenv("PPALS_PAD_WASTE")) max_waste = std::atof(e);
+  const double max_waste = pad_mode == 1 ? 100.0 : 0.03;  // (forced: whatever the padding costs — tests)
   const bool may_pad = pad_mode == 1 || (pad_mode != 0 && (double)V_.nloc * esz >= 1e8);
   // leading block of a storage order worth padding: the smallest q whose padding is cheap, if the
   // plain order has no aligned position that early
@@ -889,9 +881,8 @@ size_t CpEngine::ms_X_slack() const {
 // Candidates are optional: none are taken when the device is short of room.
 void CpEngine::ms_alloc_candidates(size_t cap) {
   int nb = 4;
-  if (const char *e = std::getenv("PPALS_PLACE_BLOCKS")) nb = std::max(1, std::atoi(e));
-  size_t spacer = (size_t)6 << 30;
-  if (const char *e = std::getenv("PPALS_PLACE_SPACER_MB")) spacer = (size_t)std::max(0, std::atoi(e)) << 20;
+  // (a lowered PPALS_PLACE_MIN_MB means small tensors — the CPU tests of this machinery: a token spacer)
+  const size_t spacer = std::getenv("PPALS_PLACE_MIN_MB") ? ((size_t)1 << 20) : ((size_t)6 << 30);
   const double tensor_bytes = (double)V_.nloc * dtype_size(V_.dtype);
   if (tensor_bytes >= 2.5e10) nb = std::min(nb, 3);  // scans of >= 4 ms: fewer measurements
   std::vector<void *> spacers;
@@ -908,41 +899,6 @@ void CpEngine::ms_alloc_candidates(size_t cap) {
   for (void *sp : spacers) ops_.free(sp);
 }
 
-// PPALS_PLACE_COMMON=1: one block for all roots — the one with the smallest sum of the roots' best
-// times — so that consecutive steps overwrite the same 320 MB (cfg2). Measured and not kept as the
-// default (tools/runs/r03_r.sh, r03_s.sh: three to four sessions per setting on one box, headline
-// 533/558/559 with a common block against 524/591/556 and 580/581/559 with a block per root).
-void CpEngine::ms_choose_common_block() {
-  const char *e = std::getenv("PPALS_PLACE_COMMON");
-  if (!e || std::atoi(e) == 0) return;
-  if (ms_cand_.empty() || ms_X_alt_.empty()) return;
-  const size_t nb = ms_X_alt_.size() + 1;
-  size_t bb = 0;
-  double bsum = 1e300;
-  for (size_t b = 0; b < nb; b++) {
-    double sum = 0;
-    for (auto &r : ms_cand_)
-      if (!r.empty()) sum += b < r.size() ? r[b].first : 1e300;
-    if (sum < bsum) {
-      bsum = sum;
-      bb = b;
-    }
-  }
-  for (size_t r = 0; r < ms_cand_.size(); r++) {
-    if (ms_cand_[r].empty() || bb >= ms_cand_[r].size()) continue;
-    ms_X_root_[r] = bb == 0 ? nullptr : ms_X_alt_[bb - 1];
-    ms_X_off_[r] = ms_cand_[r][bb].second;
-  }
-  if (getenv("PPALS_DEBUG_ADDR")) {
-    fprintf(stderr, "[ppals] X of every root in block %p (sum of the roots' scans %.3f ms):",
-            bb == 0 ? ms_X_base_ : ms_X_alt_[bb - 1], bsum * 1e3);
-    for (size_t r = 0; r < ms_cand_.size(); r++)
-      if (!ms_cand_[r].empty()) fprintf(stderr, " root %zu +%lld MB", r, (long long)(ms_X_off_[r] >> 20));
-    fprintf(stderr, "\n");
-  }
-  ms_cand_.clear();
-}
-
 // The second resident layout is the session's own buffer, so its place can be chosen as well: with
 // the result block fixed (chosen above with the roots that read the tensor's own buffer weighing
 // in), a few further copies of the layout are tried elsewhere in the device memory and the one the
@@ -951,10 +907,9 @@ void CpEngine::ms_choose_common_block() {
 // allocated until the choice is made, so that each lands somewhere else; all but one are freed.
 void CpEngine::ms_tune_second_layout() {
   if (lay_.size() < 2 || !lay_[1].owned || lay_[1].bytes == 0) return;
-  int nc = 3;
-  if (const char *e = std::getenv("PPALS_PLACE_LAYOUTS")) nc = std::max(1, std::atoi(e));
+  const int nc = 3;
   const size_t bytes = lay_[1].bytes;
-  if (nc <= 1 || (double)bytes > 1.7e10) return;  // larger layouts span the regions anyway
+  if ((double)bytes > 1.7e10) return;  // larger layouts span the regions anyway
   std::vector<int> roots;
   double cur = 0;
   for (int r = 0; r < N_; r++)
@@ -963,7 +918,6 @@ void CpEngine::ms_tune_second_layout() {
       cur += ms_tuned_ms_[r];
     }
   if (roots.empty()) return;
-  const bool dbg = getenv("PPALS_DEBUG_ADDR") != nullptr;
   struct Cand {
     void *p;
     double sum;
@@ -995,9 +949,6 @@ void CpEngine::ms_tune_second_layout() {
       ms_start_step(r);
       sum += ms_tuned_ms_[r];
     }
-    if (dbg)
-      fprintf(stderr, "[ppals] second layout at %p: its roots scan in %.3f ms (so far %.3f ms at %p)\n", p,
-              sum * 1e3, best.sum * 1e3, best.p);
     if (sum < best.sum * 0.99) {
       rejected.push_back(best.p);
       best = snapshot(p, sum);
@@ -1142,7 +1093,6 @@ void CpEngine::ms_start_step(int first) {
     if (bytes >= place_min_bytes() && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
       const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
       const int reps = large ? 1 : 2;
-      const int verbose = getenv("PPALS_DEBUG_ADDR") ? std::atoi(getenv("PPALS_DEBUG_ADDR")) : 0;
       double best = 1e300;
       for (size_t b = 0; b <= ms_X_alt_.size(); b++) {
         void *base = b == 0 ? ms_X_base_ : ms_X_alt_[b - 1];
@@ -1164,9 +1114,6 @@ void CpEngine::ms_start_step(int first) {
           // keep, share and free candidate blocks run on the CPU stand-in as well)
           if (const char *e = std::getenv("PPALS_PLACE_PREFER_BLOCK"))
             if ((first & 1) && (int)b == std::atoi(e)) tmin *= 1e-3;
-          if (verbose >= 2)
-            fprintf(stderr, "[ppals] root %d: X %p +%lld MB %.3f ms\n", first, base, (long long)mb,
-                    tmin * 1e3);
           ms_place_worst_[first] = std::max(ms_place_worst_[first], tmin);
           ms_place_ncand_[first]++;
           if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
@@ -1181,11 +1128,7 @@ void CpEngine::ms_start_step(int first) {
         }
       }
       // the other kind of result store at the chosen placement (see hip_ops.hip, nt_store)
-      static const bool try_kinds = [] {
-        const char *e = std::getenv("PPALS_PLACE_STORE_KIND");
-        return !(e && std::atoi(e) == 0);
-      }();
-      if (try_kinds && xbytes >= ((size_t)32 << 20)) {
+      if (xbytes >= ((size_t)32 << 20)) {
         double t_alt[2] = {1e300, 1e300};
         void *base = ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_;
         for (int kind = 0; kind < 2; kind++) {
@@ -1200,22 +1143,11 @@ void CpEngine::ms_start_step(int first) {
         }
         ms_X_nt_[first] = t_alt[1] < t_alt[0] ? 1 : 0;
         best = std::min(t_alt[0], t_alt[1]);
-        if (verbose)
-          fprintf(stderr, "[ppals] root %d: ordinary stores %.3f ms, non-temporal %.3f ms\n", first,
-                  t_alt[0] * 1e3, t_alt[1] * 1e3);
       }
       ms_tuned_ms_[first] = best;
       ms_root_layout_[first] = (int)(pl.lay - lay_.data());
-      if (verbose)
-        fprintf(stderr, "[ppals] root %d: X placed in block %p at +%lld MB (%.3f ms, %zu blocks tried)\n",
-                first, ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_,
-                (long long)(ms_X_off_[first] >> 20), best * 1e3, ms_X_alt_.size() + 1);
     }
   }
-  if (getenv("PPALS_DEBUG_ADDR"))
-    fprintf(stderr, "[ppals] step roots %d..+%d: src %p (layout %d of %d) X %p L %lld J %lld T %lld\n",
-            first, k, src, (int)(pl.lay - lay_.data()), (int)lay_.size(), ms_X_.buf, (long long)L,
-            (long long)J, (long long)T);
   launch_scan(ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_, ms_X_off_[first]);
   ms_X_.pending = false;
   ms_X_.valid = true;
@@ -2016,10 +1948,9 @@ void CpEngine::pp_build_all() {
       ++it;
     }
   }
-  // ... and its buffers go back to the device when they are large (PPALS_PP_SCRATCH_KEEP bytes,
-  // default 2 GiB: below that, keeping one per level saves the hipMalloc / hipFree of every phase)
-  size_t keep = (size_t)2 << 30;
-  if (const char *e = std::getenv("PPALS_PP_SCRATCH_KEEP")) keep = (size_t)std::atoll(e);
+  // ... and its buffers go back to the device when they are large (above 2 GiB: below that, keeping
+  // one per level saves the hipMalloc / hipFree of every phase)
+  const size_t keep = (size_t)2 << 30;
   for (auto it = pp_pool_.begin(); it != pp_pool_.end();) {
     if (it->first[0] == '#' && it->second.cap > keep) {
       ops_.free(it->second.buf);

@@ -188,7 +188,6 @@ class CpEngine {
   int64_t ms_X_off_[MAX_ORDER] = {0};
   void ms_alloc_candidates(size_t cap);
   void ms_release_unchosen();
-  void ms_choose_common_block();
   int ms_X_nt_[MAX_ORDER];  // store kind of the root's scan: -1 the back end's rule, 0 ordinary, 1 non-temporal
   void ms_tune_second_layout();
   double ms_tuned_ms_[MAX_ORDER] = {0};   // the chosen placement's scan time, seconds
@@ -245,7 +244,7 @@ class CpEngine {
   const PPOp &pp_get(const std::string &seq);
   // out (+)= T contracted over `cmode` with f; T is a pair operator (two modes, any storage order)
   void pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, double *out, int64_t out_rows);
-  bool pp_fast_ = true;  // both resident layouts + typed level-1 operators (PPALS_PP_FAST=0: off)
+  bool pp_fast_ = true;  // both resident layouts + typed level-1 operators (pp_operator() switches it off for its fp64 hand-out)
   bool pp_no_borrow_ = false;  // pp_operator(): never hand out the (scaled) multi-sweep intermediate
   void pp_clear();
   void pp_build_all();

@@ -72,9 +72,6 @@ class HipOps : public Ops {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
     ncu_ = prop.multiProcessorCount;
-    // PPALS_SCAN_VARIANT: 2 (default) buffer-load suffix scan, 1 global-load fast kernels,
-    // 0 generic predicated kernels — for A/B measurements
-    if (const char *v = getenv("PPALS_SCAN_VARIANT")) variant_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_update,
@@ -83,32 +80,20 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<false, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    if (const char *v = getenv("PPALS_UPDATE_STAGE")) stage_update_ = atoi(v);
-    if (const char *v = getenv("PPALS_UPDATE_FUSE_NORM")) update_fuse_norm_ = atoi(v);
-    if (const char *v = getenv("PPALS_UPDATE_MFMA")) update_mfma_ = atoi(v);
-    if (const char *v = getenv("PPALS_UPDATE_PRESOLVE")) update_presolve_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
-    if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));
     if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_SIGMA_SCALE")) eig_sigma_scale_ = atof(v);
     if (const char *v = getenv("PPALS_EIG_COLD")) eig_cold_ = atoi(v);
-    if (const char *v = getenv("PPALS_RANK_MFMA")) rank_mfma_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
-    if (const char *v = getenv("PPALS_GRAM_MFMA")) gram_mfma_ = atoi(v);
-    if (const char *v = getenv("PPALS_GRAM_SYRK")) gram_syrk_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_m,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_apply,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    if (const char *v = getenv("PPALS_EIG_FUSED")) eig_fused_ = atoi(v);
-    if (const char *v = getenv("PPALS_EIG_LAZY")) eig_lazy_ok_ = atoi(v);
     if (const char *v = getenv("PPALS_SYM_LDS_MIN")) sym_lds_min_ = std::max(32, atoi(v));
     if (const char *v = getenv("PPALS_EIG_DEFER")) eig_defer_ok_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
@@ -230,7 +215,7 @@ class HipOps : public Ops {
   bool rank_mfma(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                  double *out) {
     constexpr int VEC = ScanTraits<TV>::VEC;
-    if (!rank_mfma_ || R > 32 || M % VEC != 0 || M < VEC || (((uintptr_t)V) & 15) != 0 || K < 1)
+    if (R > 32 || M % VEC != 0 || M < VEC || (((uintptr_t)V) & 15) != 0 || K < 1)
       return false;
     const int RB = MODE == 2 ? 1 : (R + 3) / 4;
     const int64_t nkb64 = (K + 15) / 16;
@@ -275,7 +260,7 @@ class HipOps : public Ops {
   bool rank_split(void *V, int64_t M, int64_t K, const double *Q, const double *P, int R,
                   double *out) {
     constexpr int VEC = ScanTraits<TV>::VEC;
-    if (!rank_mfma_ || R <= 32 || R > 256 || M % VEC != 0 || M < VEC ||
+    if (R <= 32 || R > 256 || M % VEC != 0 || M < VEC ||
         (((uintptr_t)V) & 15) != 0 || K < 1)
       return false;
     const int RB = (R + 3) / 4;
@@ -552,7 +537,7 @@ class HipOps : public Ops {
 #define LAUNCH_PREFIX_FAST(NTv)                                                               \
   hipLaunchKernelGGL((k_scan_prefix_fast<TV, NTv, 12>), grid_il, dim3(256), 0, st_, V, M, K, P, per, \
                      nblk, dst, dst_ks, dst_ns, dst_ss, ncols, dst32)
-        if (al && variant_ >= 1 && M >= VEC) {
+        if (al && M >= VEC) {
           if (NT == 1) LAUNCH_PREFIX_FAST(1);
           else if (NT == 2) LAUNCH_PREFIX_FAST(2);
           else if (NT == 3) LAUNCH_PREFIX_FAST(3);
@@ -642,11 +627,8 @@ class HipOps : public Ops {
         // the result next streams it from HBM either way. Not on every pair of buffers, though: in one
         // process (r03q_place6_nt_same_process.txt) 1.21 -> 1.06 ms for some, +1 % for others — so
         // the engine's placement tuner measures both kinds for the first-level intermediate
-        // (scan_store_mode); this rule is for every other large result. PPALS_SCAN_NT_MB moves it.
-        static const double nt_min_bytes = [] {
-          const char *e = std::getenv("PPALS_SCAN_NT_MB");
-          return (e ? std::atof(e) : 192.0) * 1048576.0;
-        }();
+        // (scan_store_mode); this rule is for every other large result.
+        constexpr double nt_min_bytes = 192.0 * 1048576.0;
         const bool nt_store =
             nsplit == 1 && (scan_nt_mode_ < 0 ? (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes
                                               : scan_nt_mode_ == 1);
@@ -672,7 +654,7 @@ class HipOps : public Ops {
         // cfg5, 625 tiles, 73 us — is a round and a quarter at 2 waves per SIMD; handing it to the
         // register-lean persistent form with 3 waves, k_scan_suffix_lean<2,4,0,3>, was measured:
         // 40 HOOI sweeps 0.0446 / 0.0443 s against 0.0442 / 0.0441 s. Not kept.)
-        if (al && variant_ >= 2 && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
+        if (al && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
             !(sizeof(TV) == 8 && nsplit > 1)) {
           if (NT == 1) {
             LAUNCH_SUFFIX_BUF(1)
@@ -683,7 +665,7 @@ class HipOps : public Ops {
           } else {
             LAUNCH_SUFFIX_BUF(4)
           }
-        } else if (al && variant_ >= 1 && M >= VEC) {
+        } else if (al && M >= VEC) {
           if (NT == 1) {
             LAUNCH_SUFFIX_FAST(1)
           } else if (NT == 2) {
@@ -921,15 +903,10 @@ class HipOps : public Ops {
       nrm.scales = small(MAX_ORDER);
       norm_armed_ = false;
     }
-    if (stage_update_ && lds + stage <= 150 * 1024) {
-      if (update_mfma_)
-        hipLaunchKernelGGL((k_cp_mode_update<true, true>), dim3(1), dim3(1024), lds + stage, st_, Gall, N,
-                           mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
-                           ldd, ratio, S, Sinv, dwsq, presolved, nrm);
-      else
-        hipLaunchKernelGGL((k_cp_mode_update<true, false>), dim3(1), dim3(1024), lds + stage, st_, Gall,
-                           N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
-                           ldd, ratio, S, Sinv, dwsq, presolved, nrm);
+    if (lds + stage <= 150 * 1024) {
+      hipLaunchKernelGGL((k_cp_mode_update<true, true>), dim3(1), dim3(1024), lds + stage, st_, Gall, N, mode,
+                         R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio, S,
+                         Sinv, dwsq, presolved, nrm);
     } else {
       hipLaunchKernelGGL((k_cp_mode_update<false, false>), dim3(1), dim3(1024), lds, st_, Gall, N, mode,
                          R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio,
@@ -940,7 +917,7 @@ class HipOps : public Ops {
   bool arm_normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall, int mode,
                      double *wsq) override {
     norm_armed_ = false;
-    if (!update_fuse_norm_ || R > 64 || force_jacobi_ || !stage_update_ || N > MAX_ORDER) return false;
+    if (R > 64 || force_jacobi_ || N > MAX_ORDER) return false;
     int64_t tot = 0;
     for (int i = 0; i < N; i++) tot += rows[i] * R;
     const size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
@@ -963,7 +940,7 @@ class HipOps : public Ops {
                        double *Sinv) override {
     sys_ready_ = false;
     sys_armed_ = false;
-    if (!update_presolve_ || force_jacobi_ || R > 32 || !S || !Sinv) return;
+    if (force_jacobi_ || R > 32 || !S || !Sinv) return;
     sys_.Gall = Gall;
     sys_.N = N;
     sys_.mode = mode;
@@ -1108,7 +1085,7 @@ class HipOps : public Ops {
   void unfold_gram(const void *X, int dt, int64_t L, int64_t J, int64_t T, double *G) override {
     RoctxRange roctx_("K12/K13 unfold gram");
     const int64_t C = L * T;
-    if (gram_mfma_ && dt == F64 && J >= 64 && J <= 8192 && C >= 16 && C <= 4096 &&
+    if (dt == F64 && J >= 64 && J <= 8192 && C >= 16 && C <= 4096 &&
         (double)J * (double)C * 8.0 <= 64e6) {
       // the Gram of a HOOI leaf (a few hundred rows and columns): the latency-bound symmetric
       // product of the eigen-step (one 16 x 16 tile per workgroup, 8 waves split the columns) on
@@ -1125,7 +1102,7 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       return;
     }
-    if (gram_mfma_ && gram_syrk_ && dt == F32 && J >= 64 && C >= 4096 &&
+    if (dt == F32 && J >= 64 && C >= 4096 &&
         ((L == 1 && J % 4 == 0) || (L > 1 && L % 4 == 0))) {
       // K13 at size (the HOSVD Grams of the full tensor): the tiled SYRK, upper triangle only
       const int nt = (int)((J + 63) / 64);
@@ -1161,7 +1138,7 @@ class HipOps : public Ops {
     if (nsplit > 1) dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * J * J);
     dim3 grid(tiles, tiles, nsplit);
     prof_begin(1, (double)C * J * dtype_size(dt));
-    if (gram_mfma_ && J >= 16) {  // matrix cores (K13); tiny modes: the VALU tile kernel
+    if (J >= 16) {  // matrix cores (K13); tiny modes: the VALU tile kernel
       if (dt == F32)
         hipLaunchKernelGGL(k_unfold_gram_mfma<float>, grid, dim3(256), 0, st_, (const float *)X, L, J,
                            T, per, dst);
@@ -1471,7 +1448,7 @@ class HipOps : public Ops {
     es.rot_pending = false;  // (whatever rotation was owed belonged to the factor this call replaces)
     if (es.valid && (es.J != J || es.rank != rank)) es.valid = false;
     if (es.valid && projector_step(es, G, J, rank, U, slot, false)) return;
-    if (es.valid && eig_fused_) {  // the spectral bound may have been outrun: once more on the measured norm
+    if (es.valid) {  // the spectral bound may have been outrun: once more on the measured norm
       eig_frob_once_ = true;
       const bool ok = projector_step(es, G, J, rank, U, slot, false);
       eig_frob_once_ = false;
@@ -1488,7 +1465,7 @@ class HipOps : public Ops {
       if (cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true)) return;
       // a flat spectrum around the cut (the Gram of a noise tensor: the HOSVD initialisation), where
       // Ritz values cannot place the shift: place it by COUNTING eigenvalues with the sign iteration
-      if (eig_fused_ && cold_ok_ && cold_bisect(es, G, J, rank, U, slot)) return;
+      if (cold_ok_ && cold_bisect(es, G, J, rank, U, slot)) return;
     }
     es.valid = false;
     if (eig_debug_)
@@ -1538,7 +1515,7 @@ class HipOps : public Ops {
   void eig_lazy(int slot, bool on) override {
     if (slot < 0) return;
     EigState &es = eig_state_[slot];
-    es.lazy = on && eig_lazy_ok_ && eig_fused_;
+    es.lazy = on;
     if (es.lazy) lazy_prepare(es);
   }
   void eig_defer(int slot, bool on) override {
@@ -1870,7 +1847,7 @@ class HipOps : public Ops {
     // cold start (the first HOOI sweeps move the spectrum by factors); beyond it the iteration still
     // converges up to sqrt(3) x, after which an eigenvalue is folded to the wrong side, the count
     // comes out short and the step is repeated on the measured Frobenius norm (top_eigvecs_warm).
-    const bool fused_scale = eig_fused_ && !strict && m <= 1 && eig_sigma_scale_ <= 0 && !eig_frob_once_;
+    const bool fused_scale = !strict && m <= 1 && eig_sigma_scale_ <= 0 && !eig_frob_once_;
     const double *pow_y = nullptr, *pow_p = nullptr;
     int pow_n = 0;
     if (m == 1) {
@@ -1954,7 +1931,7 @@ class HipOps : public Ops {
     const unsigned ntri = sym_tiles(Ji);
     // fused tail: the check sums ride on the LAST step's two products (per-tile partial sums of
     // ||X_prev^2 - I||_F^2 and of trace(X_new), added up by the tail's last kernel)
-    const bool fused_tail = eig_fused_ && m <= 1 && rank + kWide <= 64;
+    const bool fused_tail = m <= 1 && rank + kWide <= 64;
     double *pe2 = (double *)ensure(ws_part2_, ws_part2_sz_, sizeof(double) * (2 * (size_t)ntri + 2 * 256 + 2));
     double *ptr_ = pe2 + ntri;
     auto ns_step = [&](double mu, bool last = false) {
@@ -2156,7 +2133,7 @@ class HipOps : public Ops {
     double *cur = Z, *oth = Z2;
     for (int it = 0; it < 4; it++) {
       gemm_nn(G, J, cur, J, nullptr, 0, oth, J, Ji, b, Ji, 1.0, 0.0);  // G * block
-      if (eig_fused_ && b <= 64) {
+      if (b <= 64) {
         // Cholesky QR twice: Gram (one wave per entry) | M = R^-1 by one workgroup | thin product
         double *src = oth, *dst = cur;
         for (int pass = 0; pass < 2; pass++) {
@@ -2540,18 +2517,15 @@ class HipOps : public Ops {
   }
   double *small(int n) { return (double *)ensure(ws_small_, ws_small_sz_, sizeof(double) * n); }
 
-  int dev_ = 0, ncu_ = 256, variant_ = 2, force_jacobi_ = 0, persist_mult_ = 40, stage_update_ = 1;
+  int dev_ = 0, ncu_ = 256, force_jacobi_ = 0, persist_mult_ = 40;
   int eig_debug_ = 0;
   SysArgs sys_;             // arm_gram_system: the system the next contraction prepares on the side
   int sys_R_ = 0;
   bool sys_armed_ = false, sys_ready_ = false;
-  int update_mfma_ = 1;     // PPALS_UPDATE_MFMA=0: the row products of the fused update as VALU loops
-  int update_presolve_ = 1; // PPALS_UPDATE_PRESOLVE=0: S / S^-1 always inside the update launch
   NormArgs norm_;           // arm_normalize: folded into the next cp_mode_update
   int norm_mode_ = -1;
   const double *norm_G_ = nullptr;
   bool norm_armed_ = false;
-  int update_fuse_norm_ = 1;  // PPALS_UPDATE_FUSE_NORM=0: Normalize always a launch of its own
   bool eig_frob_once_ = false;
   void *ws_jac_ = nullptr;  // rotation product of the one-sided Jacobi (r x r)
   size_t ws_jac_sz_ = 0;
@@ -2559,15 +2533,11 @@ class HipOps : public Ops {
   int eig_defer_ok_ = 1;    // PPALS_EIG_DEFER=0: every projector step waits for its own checks
   int eig_defer_fail_ = 0;  // PPALS_EIG_DEFER_FAIL=n (tests): every n-th deferred check is reported as failed
   int eig_defer_count_ = 0;
-  int eig_fused_ = 1;  // PPALS_EIG_FUSED=0: the multi-launch tail and the Frobenius scale (A/B, tests)
   int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
   void *ws_cold_ = nullptr;
   size_t ws_cold_sz_ = 0;
   double eig_sigma_scale_ = 0;  // PPALS_EIG_SIGMA_SCALE=f: shift = f * (estimate of the next eigenvalue) (tests)
-  int gram_mfma_ = 1;     // PPALS_GRAM_MFMA=0: the fp64 VALU Gram kernel (A/B, tests)
-  int gram_syrk_ = 1;     // PPALS_GRAM_SYRK=0: the 32 x 32-tile Gram kernel of round 2 (A/B)
   int force_eiginv_ = 0;  // PPALS_FORCE_EIGINV=1: R > 64 always inverts S through dsyevd (tests)
-  int rank_mfma_ = 1;  // PPALS_RANK_MFMA=0: the fp64 VALU stream kernels (A/B, tests)
   int eig_fast_ = 1;  // PPALS_EIG_FAST=0: always the full eigensolver (A/B, tests)
   std::map<int, EigState> eig_state_;  // by slot
   int eig_next_base_ = 0;
@@ -2576,7 +2546,6 @@ class HipOps : public Ops {
   size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;
   hipStream_t st_ = nullptr;
   hipStream_t st2_ = nullptr;  // the Jacobi of a lazy eigen-step (created on first use)
-  int eig_lazy_ok_ = 1;        // PPALS_EIG_LAZY=0: eigenvectors always inside the step (A/B, tests)
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;
   size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0,

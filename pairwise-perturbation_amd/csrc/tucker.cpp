@@ -52,7 +52,6 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
   ops_.zero(core_prev_, sizeof(double) * ncore_);
   G_ = (double *)ops_.alloc(sizeof(double) * maxs * maxs);
   if (const char *e = std::getenv("PPALS_TUCKER_THIN")) thin_enabled_ = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PPALS_TUCKER_DEFER")) defer_enabled_ = std::atoi(e) != 0;
   scal_ = (double *)ops_.alloc(sizeof(double) * 64);
   yend_elems_ = ncore_ / r_[N_ - 1] * V_.glens[N_ - 1];
   Yend_ = (double *)ops_.alloc(sizeof(double) * yend_elems_);
@@ -622,12 +621,6 @@ void TuckerEngine::rollback_and_redo() {
   const std::vector<int> steps = defer_log_;
   defer_log_.clear();
   defer_rollbacks_++;
-  if (std::getenv("PPALS_TUCKER_DEFER_DEBUG")) {
-    fprintf(stderr, "[ppals tucker] eigen-step of mode %d not accepted: repeating %d step(s):", steps[0],
-            (int)steps.size());
-    for (int j : steps) fprintf(stderr, " %d", j);
-    fprintf(stderr, "\n");
-  }
   ops_.sync();
   for (size_t k = 0; k < steps.size(); k++) {
     const int j = steps[k];

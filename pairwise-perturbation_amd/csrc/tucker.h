@@ -101,7 +101,7 @@ class TuckerEngine {
   // stepped since goes back to what it was and those steps are repeated, checked one by one.
   std::vector<int> defer_log_;
   std::vector<double *> Wsave_;
-  bool defer_enabled_ = true;  // PPALS_TUCKER_DEFER=0: off
+  bool defer_enabled_ = true;  // (the back end decides per slot: PPALS_EIG_DEFER=0 switches every deferral off)
   int defer_rollbacks_ = 0;
   void settle_mode(int i);  // before mode i is stepped again
   void settle_all();        // before anything derived from the factors is read

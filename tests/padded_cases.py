@@ -14,7 +14,6 @@ import test_gpu_cp as G
 @pytest.fixture(autouse=True)
 def force_padding(monkeypatch):
     monkeypatch.setenv("PPALS_PAD_LAYOUT", "1")
-    monkeypatch.setenv("PPALS_PAD_WASTE", "100")
 
 
 test_tree_nodes_and_mttkrp = G.test_tree_nodes_and_mttkrp

@@ -110,14 +110,10 @@ def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
         return out
 
     plain = run({"PPALS_PLACE_TUNE": "0"})
-    tuned = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_SPACER_MB": "1", "PPALS_PLACE_BLOCKS": "3",
-                 "PPALS_PLACE_LAYOUTS": "3"})
-    one = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_BLOCKS": "1", "PPALS_PLACE_LAYOUTS": "1",
-               "PPALS_PLACE_COMMON": "1"})
-    mixed = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_SPACER_MB": "1", "PPALS_PLACE_BLOCKS": "4",
-                 "PPALS_PLACE_LAYOUTS": "2", "PPALS_PLACE_PREFER_BLOCK": "2"})   # odd roots elsewhere
-    for a, b, c_, d in zip(plain, tuned, one, mixed):
-        assert (a == b).all() and (a == c_).all() and (a == d).all()
+    tuned = run({"PPALS_PLACE_MIN_MB": "0"})
+    mixed = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_PREFER_BLOCK": "2"})   # odd roots elsewhere
+    for a, b, d in zip(plain, tuned, mixed):
+        assert (a == b).all() and (a == d).all()
 
 
 @pytest.mark.parametrize("lens,ranks", [([12, 10, 9], [3, 4, 2]), ([9, 8, 7, 6], [3, 2, 3, 2])])

@@ -53,7 +53,6 @@ def _setenv(monkeypatch, c):
     if c["roots"] > 0 and c["roots"] <= len(c["lens"]) - 2:
         monkeypatch.setenv("PPALS_MSDT_ROOTS", str(c["roots"]))
     monkeypatch.setenv("PPALS_PAD_LAYOUT", str(c["pad"]))
-    monkeypatch.setenv("PPALS_PAD_WASTE", "100")
 
 
 @pytest.mark.parametrize("c", _cases(NCASES, SEED), ids=lambda c: "-".join(map(str, c["lens"])) + f"-R{c['R']}")

@@ -179,6 +179,39 @@ def _decaying_tensor(lens, inner, seed, noise):
     return np.asfortranarray(V + noise * np.linalg.norm(V) / np.linalg.norm(E) * E)
 
 
+@pytest.mark.parametrize("env", [{"PPALS_SYM_LDS_MIN": "64"}, {"PPALS_ROCTX": "1"}])
+def test_projector_route_under_switches(pp, env, tmp_path, monkeypatch):
+    """PPALS_SYM_LDS_MIN=64: every symmetric product of the sign iteration (and the leaf Grams) on the
+    LDS-tiled kernel that production uses from 768 rows on (k_dgemm_nt_sym_lds<32>: ragged 32 x 32
+    tiles at 96 / 80 / 72 rows, the check sums per workgroup); PPALS_ROCTX=1: the named ranges around
+    the kernels switched on. Same iterates as the oracle either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
+    lens, ranks = [96, 80, 72], [5, 6, 4]
+    V = _decaying_tensor(lens, [10, 9, 8], 5, 0.05)
+    W0, c0 = O.hosvd(V, ranks)
+    _, it_ref, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=6, resprint=10 ** 9)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    W_h, _ = s.get_factors()
+    for a, b in zip(W_h, W0):
+        assert relerr(proj(a), proj(b)) < 1e-8
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.sweeps_dt(7)
+    W, core = s.get_factors()
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+        assert relerr(proj(a), proj(b)) < 1e-7, (env, relerr(proj(a), proj(b)))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
+    c2.close()
+
+
 def _slow_decay_tensor(lens, inner, decay, seed, noise):
     """multilinear rank `inner`, singular values of mode m falling like decay[m]**k, plus relative noise"""
     rng = np.random.default_rng(seed)
@@ -524,27 +557,20 @@ def test_hosvd_gram_syrk_f32(pp, lens, ranks, monkeypatch):
     """K13 for fp32 tensor storage at a size where the tiled SYRK runs (k_unfold_syrk_f32: upper
     triangle of 64 x 64 tiles, ragged edges, both unfolding layouts — mode in front / mode behind —
     and reduction splits): the HOSVD factors as subspaces and ||core|| against the oracle on the
-    SAME fp32-representable values (the products are exact in fp64, so only rounding order differs),
-    and against the round-2 kernel (PPALS_GRAM_SYRK=0). The third shape has no 4-aligned rows and
-    takes the old kernel either way."""
+    SAME fp32-representable values (the products are exact in fp64, so only rounding order differs).
+    The third shape has no 4-aligned rows and takes the 32 x 32-tile kernel."""
     V = _decaying_tensor(lens, [min(s, r + 4) for s, r in zip(lens, ranks)], 7, 0.05)
     V = np.asfortranarray(V.astype(np.float32).astype(np.float64))
     W_ref, core_ref = O.hosvd(V, ranks)
-    got = []
-    for syrk in ("1", "0"):
-        monkeypatch.setenv("PPALS_GRAM_SYRK", syrk)
-        c2 = pp.Context(0)
-        t = pp.Tensor(c2, lens, 0).upload(V)
-        s = pp.Tucker(c2, t, ranks)
-        s.hosvd()
-        W, core = s.get_factors()
-        for a, b, r in zip(W, W_ref, ranks):
-            assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
-            assert relerr(proj(a), proj(b)) < 1e-8, (syrk, relerr(proj(a), proj(b)))
-        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-6 * np.linalg.norm(core_ref)
-        got.append(W)
-        s.close()
-        t.close()
-        c2.close()
-    for a, b in zip(*got):
-        assert relerr(proj(a), proj(b)) < 1e-9
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 0).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    W, core = s.get_factors()
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+        assert relerr(proj(a), proj(b)) < 1e-8, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-6 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
+    c2.close()

@@ -31,7 +31,7 @@ def test_sharded_engine_matches_oracle(world, padded):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         if padded:
-            env.update(PPALS_PAD_LAYOUT="1", PPALS_PAD_WASTE="100")
+            env.update(PPALS_PAD_LAYOUT="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "hostsim_rank.py")],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))

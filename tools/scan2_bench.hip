@@ -16,6 +16,7 @@
 
 #include "../pairwise-perturbation_amd/csrc/ops.h"
 #include "../pairwise-perturbation_amd/csrc/kernels_scan.hip.h"
+#include "scan_lean_kernels.hip.h"
 
 using namespace ppals;
 #define CK(x)                                                                   \
