@@ -1243,6 +1243,11 @@ class HipOps : public Ops {
   // profiles/r04d_nsprod_*.txt: 640 rows 18.6 vs 21.3 us, 896 rows 35.6 vs 30.8, 1344 rows 88.6 vs
   // 68.1) it is 2 J^3 flops — 32 x 32 tiles staged through LDS. sym_tiles() = workgroups = check-sum
   // partials per product.
+  // (the GEMM kernels address their operands with 32-bit element offsets)
+  static void gemm_offsets_fit(int64_t lda, int64_t ca, int64_t ldb, int64_t cb) {
+    if ((double)lda * (double)ca >= 4.0e9 || (double)ldb * (double)cb >= 4.0e9)
+      throw std::runtime_error("ppals: dense operand of the eigen-step beyond 2^32 elements");
+  }
   unsigned sym_tiles(int M) const {
     const unsigned nt = (unsigned)((M + (M >= sym_lds_min_ ? 31 : 15)) / (M >= sym_lds_min_ ? 32 : 16));
     return nt * (nt + 1) / 2;
@@ -1250,6 +1255,7 @@ class HipOps : public Ops {
   void sym_product(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D, int64_t ldd,
                    double *C, int64_t ldc, int M, int K, double alpha, double beta, int chk_mode = 0,
                    double *chk_part = nullptr) {
+    gemm_offsets_fit(lda, K, ldb, K);
     if (M >= sym_lds_min_)
       hipLaunchKernelGGL(k_dgemm_nt_sym_lds<32>, dim3(sym_tiles(M)), dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C,
                          ldc, M, K, alpha, beta, chk_mode, chk_part);
@@ -1259,6 +1265,7 @@ class HipOps : public Ops {
   }
   void gemm_nt(const double *A, int64_t lda, const double *Bt, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
+    gemm_offsets_fit(lda, K, ldb, K);
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(k_dgemm_nx<false>, grid, dim3(256), 0, st_, A, lda, Bt, ldb, D, ldd, C, ldc, M,
                        N, K, alpha, beta);
@@ -1274,6 +1281,7 @@ class HipOps : public Ops {
   // the same with the second operand as it is (K x N, column-major): thin tails, no transposition
   void gemm_nn(const double *A, int64_t lda, const double *B, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
+    gemm_offsets_fit(lda, K, ldb, N);
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(k_dgemm_nx<true>, grid, dim3(256), 0, st_, A, lda, B, ldb, D, ldd, C, ldc, M, N,
                        K, alpha, beta);

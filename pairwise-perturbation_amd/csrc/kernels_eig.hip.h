@@ -51,9 +51,12 @@ __global__ __launch_bounds__(256) void k_dgemm_nx(const double *__restrict__ A, 
   const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
   // clamped operand rows: lanes past the edge re-read the last row, their results are not stored
   const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, N - 1);
-  const double *__restrict__ ap = A + ia;
-  const double *__restrict__ bp = BN ? Bt + (int64_t)ldb * jb : Bt + jb;
-  const int64_t bstep = BN ? 1 : ldb;
+  // 32-bit element offsets from the (uniform) matrix bases: one v_mad per load instead of a 64-bit
+  // multiply-add chain — the address arithmetic of 26 loads per lane was ~1 us of a 8 us launch
+  // (tools/nsprod_bench.hip, round 4). The matrices here are far below 2^32 bytes.
+  const unsigned la = (unsigned)lda, lb = (unsigned)ldb;
+  const unsigned a0 = (unsigned)ia, b0 = BN ? lb * (unsigned)jb : (unsigned)jb;
+  const unsigned bstep = BN ? 1u : lb;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   const int ksteps = (K + 3) / 4;
   const int spw = (ksteps + 3) / 4;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void k_dgemm_nx(const double *__restrict__ A, 
       const int k = (s0 + u) * 4 + g;
       const bool ok = (s0 + u) < s_end && k < K;  // beyond the range: multiply by zero
       const int kc = ok ? k : 0;
-      const double a = ap[(int64_t)lda * kc], b = bp[bstep * kc];
+      const double a = A[a0 + la * (unsigned)kc], b = Bt[b0 + bstep * (unsigned)kc];
       av[u] = ok ? a : 0.0;
       bv[u] = ok ? b : 0.0;
     }
@@ -124,8 +127,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
   const int tj = ti + rem;
   const int i0 = ti * 16, j0 = tj * 16;
   const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, M - 1);
-  const double *__restrict__ ap = A + ia;
-  const double *__restrict__ bp = Bt + jb;
+  const unsigned la = (unsigned)lda, lb = (unsigned)ldb;  // (32-bit offsets: see k_dgemm_nx)
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   const int ksteps = (K + 3) / 4;
   const int spw = (ksteps + NW - 1) / NW;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgemm_nt_sym(const double *__restri
       const int k = (s0 + u) * 4 + g;
       const bool ok = (s0 + u) < s_end && k < K;
       const int kc = ok ? k : 0;
-      const double a = ap[(int64_t)lda * kc], b = bp[(int64_t)ldb * kc];
+      const double a = A[(unsigned)ia + la * (unsigned)kc], b = Bt[(unsigned)jb + lb * (unsigned)kc];
       av[u] = ok ? a : 0.0;
       bv[u] = ok ? b : 0.0;
     }

@@ -275,6 +275,48 @@ def test_core_rank_above_64_stays_on_the_projector_route(pp, lens, ranks, inner,
     c2.close()
 
 
+def test_core_rank_above_64_on_a_flat_spectrum(pp, tmp_path, monkeypatch, capfd):
+    """A noise tensor (`-tensor r2`: U(0.5, 1), test_ALS.cxx:272) at core rank 70: below the mean
+    component the Gram's spectrum is a flat bulk, Ritz values cannot place a shift, and the cold start
+    must COUNT eigenvalues with the sign iteration (cold_bisect) and finish with a tail of up to 86
+    columns by plain launches (block Gram-Schmidt + the one-sided Jacobi). hosvd + 3 sweeps against
+    numpy's reading — projectors to what the tiny gaps allow, ||core|| and the fit tightly — and a
+    step log without the vendor solver."""
+    import numpy_ref as NR
+    lens, ranks = [1000, 36, 28], [70, 20, 16]   # (eigenvalues 70 and 75 of the mode-0 Gram: 1.5 % apart)
+    V = O.fill_uniform(int(np.prod(lens)), 13, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W0, c0 = NR.tucker_hosvd(V, ranks)
+    W_ref, core_ref = NR.tucker_hooi(V, W0, 3)
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    capfd.readouterr()
+    s.hosvd()
+    W_h, core_h = s.get_factors()
+    Vn = np.linalg.norm(V)
+    # (the 70th and 71st eigenvalue of a flat bulk lie 1e-3 apart relative to the bulk: the SUBSPACE is
+    # defined to eps * lambda_1 / gap only; the captured energy is defined sharply)
+    assert abs(np.linalg.norm(core_h) - np.linalg.norm(c0)) < 1e-9 * Vn
+    for a, r in zip(W_h, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.sweeps_dt(3)
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * Vn
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-5, relerr(proj(a), proj(b))
+    log = [ln for ln in err.splitlines() if "[ppals eig]" in ln]
+    assert any("by counting" in ln and "accepted" in ln for ln in log), "\n".join(log[-40:])
+    assert not any("dsyevd" in ln for ln in log), "\n".join(log)
+    s.close()
+    t.close()
+    c2.close()
+
+
 def test_thin_route_with_more_than_64_columns_needs_no_vendor_solver(pp, tmp_path, monkeypatch, capfd):
     """A tall unfolding whose small side has 64 < c <= 128 columns (rank 70 of 90): the c x c
     eigen-problem is solved whole by the one-workgroup one-sided Jacobi (k_jacobi_onesided), not by

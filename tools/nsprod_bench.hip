@@ -49,6 +49,112 @@ static void chain(const char *name, double *X, double *Y, int J, int n) {
   printf("%-34s J=%d: %.2f us per product (chain of %d, median of 7)\n", name, J, ts[3], n);
 }
 
+// ---- where does a product's time go, and does it matter which XCD computes which tile? A copy of
+// k_dgemm_nt_sym<8> with (a) the tile of a workgroup taken from a table (XCD-aware orders: workgroups
+// b and b + 8 share an XCD, so a table can give every XCD a compact patch of the tile triangle and
+// with it fewer operand row-blocks to pull into its L2 after the kernel boundary emptied it) and
+// (b) optional phase stamps (s_memrealtime, 10 ns) by lane 0 of wave 0: start | operands in
+// registers | MFMAs done | partial tiles combined | stores issued.
+template <int NW, bool STAMP>
+__global__ __launch_bounds__(64 * NW) void k_sym_probe(const double *__restrict__ A, const double *__restrict__ Bt,
+                                                       double *__restrict__ C, int M, double alpha,
+                                                       const ushort2 *__restrict__ tile_map,
+                                                       unsigned long long *__restrict__ stamps) {
+  constexpr int UN = 13;
+  __shared__ double part[NW - 1][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if (STAMP && threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+  const ushort2 tt = tile_map[blockIdx.x];
+  const int i0 = tt.x * 16, j0 = tt.y * 16;
+  const int ia = min(i0 + l16, M - 1), jb = min(j0 + l16, M - 1);
+  const double *__restrict__ ap = A + ia;
+  const double *__restrict__ bp = Bt + jb;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (M + 3) / 4;
+  const int spw = (ksteps + NW - 1) / NW;
+  const int s_begin = wave * spw, s_end = min(ksteps, s_begin + spw);
+  for (int s0 = s_begin; s0 < s_end; s0 += UN) {
+    double av[UN], bv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int k = (s0 + u) * 4 + g;
+      const bool ok = (s0 + u) < s_end && k < M;
+      const int kc = ok ? k : 0;
+      const double a = ap[(int64_t)M * kc], b = bp[(int64_t)M * kc];
+      av[u] = ok ? a : 0.0;
+      bv[u] = ok ? b : 0.0;
+    }
+    if (STAMP) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) t1 = __builtin_amdgcn_s_memrealtime();
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  if (STAMP && threadIdx.x == 0) {
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    t2 = __builtin_amdgcn_s_memrealtime();
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (STAMP && threadIdx.x == 0) t3 = __builtin_amdgcn_s_memrealtime();
+  if (wave > 0) return;
+  const int j = j0 + l16;
+  if (j < M) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = i0 + g + 4 * r;
+      if (i < M && i <= j) {
+        double v = acc[r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) v += part[w][r][lane];
+        v *= alpha;
+        C[i + (int64_t)M * j] = v;
+        if (i != j) C[j + (int64_t)M * i] = v;
+      }
+    }
+  }
+  if (STAMP && threadIdx.x == 0) {
+    unsigned long long *st = stamps + 8 * (size_t)blockIdx.x;
+    st[0] = t0;
+    st[1] = t1;
+    st[2] = t2;
+    st[3] = t3;
+    st[4] = __builtin_amdgcn_s_memrealtime();
+    st[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7;
+  }
+}
+static unsigned morton2(unsigned x, unsigned y) {
+  unsigned r = 0;
+  for (int b = 0; b < 8; b++) r |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+  return r;
+}
+// tile tables: 0 = row-major upper triangle (what the product does), 1 = Morton order cut into 8
+// consecutive patches, patch = blockIdx % 8, 2 = block rows dealt to XCDs (tile rows ti % 8 == xcd)
+static std::vector<ushort2> tile_table(int J, int kind) {
+  const int nt = (J + 15) / 16;
+  std::vector<ushort2> all;
+  for (int ti = 0; ti < nt; ti++)
+    for (int tj = ti; tj < nt; tj++) all.push_back(ushort2{(unsigned short)ti, (unsigned short)tj});
+  if (kind == 0) return all;
+  std::vector<ushort2> ord = all;
+  if (kind == 1)
+    std::sort(ord.begin(), ord.end(), [](ushort2 a, ushort2 b) { return morton2(a.x, a.y) < morton2(b.x, b.y); });
+  else
+    std::stable_sort(ord.begin(), ord.end(), [](ushort2 a, ushort2 b) { return (a.x % 8) < (b.x % 8); });
+  const int n = (int)ord.size();
+  std::vector<int> start(9, 0);
+  for (int c = 0; c < 8; c++) start[c + 1] = start[c] + n / 8 + (c < n % 8 ? 1 : 0);
+  std::vector<ushort2> out(n);
+  for (int b = 0; b < n; b++) out[b] = ord[start[b % 8] + b / 8];
+  return out;
+}
+
 // ---- the same chain of products as ONE persistent launch (review of round 3: "measure it"): one
 // 16 x 16 tile per workgroup exactly as k_dgemm_nt_sym<8>, the iterate ping-pongs between X and Y,
 // and between two products every workgroup passes a grid barrier. Two barrier forms:
@@ -234,6 +340,72 @@ int main(int argc, char **argv) {
   chain<4>("k_dgemm_nt_sym<4>  (256 threads)", X, Y, J, 40);
   chain<8>("k_dgemm_nt_sym<8>  (512 threads)", X, Y, J, 40);
   chain<16>("k_dgemm_nt_sym<16> (1024 threads)", X, Y, J, 40);
+  if (J <= 512) {  // tile -> XCD orders and the phases of one product
+    const unsigned nt = (unsigned)((J + 15) / 16), ntri = nt * (nt + 1) / 2;
+    ushort2 *dmap;
+    unsigned long long *dst;
+    CK(hipMalloc(&dmap, sizeof(ushort2) * ntri));
+    CK(hipMalloc(&dst, sizeof(unsigned long long) * 8 * ntri));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int kind = 0; kind < 3; kind++) {
+      std::vector<ushort2> tab = tile_table(J, kind);
+      CK(hipMemcpy(dmap, tab.data(), sizeof(ushort2) * ntri, hipMemcpyHostToDevice));
+      std::vector<float> tsv;
+      const int n = 40;
+      for (int rep = 0; rep < 7; rep++) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < n; i++) {
+          hipLaunchKernelGGL((k_sym_probe<8, false>), dim3(ntri), dim3(512), 0, 0, X, X, Y, J, 1e-3, dmap, dst);
+          std::swap(X, Y);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tsv.push_back(ms * 1e3f / n);
+      }
+      std::sort(tsv.begin(), tsv.end());
+      // operand row-blocks an XCD needs under this table (blockIdx % 8 = XCD, as observed)
+      double need = 0;
+      for (int c = 0; c < 8; c++) {
+        std::vector<char> seen(nt, 0);
+        for (unsigned b = c; b < ntri; b += 8) seen[tab[b].x] = seen[tab[b].y] = 1;
+        for (char v : seen) need += v;
+      }
+      printf("tile order %-28s J=%d: %.2f us per product; an XCD touches %.1f of %u operand row-blocks\n",
+             kind == 0 ? "row-major (product)" : kind == 1 ? "Morton patches per XCD" : "tile rows dealt to XCDs", J,
+             tsv[3], need / 8, nt);
+    }
+    {  // phases (stamps cost a wait for all loads before the first MFMA: an upper bound of the load phase)
+      std::vector<ushort2> tab = tile_table(J, 0);
+      CK(hipMemcpy(dmap, tab.data(), sizeof(ushort2) * ntri, hipMemcpyHostToDevice));
+      for (int i = 0; i < 6; i++) {  // a chain, so that the stamped launch starts behind a kernel boundary
+        hipLaunchKernelGGL((k_sym_probe<8, true>), dim3(ntri), dim3(512), 0, 0, X, X, Y, J, 1e-3, dmap, dst);
+        std::swap(X, Y);
+      }
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> st(8 * (size_t)ntri);
+      CK(hipMemcpy(st.data(), dst, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+      unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+      double ph[4] = {0, 0, 0, 0};
+      for (unsigned b = 0; b < ntri; b++) {
+        const unsigned long long *q = &st[8 * (size_t)b];
+        tmin = std::min(tmin, q[0]);
+        smax = std::max(smax, q[0]);
+        tmax = std::max(tmax, q[4]);
+        for (int k = 0; k < 4; k++) ph[k] += (double)(q[k + 1] - q[k]) * 0.01 / ntri;
+      }
+      printf("phases of one product (lane 0 of wave 0, mean over %u workgroups, us): operands %.2f | MFMA %.2f | "
+             "combine %.2f | stores %.2f;  first -> last workgroup start %.2f us, first start -> last stamp %.2f us\n",
+             ntri, ph[0], ph[1], ph[2], ph[3], (double)(smax - tmin) * 0.01, (double)(tmax - tmin) * 0.01);
+    }
+    CK(hipMemcpy(X, h.data(), sizeof(double) * J * J, hipMemcpyHostToDevice));
+    CK(hipFree(dmap));
+    CK(hipFree(dst));
+  }
   // the LDS-tiled kernel (large matrices)
   for (int ts : {32, 64}) {
     hipEvent_t e0, e1;
