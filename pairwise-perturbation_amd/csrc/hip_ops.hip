@@ -715,6 +715,34 @@ class HipOps : public Ops {
       scan_t<double>((const double *)V, L, J, T, f, nf, R, (double *)out, out_tstride,
                      out_rstride, out32, pad);
   }
+  // Tucker mode product keeping the mode in place. Small inputs (the second-level products of a
+  // chain: tens of MB with at least a tile of contiguous rows) run as ONE batched thin GEMM on the
+  // fp64 matrix cores instead of the streaming scan's pack + scan + slab-combine launches; everything
+  // else is the scan.
+  void ttm_keep(const void *X, int dt, int64_t L, int64_t J, int64_t T, const double *W, int64_t ldw,
+                int Kc, double *out) override {
+    const double bytes = (double)L * J * T * dtype_size(dt);
+    if (L >= 16 && Kc <= 64 && bytes <= 64e6 && (double)L * J < 2e9 && T <= 65535 && J >= 16 &&
+        (double)ldw * Kc < 4e9) {
+      RoctxRange roctx_("K11 mode product (batched thin GEMM)");
+      const int nt = Kc <= 16 ? 1 : (Kc <= 32 ? 2 : 4);
+      dim3 grid((unsigned)((L + 15) / 16), (unsigned)((Kc + 16 * nt - 1) / (16 * nt)), (unsigned)T);
+      prof_begin(1, bytes);
+#define PPALS_MPS(TA_, NT_)                                                                               \
+  hipLaunchKernelGGL((k_mode_product_small<TA_, NT_>), grid, dim3(512), 0, st_, (const TA_ *)X, (int)L, (int)J, W, \
+                     ldw, Kc, out)
+      if (dt == F32) {
+        if (nt == 1) PPALS_MPS(float, 1); else if (nt == 2) PPALS_MPS(float, 2); else PPALS_MPS(float, 4);
+      } else {
+        if (nt == 1) PPALS_MPS(double, 1); else if (nt == 2) PPALS_MPS(double, 2); else PPALS_MPS(double, 4);
+      }
+#undef PPALS_MPS
+      prof_end();
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    Ops::ttm_keep(X, dt, L, J, T, W, ldw, Kc, out);
+  }
   // padded resident layout, see ops.h: a pitched copy (rows == 1) or a transposition whose
   // destination rows are padded
   void pad_layout(const void *src, int dt, int64_t rows, int64_t cols, int64_t blk, int64_t ld,

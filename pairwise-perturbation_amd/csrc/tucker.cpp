@@ -193,7 +193,12 @@ void TuckerEngine::compute_left_half_on_vt(Node &n) {
     f.ptr = wptr(m);
     f.rows = dims[p];
     f.ld = V_.glens[m];
-    ops_.scan_contract(cur, cur_dt, L, dims[p], T, &f, 1, r_[m], dst, dst_dt, L * r_[m], L);
+    // (the step that reads the tensor is a scan; a later one reads a small intermediate and writes
+    // fp64: the back end may run it as one batched GEMM, Ops::ttm_keep)
+    if (cur != VT_ && dst_dt == F64)
+      ops_.ttm_keep(cur, cur_dt, L, dims[p], T, f.ptr, f.ld, r_[m], (double *)dst);
+    else
+      ops_.scan_contract(cur, cur_dt, L, dims[p], T, &f, 1, r_[m], dst, dst_dt, L * r_[m], L);
     cur = dst;
     cur_dt = dst_dt;
     dims[p] = r_[m];
@@ -301,7 +306,10 @@ void TuckerEngine::compute_node(int idx) {
     f.rows = dims[m];
     f.ld = V_.glens[m];
     // out[l + Lout*(k + r*t)]: the mode product that keeps the mode in place (als_Tucker.cxx:224)
-    ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, dst_dt, Lout * r_[m], Lout);
+    if (cur != V_.data && dst_dt == F64 && Lout == L)
+      ops_.ttm_keep(cur, cur_dt, L, dims[m], T, f.ptr, f.ld, r_[m], (double *)dst);
+    else
+      ops_.scan_contract(cur, cur_dt, L, dims[m], T, &f, 1, r_[m], dst, dst_dt, Lout * r_[m], Lout);
     cur = dst;
     cur_dt = dst_dt;
     dims[m] = r_[m];

@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B=pairwise-perturbation_amd/bin
+CFG5="-model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -pp 0 -maxiter 40 -prec 32"
+tools/gpu_steps.sh \
+ "r04r_tucker|600|python -m pytest tests/test_gpu_tucker.py tests/test_gpu_fullsize.py -x -q -k 'tucker or Tucker or cfg5 or rank or flat or eigen or projector or hosvd or order6'" \
+ "r04r_cfg5|100|$B/test_ALS $CFG5 -filename gpurun_out/r04r_cfg5.csv && $B/test_ALS $CFG5 -filename gpurun_out/r04r_cfg5_2.csv" \
+ "r04r_trace_cfg5|300|rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04r_trace_cfg5 -o r04r -- $B/test_ALS $CFG5 -filename gpurun_out/r04r_cfg5_prof.csv"
