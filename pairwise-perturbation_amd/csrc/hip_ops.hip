@@ -97,6 +97,8 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_SYM_LDS_MIN")) sym_lds_min_ = std::max(32, atoi(v));
     if (const char *v = getenv("PPALS_EIG_DEFER")) eig_defer_ok_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_h,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_jacobi_onesided,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_small,
@@ -1258,6 +1260,7 @@ class HipOps : public Ops {
     double *chk_pinned = nullptr;
     hipEvent_t ev_chk = nullptr;
     double *GBd = nullptr, *chkd = nullptr;  // G*B (J x rank) and the checks' device block, the slot's own
+    double *Md = nullptr, *C2d = nullptr;    // M and Z'^T G Z' of a deferred step (64 x 64 each)
     size_t GBd_elems = 0;
     struct {
       double sigma = 0, rho = 0, ell0 = 0;
@@ -1308,11 +1311,12 @@ class HipOps : public Ops {
   }
   // the same with the second operand as it is (K x N, column-major): thin tails, no transposition
   void gemm_nn(const double *A, int64_t lda, const double *B, int64_t ldb, const double *D,
-               int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta) {
+               int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta,
+               const double *Qov = nullptr, int mov = 0) {
     gemm_offsets_fit(lda, K, ldb, N);
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(k_dgemm_nx<true>, grid, dim3(256), 0, st_, A, lda, B, ldb, D, ldd, C, ldc, M, N,
-                       K, alpha, beta);
+                       K, alpha, beta, Qov, mov);
   }
   // full solver + what the next call of the slot needs (rank-th and next eigenvalue, the basis)
   void eig_bootstrap(EigState &es, double *G, int64_t J, int rank, double *U) {
@@ -1525,7 +1529,9 @@ class HipOps : public Ops {
     es.ev_chk = nullptr;
     if (es.GBd) hipFree(es.GBd);
     if (es.chkd) hipFree(es.chkd);
-    es.GBd = es.chkd = nullptr;
+    if (es.Md) hipFree(es.Md);
+    if (es.C2d) hipFree(es.C2d);
+    es.GBd = es.chkd = es.Md = es.C2d = nullptr;
     es.GBd_elems = 0;
     if (es.ev_h) hipEventDestroy(es.ev_h);
     if (es.ev_done) hipEventDestroy(es.ev_done);
@@ -1546,6 +1552,8 @@ class HipOps : public Ops {
       HIP_CHECK(hipHostMalloc(&es.chk_pinned, kEigReadback, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&es.ev_chk, hipEventDisableTiming));
       HIP_CHECK(hipMalloc(&es.chkd, kEigReadback));
+      HIP_CHECK(hipMalloc(&es.Md, sizeof(double) * 64 * 64));
+      HIP_CHECK(hipMalloc(&es.C2d, sizeof(double) * 64 * 64));
     }
   }
   void eig_lazy(int slot, bool on) override {
@@ -1716,14 +1724,49 @@ class HipOps : public Ops {
                            int *status, const double *pe2, const double *ptr_, int np, int rounds = 1,
                            double *Uout2 = nullptr, EigState *lazy = nullptr, double *host_chk = nullptr) {
     const int Ji = (int)J;
-    gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
     const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
     const int rows_per = (int)((J + nblk - 1) / nblk);
-    // deferred acceptance (host_chk): the basis goes straight into the caller's buffer, and what the
-    // checks read lives in the slot's own buffers — they are finished on the second stream while
-    // the main stream has long moved on and reuses the workspace
-    const bool deferred = lazy && host_chk && rounds == 1;
-    double *src = Z, *dst = deferred ? Uout : Z2;
+    const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && 3 * cols * cols <= (int)kEE;
+    if (deferred) {
+      // The tail of a DEFERRED step in five launches (kernels_eig.hip.h, k_tn_pair / k_chol_h /
+      // k_rmult_pair): the basis goes straight into the caller's buffer, what the checks read lives
+      // in the slot's own buffers — they are finished on the second stream while the main stream
+      // has long moved on and reuses the workspace.
+      EigState &es = *lazy;
+      lazy_prepare(es);
+      if (es.GBd_elems < (size_t)J * cols) {
+        if (es.GBd) HIP_CHECK(hipFree(es.GBd));
+        HIP_CHECK(hipMalloc(&es.GBd, sizeof(double) * (size_t)J * cols));
+        es.GBd_elems = (size_t)J * cols;
+      }
+      double *C1 = C, *Mw = H;
+      gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5, QD, m);  // Z' = [q_D | P Omega_rest]
+      gemm_nn(G, J, Z, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);           // G Z'
+      // (a Jacobi of this slot that is still in flight — a step that was not accepted — must be through
+      // with the slot's buffers before they are written again)
+      if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
+      hipLaunchKernelGGL(k_tn_pair, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, Z, GZ, J, cols, C1, es.C2d,
+                         pe2, ptr_, np, chk, es.chkd);
+      hipLaunchKernelGGL(k_chol_h, dim3(1), dim3(k_chol_threads(cols)), sizeof(double) * (4 * (size_t)cols * cols + 8),
+                         st_, C1, cols, Mw, es.Md, status, chk, es.chkd);
+      hipLaunchKernelGGL(k_rmult_pair, dim3(grid_for(2 * J * cols, 256)), dim3(256), sizeof(double) * cols * cols, st_,
+                         Z, GZ, J, cols, Mw, Uout, es.GBd);
+      es.jacobi_launched = true;
+      HIP_CHECK(hipEventRecord(es.ev_h, st_));
+      HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
+      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
+                         sizeof(double) * (3 * (size_t)cols * cols + 17 + 128), st2_, Uout, es.GBd, J, cols,
+                         (const double *)nullptr, rows_per, (const double *)nullptr, (const double *)nullptr, -1,
+                         (double *)nullptr, Uout2, es.chkd, es.chkd + kEigOffResp, host_chk, es.Md, es.C2d, es.Hd);
+      HIP_CHECK(hipEventRecord(es.ev_chk, st2_));
+      const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
+      hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
+                         es.Hd, cols, es.Yd, es.evd, es.ev_pinned);
+      HIP_CHECK(hipEventRecord(es.ev_done, st2_));
+      return;
+    }
+    gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5);
+    double *src = Z, *dst = Z2;
     for (int rd = 0; rd < rounds; rd++) {
       const int mm = rd == 0 ? m : 0;  // (the deflated columns are in place after the first round)
       hipLaunchKernelGGL(k_tn_two, dim3((cols * cols + mm * cols + 15) / 16), dim3(1024), 0, st_, src, QD,
@@ -1736,17 +1779,8 @@ class HipOps : public Ops {
       gemm_nn(src, J, H, cols, nullptr, 0, dst, J, Ji, cols, cols, 1.0, 0.0);
       std::swap(src, dst);
     }
-    double *B = src;  // (rounds == 1: Z2 / the caller's buffer, rounds == 2: Z)
+    double *B = src;  // (rounds == 1: Z2, rounds == 2: Z)
     double *GB = GZ;
-    if (deferred) {
-      EigState &es = *lazy;
-      if (es.GBd_elems < (size_t)J * cols) {
-        if (es.GBd) HIP_CHECK(hipFree(es.GBd));
-        HIP_CHECK(hipMalloc(&es.GBd, sizeof(double) * (size_t)J * cols));
-        es.GBd_elems = (size_t)J * cols;
-      }
-      GB = es.GBd;
-    }
     gemm_nn(G, J, B, J, nullptr, 0, GB, J, Ji, cols, Ji, 1.0, 0.0);
     double *Hd2 = nullptr;
     if (lazy) {
@@ -1758,24 +1792,6 @@ class HipOps : public Ops {
       lazy_prepare(es);
       if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
       Hd2 = es.Hd;
-    }
-    if (deferred) {
-      EigState &es = *lazy;
-      hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, B, GB, J, cols, H,
-                         Hd2, pe2, ptr_, np, chk, es.chkd);
-      es.jacobi_launched = true;
-      HIP_CHECK(hipEventRecord(es.ev_h, st_));
-      HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
-      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
-                         sizeof(double) * ((size_t)cols * cols + 17 + 128), st2_, B, GB, J, cols, es.Hd, rows_per,
-                         (const double *)nullptr, (const double *)nullptr, -1, (double *)nullptr, Uout2,
-                         es.chkd, es.chkd + kEigOffResp, host_chk);
-      HIP_CHECK(hipEventRecord(es.ev_chk, st2_));
-      const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
-      hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
-                         es.Hd, cols, es.Yd, es.evd, es.ev_pinned);
-      HIP_CHECK(hipEventRecord(es.ev_done, st2_));
-      return;
     }
     hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st_, B, GB, J, cols, H, Hd2);
     double *resp = chk + kEigOffResp;

@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void k_dgemm_nx(const double *__restrict__ A, 
                                                   const double *__restrict__ Bt, int64_t ldb,
                                                   const double *__restrict__ D, int64_t ldd,
                                                   double *__restrict__ C, int64_t ldc, int M, int N,
-                                                  int K, double alpha, double beta) {
+                                                  int K, double alpha, double beta,
+                                                  const double *__restrict__ Qov = nullptr, int mov = 0) {
+  // Qov / mov: the first `mov` result columns are REPLACED by the columns of Qov (M x mov, ld = M) —
+  // the deflated eigenvector takes its place in front of the projected basis without a copy launch
   constexpr int UN = 13;
   __shared__ double part[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256) void k_dgemm_nx(const double *__restrict__ A, 
       if (i < M) {
         double v = alpha * (((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane]);
         if (D) v += beta * D[i + ldd * (int64_t)j];
+        if (j < mov) v = Qov[i + (int64_t)M * j];
         C[i + ldc * (int64_t)j] = v;
       }
     }
@@ -804,34 +808,9 @@ __global__ void k_scale_by_frob(double *__restrict__ X, int64_t n, const double 
 }
 
 // C = A^T B for two tall matrices (rows x r, column-major, ld = rows): one wave per entry (p, q)
-// chk_out != nullptr (deferred acceptance: the checks are finished on the second stream, which must
-// not read the shared workspace): ONE extra workgroup — the last — adds up the sign iteration's
-// per-tile check sums (np each) into chk_out[0], chk_out[1] and copies the step's norm word [8] and
-// status words from the workspace block chk_src into the slot's own block.
 __global__ void k_tn_small(const double *__restrict__ A, const double *__restrict__ B, int64_t rows,
-                           int r, double *__restrict__ C, double *__restrict__ C2 = nullptr,
-                           const double *__restrict__ part_e2 = nullptr,
-                           const double *__restrict__ part_tr = nullptr, int np = 0,
-                           const double *__restrict__ chk_src = nullptr,
-                           double *__restrict__ chk_out = nullptr) {
-  if (chk_out && blockIdx.x == gridDim.x - 1) {
-    __shared__ double red[17];
-    double e2 = 0, tr = 0;
-    for (int i = threadIdx.x; i < np; i += blockDim.x) {
-      e2 += part_e2[i];
-      tr += part_tr[i];
-    }
-    e2 = block_sum(e2, red);
-    tr = block_sum(tr, red);
-    if (threadIdx.x == 0) {
-      chk_out[0] = e2;
-      chk_out[1] = tr;
-      chk_out[8] = chk_src[8];
-    }
-    if (threadIdx.x < 4) chk_out[kEigOffStatus + threadIdx.x] = chk_src[kEigOffStatus + threadIdx.x];
-    return;
-  }
-  const int nblocks = chk_out ? gridDim.x - 1 : gridDim.x;
+                           int r, double *__restrict__ C, double *__restrict__ C2 = nullptr) {
+  const int nblocks = gridDim.x;
   const int lane = threadIdx.x & 63;
   const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nw = (int)(((int64_t)nblocks * blockDim.x) >> 6);
@@ -987,6 +966,170 @@ __global__ void k_tn_two(const double *__restrict__ Z, const double *__restrict_
     for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
     s = wave_sum(s);
     if (lane == 0) C[e] = s;
+  }
+}
+
+// ---- the tail of a deferred step in five launches (round 4): Z' = [q_D | P Omega_rest] | G Z' |
+// k_tn_pair | k_chol_h | k_rmult_pair. With the deflated vector in front of Z', ONE Cholesky QR of
+// all columns keeps it (the first column of a QR is the first column, normalised) and clears the
+// others of it; and H = B^T G B = M^T (Z'^T G Z') M needs no product with B: the 20 x 20 algebra
+// rides in the one-workgroup kernel that makes M, and B, G B are two right-multiplications by M in
+// one launch.
+// k_tn_pair: C1[p + cols q] = z_p^T z_q, C2[p + cols q] = z_p^T (G z)_q — one wave per entry. The last
+// workgroup instead adds up the sign iteration's check sums (np partials each) into chk_out[0],
+// chk_out[1] and carries the step's norm word [8] over into the slot's check block.
+__global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict__ GZ, int64_t rows, int cols,
+                          double *__restrict__ C1, double *__restrict__ C2,
+                          const double *__restrict__ part_e2, const double *__restrict__ part_tr, int np,
+                          const double *__restrict__ chk_src, double *__restrict__ chk_out) {
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x >= 64) return;
+    double e2 = 0, tr = 0;
+    for (int i = lane; i < np; i += 64) {
+      e2 += part_e2[i];
+      tr += part_tr[i];
+    }
+    e2 = wave_sum(e2);
+    tr = wave_sum(tr);
+    if (lane == 0) {
+      chk_out[0] = e2;
+      chk_out[1] = tr;
+      chk_out[8] = chk_src[8];
+    }
+    return;
+  }
+  const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nw = (int)(((int64_t)(gridDim.x - 1) * blockDim.x) >> 6);
+  for (int e = wid; e < cols * cols; e += nw) {
+    const int p = e % cols, q = e / cols;
+    const double *a = Z + rows * p, *b = Z + rows * q, *c = GZ + rows * q;
+    double s1 = 0, s2 = 0;
+    for (int64_t i = lane; i < rows; i += 64) {
+      const double x = a[i];
+      s1 += x * b[i];
+      s2 += x * c[i];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      C1[e] = s1;
+      C2[e] = s2;
+    }
+  }
+}
+// k_chol_h (ONE workgroup): M = R^-1 with C1 = Z'^T Z' = R^T R, so that Z' M is orthonormal -> M and
+// M2 (the slot's copy: the second stream forms H = M^T sym(C2) M from it, k_sub_residual); the step's
+// status words into the slot's check block. The elimination of k_chol_m on ALL columns (two pivots
+// per barrier: ten dependent rounds at n = 20). *status: 1 = a pivot not safely positive, 2 = pivots
+// spread by more than 4, else 0. dynamic LDS: 4 n^2 + 8 doubles.
+// (Measured and not kept, round 4: the inverse square root by its series — Z' = P Omega is close to
+// orthonormal — needs ||I - C1|| <= 1e-3 for three terms; a HOOI sweep of cfg5 turns the subspace by
+// 0.03-0.07 rad, ||I - C1|| = 5e-4 ... 5e-3 with n = 20 columns: the series was taken in 1 step of 130.)
+__global__ __launch_bounds__(1024) void k_chol_h(const double *__restrict__ C1, int n,
+                                                 double *__restrict__ M, double *__restrict__ M2,
+                                                 int *__restrict__ status,
+                                                 const double *__restrict__ chk_src,
+                                                 double *__restrict__ chk_out) {
+  extern __shared__ double lds[];
+  const int w2 = 2 * n;
+  double *E0 = lds, *E1 = E0 + n * w2;  // row-major n x 2n: [C | I] being eliminated
+  double *sc = E1 + n * w2;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int e = tid; e < n * w2; e += nthr) {
+    const int i = e / w2, j = e - i * w2;
+    E0[e] = j < n ? 0.5 * (C1[i + n * j] + C1[j + n * i]) : ((j - n == i) ? 1.0 : 0.0);
+  }
+  lds_barrier();
+  if (tid == 0) {
+    double dmax = 0;
+    for (int k = 0; k < n; k++) dmax = fmax(dmax, E0[k * w2 + k]);
+    sc[0] = dmax;
+    sc[1] = dmax;
+    sc[2] = 0.0;
+  }
+  lds_barrier();
+  double *src = E0, *dst = E1;
+  for (int k = 0; k < n; k += 2) {
+    const double d = src[k * w2 + k];
+    if (!(d > 1e-14 * sc[0])) {  // (uniform)
+      if (tid == 0) sc[2] = 1.0;
+      break;
+    }
+    const double dinv = 1.0 / d;
+    const bool two = k + 1 < n;
+    double d1 = d, d1inv = 0.0, lk1 = 0.0;
+    bool bad1 = false;
+    if (two) {
+      lk1 = src[(k + 1) * w2 + k] * dinv;
+      d1 = src[(k + 1) * w2 + (k + 1)] - lk1 * src[k * w2 + (k + 1)];
+      bad1 = !(d1 > 1e-14 * sc[0]);
+      d1inv = bad1 ? 0.0 : 1.0 / d1;
+    }
+    if (tid == 0) sc[1] = fmin(sc[1], (two && !bad1) ? fmin(d, d1) : d);
+    for (int e = tid; e < n * w2; e += nthr) {
+      const int i = e / w2, j = e - i * w2;
+      double v = src[e];
+      const double akj = src[k * w2 + j];
+      if (i > k) v -= (src[i * w2 + k] * dinv) * akj;
+      if (two && !bad1 && i > k + 1) {
+        const double aik1 = src[i * w2 + (k + 1)] - (src[i * w2 + k] * dinv) * src[k * w2 + (k + 1)];
+        const double ak1j = src[(k + 1) * w2 + j] - lk1 * akj;
+        v -= (aik1 * d1inv) * ak1j;
+      }
+      dst[e] = v;
+    }
+    lds_barrier();
+    double *t0 = src;
+    src = dst;
+    dst = t0;
+    if (two && bad1) {
+      if (tid == 0) sc[2] = 1.0;
+      break;
+    }
+  }
+  lds_barrier();
+  const bool bad = sc[2] != 0.0;
+  const int st = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
+  if (tid == 0) {
+    *status = st;
+    union {
+      int w[2];
+      double d;
+    } u;
+    u.w[0] = st;
+    u.w[1] = status[1];
+    chk_out[kEigOffStatus] = u.d;
+  } else if (tid < 4) {
+    chk_out[kEigOffStatus + tid] = chk_src[kEigOffStatus + tid];
+  }
+  if (bad) return;
+  // src = [D L_1^T | L_1^-1]; M[p][q] = L_1^-1[q][p] / sqrt(d_q) for p <= q (upper triangular)
+  for (int e = tid; e < n * n; e += nthr) {
+    const int p = e % n, q = e / n;
+    const double v = (p <= q) ? src[q * w2 + n + p] / sqrt(src[q * w2 + q]) : 0.0;
+    M[e] = v;
+    M2[e] = v;
+  }
+}
+// k_rmult_pair: B = Z M -> out1, G B = GZ M -> out2 (rows x cols each, M cols x cols upper triangular)
+__global__ __launch_bounds__(256) void k_rmult_pair(const double *__restrict__ Z, const double *__restrict__ GZ,
+                                                    int64_t rows, int cols, const double *__restrict__ M,
+                                                    double *__restrict__ out1, double *__restrict__ out2) {
+  extern __shared__ double sM[];
+  for (int e = threadIdx.x; e < cols * cols; e += blockDim.x) sM[e] = M[e];
+  __syncthreads();
+  const int64_t total = 2 * rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int which = (int)(e / (rows * cols));
+    const int64_t r = e - (int64_t)which * rows * cols;
+    const int64_t i = r % rows;
+    const int c = (int)(r / rows);
+    const double *src = which ? GZ : Z;
+    double a = 0;
+    for (int p = 0; p <= c; p++) a += src[i + rows * p] * sM[p + cols * c];  // (M is upper triangular)
+    (which ? out2 : out1)[i + rows * c] = a;
   }
 }
 
@@ -1204,16 +1347,50 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
                                                       double *__restrict__ U, double *__restrict__ U2,
                                                       double *__restrict__ chk,
                                                       double *__restrict__ resp,
-                                                      double *__restrict__ host = nullptr) {
+                                                      double *__restrict__ host = nullptr,
+                                                      const double *__restrict__ Mq = nullptr,
+                                                      const double *__restrict__ C2 = nullptr,
+                                                      double *__restrict__ Hout = nullptr) {
+  // Mq / C2 != nullptr (deferred steps): H = Mq^T sym(C2) Mq is formed here, by every workgroup for
+  // itself in LDS (two cols^3 products), instead of being read from H; workgroup 0 leaves it in Hout
+  // for the Jacobi that follows on this stream. dynamic LDS then: 3 cols^2 + 17 + 128 doubles.
   // host != nullptr (deferred acceptance): everything the step's checks read — the sums, the
   // Gershgorin bounds, the status words of the Cholesky kernel, the residual shares — is ALSO
   // written straight into that pinned block of the slot (same layout as chk: no copy launch)
   extern __shared__ double sH[];  // cols x cols | red[17] | lo[64] | hi[64]
   double *red = sH + cols * cols;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  for (int e = tid; e < cols * cols; e += nthr) {
-    const int i = e % cols, j = e / cols;
-    sH[e] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
+  if (Mq) {
+    double *sM = sH + cols * cols + 17 + 128, *sT = sM + cols * cols;
+    for (int e = tid; e < cols * cols; e += nthr) {
+      const int i = e % cols, j = e / cols;
+      sM[e] = Mq[e];
+      sH[e] = 0.5 * (C2[i + cols * j] + C2[j + cols * i]);  // (sym(C2) for now)
+    }
+    __syncthreads();
+    for (int e = tid; e < cols * cols; e += nthr) {  // T = sym(C2) M
+      const int i = e % cols, j = e / cols;
+      double a = 0;
+      for (int p = 0; p < cols; p++) a += sH[i + cols * p] * sM[p + cols * j];
+      sT[e] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < cols * cols; e += nthr) {  // H = M^T T (upper and lower computed alike)
+      const int i = e % cols, j = e / cols;
+      double a = 0, b = 0;
+      for (int p = 0; p < cols; p++) {
+        a += sM[p + cols * i] * sT[p + cols * j];
+        b += sM[p + cols * j] * sT[p + cols * i];
+      }
+      const double h = 0.5 * (a + b);
+      sH[e] = h;  // (every thread reads only sM / sT here: sH may be overwritten)
+      if (Hout && blockIdx.x == 0) Hout[e] = h;
+    }
+  } else {
+    for (int e = tid; e < cols * cols; e += nthr) {
+      const int i = e % cols, j = e / cols;
+      sH[e] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
+    }
   }
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * rows_per;
