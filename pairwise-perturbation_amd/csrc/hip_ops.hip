@@ -1752,6 +1752,9 @@ class HipOps : public Ops {
       hipLaunchKernelGGL(k_rmult_pair, dim3(grid_for(2 * J * cols, 256)), dim3(256), sizeof(double) * cols * cols, st_,
                          Z, GZ, J, cols, Mw, Uout, es.GBd);
       es.jacobi_launched = true;
+      // (measured, round 4: making this event the completion signal of the launch above —
+      // hipExtLaunchKernelGGL's stop event — instead of a marker packet leaves 30 us of idle main
+      // stream behind it instead of 6-8: profiles/r04v_ext_launch_event.txt)
       HIP_CHECK(hipEventRecord(es.ev_h, st_));
       HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
       hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
