@@ -55,7 +55,7 @@ static void chain(const char *name, double *X, double *Y, int J, int n) {
 // with it fewer operand row-blocks to pull into its L2 after the kernel boundary emptied it) and
 // (b) optional phase stamps (s_memrealtime, 10 ns) by lane 0 of wave 0: start | operands in
 // registers | MFMAs done | partial tiles combined | stores issued.
-template <int NW, bool STAMP>
+template <int NW, bool STAMP, bool SB = false>
 __global__ __launch_bounds__(64 * NW) void k_sym_probe(const double *__restrict__ A, const double *__restrict__ Bt,
                                                        double *__restrict__ C, int M, double alpha,
                                                        const ushort2 *__restrict__ tile_map,
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64 * NW) void k_sym_probe(const double *__restrict_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (threadIdx.x == 0) t1 = __builtin_amdgcn_s_memrealtime();
     }
+    if (SB) __builtin_amdgcn_sched_barrier(0);  // every load of the round issued before the first MFMA
 #pragma unroll
     for (int u = 0; u < UN; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
   }
@@ -378,6 +379,27 @@ int main(int argc, char **argv) {
       printf("tile order %-28s J=%d: %.2f us per product; an XCD touches %.1f of %u operand row-blocks\n",
              kind == 0 ? "row-major (product)" : kind == 1 ? "Morton patches per XCD" : "tile rows dealt to XCDs", J,
              tsv[3], need / 8, nt);
+    }
+    {  // all 26 loads of a lane in flight before the first MFMA (the compiler otherwise sinks loads to save registers)
+      std::vector<ushort2> tab = tile_table(J, 0);
+      CK(hipMemcpy(dmap, tab.data(), sizeof(ushort2) * ntri, hipMemcpyHostToDevice));
+      std::vector<float> tsv;
+      const int n = 40;
+      for (int rep = 0; rep < 7; rep++) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < n; i++) {
+          hipLaunchKernelGGL((k_sym_probe<8, false, true>), dim3(ntri), dim3(512), 0, 0, X, X, Y, J, 1e-3, dmap, dst);
+          std::swap(X, Y);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tsv.push_back(ms * 1e3f / n);
+      }
+      std::sort(tsv.begin(), tsv.end());
+      printf("row-major, scheduling barrier between the loads and the MFMAs  J=%d: %.2f us per product\n", J, tsv[3]);
     }
     {  // phases (stamps cost a wait for all loads before the first MFMA: an upper bound of the load phase)
       std::vector<ushort2> tab = tile_table(J, 0);
