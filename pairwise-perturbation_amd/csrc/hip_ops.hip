@@ -745,6 +745,29 @@ class HipOps : public Ops {
     }
     Ops::ttm_keep(X, dt, L, J, T, W, ldw, Kc, out);
   }
+  bool ttm_lead_front(const void *X, int dt, int64_t J, int64_t S, int64_t T, const double *W, int64_t ldw,
+                      int Kc, double *out) override {
+    const double bytes = (double)J * S * T * dtype_size(dt);
+    if (!(S >= 16 && J >= 16 && Kc <= 64 && bytes <= 64e6 && (double)J * S < 2e9 && T <= 65535 &&
+          (double)ldw * Kc < 4e9))
+      return false;
+    RoctxRange roctx_("K11 leading-mode product (batched thin GEMM)");
+    const int nt = Kc <= 16 ? 1 : (Kc <= 32 ? 2 : 4);
+    dim3 grid((unsigned)((S + 15) / 16), (unsigned)((Kc + 16 * nt - 1) / (16 * nt)), (unsigned)T);
+    prof_begin(1, bytes);
+#define PPALS_MPL(TA_, NT_)                                                                               \
+  hipLaunchKernelGGL((k_mode_product_lead<TA_, NT_>), grid, dim3(512), 0, st_, (const TA_ *)X, (int)J, (int)S, W,  \
+                     ldw, Kc, out)
+    if (dt == F32) {
+      if (nt == 1) PPALS_MPL(float, 1); else if (nt == 2) PPALS_MPL(float, 2); else PPALS_MPL(float, 4);
+    } else {
+      if (nt == 1) PPALS_MPL(double, 1); else if (nt == 2) PPALS_MPL(double, 2); else PPALS_MPL(double, 4);
+    }
+#undef PPALS_MPL
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+    return true;
+  }
   // padded resident layout, see ops.h: a pitched copy (rows == 1) or a transposition whose
   // destination rows are padded
   void pad_layout(const void *src, int dt, int64_t rows, int64_t cols, int64_t blk, int64_t ld,

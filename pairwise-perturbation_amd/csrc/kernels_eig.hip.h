@@ -176,6 +176,79 @@ __global__ __launch_bounds__(64 * NW) void k_mode_product_small(const TA *__rest
   }
 }
 
+// The product with the LEADING mode of a small tensor, result with the next mode in front
+// (Ops::ttm_lead_front): per batch t, C_t (S x R) = A_t^T W with A_t (J x S, ld = J) — both operands are
+// read along the contraction index (16 lines per operand load: the data is L2-resident, 25 MB at
+// cfg5). Same tiling as k_mode_product_small: 16 result rows x NT column tiles per workgroup, NW waves
+// split J.
+template <typename TA, int NT, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_mode_product_lead(const TA *__restrict__ X, int J, int S,
+                                                               const double *__restrict__ W, int64_t ldw, int R,
+                                                               double *__restrict__ out) {
+  constexpr int UN = NT <= 2 ? 13 : 7;
+  __shared__ double part[NW - 1][NT][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16 * NT;
+  const TA *__restrict__ A = X + (size_t)blockIdx.z * J * S;         // this batch: J x S, ld = J
+  double *__restrict__ C = out + (size_t)blockIdx.z * S * R;          // S x R, ld = S
+  const unsigned a0 = (unsigned)J * (unsigned)min(i0 + l16, S - 1);
+  unsigned b0[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++) b0[n] = (unsigned)ldw * (unsigned)min(j0 + 16 * n + l16, R - 1);
+  f64x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (J + 3) / 4;
+  const int spw = (ksteps + NW - 1) / NW;
+  const int s_begin = wave * spw, s_end = min(ksteps, s_begin + spw);
+  for (int s0 = s_begin; s0 < s_end; s0 += UN) {
+    double av[UN], bv[NT][UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int k = (s0 + u) * 4 + g;
+      const bool ok = (s0 + u) < s_end && k < J;
+      const int kc = ok ? k : 0;
+      const double a = (double)A[a0 + (unsigned)kc];
+      av[u] = ok ? a : 0.0;
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const double b = W[b0[n] + (unsigned)kc];
+        bv[n][u] = ok ? b : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++)
+#pragma unroll
+      for (int n = 0; n < NT; n++)
+        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[n][u], acc[n], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) part[wave - 1][n][r][lane] = acc[n][r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int n = 0; n < NT; n++) {
+    const int j = j0 + 16 * n + l16;
+    if (j < R) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i0 + g + 4 * r;
+        if (i < S) {
+          double v = acc[n][r];
+#pragma unroll
+          for (int w = 0; w < NW - 1; w++) v += part[w][n][r][lane];  // fixed order
+          C[i + (size_t)S * j] = v;
+        }
+      }
+    }
+  }
+}
+
 // The same product for a SYMMETRIC result (the iterates of the sign iteration: X^2 and
 // X (a I + b X^2) with X symmetric): only the tiles on and above the diagonal are computed
 // (blockIdx.x enumerates them), every value is stored at (i, j) and at (j, i). The result is

@@ -155,6 +155,16 @@ class Ops {
     scan_contract(X, dt, L, J, T, &f, 1, Kc, out, F64, L * Kc, L);
   }
 
+  // The product with the LEADING mode of a small tensor, the next mode moved to the front of the result:
+  //   out[s + S*(k + Kc*t)] = sum_j X[j + J*(s + S*t)] * W[j + ldw*k]
+  // (the leaf of mode 1 in a Tucker chain: what the Gram of the unfolding wants, with no transposition
+  // behind a leading-mode scan). false: the back end has no such kernel — the caller takes the generic
+  // route.
+  virtual bool ttm_lead_front(const void * /*X*/, int /*dt*/, int64_t /*J*/, int64_t /*S*/, int64_t /*T*/,
+                              const double * /*W*/, int64_t /*ldw*/, int /*Kc*/, double * /*out*/) {
+    return false;
+  }
+
   // ---- contraction of a cached intermediate (fp64) that already carries the rank index ----
   //   out[l + L*t + out_rstride*r] (+)= sum_j X[l + L*(j + J*(t + T*r))] * B[j,r]
   // B = KRP of `nf` factor refs (combined extent J). accumulate!=0: add into out.

@@ -230,6 +230,28 @@ void TuckerEngine::compute_node(int idx) {
     return;
   }
   n.front = false;
+  // The leaf of mode 1 under a parent that keeps modes 0 and 1: one product with the LEADING mode,
+  // written with mode 1 in front — the unfolding the Gram wants (no leading-mode scan + pack +
+  // transposition: 25 -> 14 us at cfg5) — when the back end has the kernel.
+  if (!dist_ && n.parent >= 0 && n.lo == 1 && n.hi == 1 && n.slo == 0 && n.shi == 0) {
+    compute_node(n.parent);
+    const Node &p = nodes_[n.parent];
+    if (!p.front && p.lo == 0 && p.hi == 1) {
+      int64_t T = 1;
+      for (int m = 2; m < N_; m++) T *= r_[m];
+      const int64_t elems = (int64_t)ext(1) * r_[0] * T;
+      if (n.cap < elems) {
+        ops_.free(n.buf);
+        n.buf = (double *)ops_.alloc(sizeof(double) * elems);
+        n.cap = elems;
+      }
+      if (ops_.ttm_lead_front(p.buf, F64, ext(0), ext(1), T, wptr(0), V_.glens[0], r_[0], n.buf)) {
+        n.front = true;
+        n.valid = true;
+        return;
+      }
+    }
+  }
   std::vector<int64_t> dims(N_);
   const void *src;
   int dt;
