@@ -95,9 +95,12 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rr_apply,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_SYM_LDS_MIN")) sym_lds_min_ = std::max(32, atoi(v));
-    if (const char *v = getenv("PPALS_EIG_DEFER")) eig_defer_ok_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_DEFER")) {
+      eig_defer_ok_ = atoi(v);
+      handover_ok_ = eig_defer_ok_ != 2;  // (2: deferred, the second stream handed over by events)
+    }
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_h,
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_rmult_chol,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_jacobi_onesided,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -135,6 +138,7 @@ class HipOps : public Ops {
     for (auto &kv : eig_small_)
       if (kv.second.Q) hipFree(kv.second.Q);
     if (st2_) hipStreamDestroy(st2_);
+    if (handover_) hipFree(handover_);
     hipStreamDestroy(st_);
   }
 
@@ -1283,8 +1287,8 @@ class HipOps : public Ops {
     double *chk_pinned = nullptr;
     hipEvent_t ev_chk = nullptr;
     double *GBd = nullptr, *chkd = nullptr;  // G*B (J x rank) and the checks' device block, the slot's own
-    double *Md = nullptr, *C2d = nullptr;    // M and Z'^T G Z' of a deferred step (64 x 64 each)
-    size_t GBd_elems = 0;
+    double *Gd = nullptr;                    // the slot's own Gram (eig_gram): the second stream reads it
+    size_t GBd_elems = 0, Gd_elems = 0;
     struct {
       double sigma = 0, rho = 0, ell0 = 0;
       int m = 0, iters = 0;
@@ -1335,11 +1339,11 @@ class HipOps : public Ops {
   // the same with the second operand as it is (K x N, column-major): thin tails, no transposition
   void gemm_nn(const double *A, int64_t lda, const double *B, int64_t ldb, const double *D,
                int64_t ldd, double *C, int64_t ldc, int M, int N, int K, double alpha, double beta,
-               const double *Qov = nullptr, int mov = 0) {
+               const double *Qov = nullptr, int mov = 0, hipStream_t st = nullptr) {
     gemm_offsets_fit(lda, K, ldb, N);
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
-    hipLaunchKernelGGL(k_dgemm_nx<true>, grid, dim3(256), 0, st_, A, lda, B, ldb, D, ldd, C, ldc, M, N,
-                       K, alpha, beta, Qov, mov);
+    hipLaunchKernelGGL(k_dgemm_nx<true>, grid, dim3(256), 0, st ? st : st_, A, lda, B, ldb, D, ldd, C, ldc,
+                       M, N, K, alpha, beta, Qov, mov);
   }
   // full solver + what the next call of the slot needs (rank-th and next eigenvalue, the basis)
   void eig_bootstrap(EigState &es, double *G, int64_t J, int rank, double *U) {
@@ -1552,10 +1556,9 @@ class HipOps : public Ops {
     es.ev_chk = nullptr;
     if (es.GBd) hipFree(es.GBd);
     if (es.chkd) hipFree(es.chkd);
-    if (es.Md) hipFree(es.Md);
-    if (es.C2d) hipFree(es.C2d);
-    es.GBd = es.chkd = es.Md = es.C2d = nullptr;
-    es.GBd_elems = 0;
+    if (es.Gd) hipFree(es.Gd);
+    es.GBd = es.chkd = es.Gd = nullptr;
+    es.GBd_elems = es.Gd_elems = 0;
     if (es.ev_h) hipEventDestroy(es.ev_h);
     if (es.ev_done) hipEventDestroy(es.ev_done);
     es.Hd = es.Yd = es.evd = nullptr;
@@ -1565,6 +1568,12 @@ class HipOps : public Ops {
   // set-up), not inside the first timed sweep
   void lazy_prepare(EigState &es) {
     if (!st2_) HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+    if (!handover_) {
+      // (zero BEFORE any stream can wait on it: a recycled allocation may hold a larger sequence number)
+      HIP_CHECK(hipMalloc(&handover_, 16));
+      HIP_CHECK(hipMemset(handover_, 0, 16));
+      HIP_CHECK(hipDeviceSynchronize());
+    }
     if (!es.Hd) {
       HIP_CHECK(hipMalloc(&es.Hd, sizeof(double) * 64 * 64));
       HIP_CHECK(hipMalloc(&es.Yd, sizeof(double) * 64 * 64));
@@ -1575,8 +1584,6 @@ class HipOps : public Ops {
       HIP_CHECK(hipHostMalloc(&es.chk_pinned, kEigReadback, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&es.ev_chk, hipEventDisableTiming));
       HIP_CHECK(hipMalloc(&es.chkd, kEigReadback));
-      HIP_CHECK(hipMalloc(&es.Md, sizeof(double) * 64 * 64));
-      HIP_CHECK(hipMalloc(&es.C2d, sizeof(double) * 64 * 64));
     }
   }
   void eig_lazy(int slot, bool on) override {
@@ -1588,6 +1595,24 @@ class HipOps : public Ops {
   void eig_defer(int slot, bool on) override {
     if (slot < 0) return;
     eig_state_[slot].defer = on && eig_defer_ok_;
+  }
+  // The slot's own Gram buffer. A deferred step leaves G B, H = B^T G B and the residual to the
+  // second stream, which reads G long after the sweep's stream has moved on to the next mode — so
+  // the Gram of a deferring slot must not live in the caller's shared workspace. Whatever the
+  // second stream still owes this slot is waited for here (the wait resolve_lazy() would do a
+  // moment later), before the caller overwrites the buffer.
+  double *eig_gram(int slot, int64_t J) override {
+    if (slot < 0 || J > 4096) return nullptr;
+    auto it = eig_state_.find(slot);
+    if (it == eig_state_.end() || !it->second.defer || !it->second.lazy) return nullptr;
+    EigState &es = it->second;
+    if (es.jacobi_launched) HIP_CHECK(hipEventSynchronize(es.ev_done));
+    if (es.Gd_elems < (size_t)(J * J)) {
+      if (es.Gd) HIP_CHECK(hipFree(es.Gd));
+      HIP_CHECK(hipMalloc(&es.Gd, sizeof(double) * (size_t)(J * J)));
+      es.Gd_elems = (size_t)(J * J);
+    }
+    return es.Gd;
   }
   // What decides whether a projector step's result is accepted, from its one read-back `hc`
   // (chk[16] | evW[64] | status[8 ints] | lamD[64] | per-workgroup residual shares, already summed
@@ -1749,12 +1774,14 @@ class HipOps : public Ops {
     const int Ji = (int)J;
     const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
     const int rows_per = (int)((J + nblk - 1) / nblk);
-    const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && 3 * cols * cols <= (int)kEE;
+    const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && cols <= 64;
     if (deferred) {
-      // The tail of a DEFERRED step in five launches (kernels_eig.hip.h, k_tn_pair / k_chol_h /
-      // k_rmult_pair): the basis goes straight into the caller's buffer, what the checks read lives
-      // in the slot's own buffers — they are finished on the second stream while the main stream
-      // has long moved on and reuses the workspace.
+      // The tail of a DEFERRED step (kernels_eig.hip.h, k_tn_pair / k_rmult_chol). On the sweep's
+      // stream only what the next mode waits for: Z' = [q_D | P Omega_rest], its Gram, B = Z' R^-1
+      // straight into the caller's buffer — three launches. Everything the CHECKS read (G B,
+      // H = B^T G B, the subspace residual, the Jacobi of H) is formed from B on the second stream,
+      // in the slot's own buffers, from the slot's own copy of the Gram (eig_gram); a Gram in the
+      // caller's workspace is multiplied on the sweep's stream first.
       EigState &es = *lazy;
       lazy_prepare(es);
       if (es.GBd_elems < (size_t)J * cols) {
@@ -1762,28 +1789,42 @@ class HipOps : public Ops {
         HIP_CHECK(hipMalloc(&es.GBd, sizeof(double) * (size_t)J * cols));
         es.GBd_elems = (size_t)J * cols;
       }
-      double *C1 = C, *Mw = H;
+      double *C1 = C;
+      const bool own_gram = G == es.Gd;
       gemm_nn(X, J, Omega, J, Omega, J, Z, J, Ji, cols, Ji, 0.5, 0.5, QD, m);  // Z' = [q_D | P Omega_rest]
-      gemm_nn(G, J, Z, J, nullptr, 0, GZ, J, Ji, cols, Ji, 1.0, 0.0);           // G Z'
       // (a Jacobi of this slot that is still in flight — a step that was not accepted — must be through
       // with the slot's buffers before they are written again)
       if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
-      hipLaunchKernelGGL(k_tn_pair, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, Z, GZ, J, cols, C1, es.C2d,
-                         pe2, ptr_, np, chk, es.chkd);
-      hipLaunchKernelGGL(k_chol_h, dim3(1), dim3(k_chol_threads(cols)), sizeof(double) * (4 * (size_t)cols * cols + 8),
-                         st_, C1, cols, Mw, es.Md, status, chk, es.chkd);
-      hipLaunchKernelGGL(k_rmult_pair, dim3(grid_for(2 * J * cols, 256)), dim3(256), sizeof(double) * cols * cols, st_,
-                         Z, GZ, J, cols, Mw, Uout, es.GBd);
+      hipLaunchKernelGGL(k_tn_pair, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, Z, (const double *)nullptr,
+                         J, cols, C1, (double *)nullptr, pe2, ptr_, np, chk, es.chkd);
+      // The second stream takes over from the kernel itself when it reads the slot's own Gram: the
+      // last workgroup of k_rmult_chol publishes a sequence number, the second stream waits for the
+      // value — no marker packet on the sweep's stream (an event record + wait costs it 6-8 us per
+      // step: profiles/r04c_cfg5_timeline_deferred_checks.txt, tools/waitvalue_bench.hip).
+      const bool by_flag = own_gram && handover_ok_ && handover_;
+      const unsigned long long seq = by_flag ? ++handover_seq_ : 0;
+      hipLaunchKernelGGL(k_rmult_chol, dim3((unsigned)((J + 63) / 64)), dim3(1024),
+                         sizeof(double) * (4 * (size_t)cols * cols + 8), st_, Z, J, cols, C1, Uout, status, chk,
+                         es.chkd, by_flag ? (unsigned *)(handover_ + 1) : (unsigned *)nullptr,
+                         by_flag ? handover_ : (unsigned long long *)nullptr, seq);
+      if (!own_gram) gemm_nn(G, J, Uout, J, nullptr, 0, es.GBd, J, Ji, cols, Ji, 1.0, 0.0);
       es.jacobi_launched = true;
-      // (measured, round 4: making this event the completion signal of the launch above —
-      // hipExtLaunchKernelGGL's stop event — instead of a marker packet leaves 30 us of idle main
-      // stream behind it instead of 6-8: profiles/r04v_ext_launch_event.txt)
-      HIP_CHECK(hipEventRecord(es.ev_h, st_));
-      HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
-      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256),
-                         sizeof(double) * (3 * (size_t)cols * cols + 17 + 128), st2_, Uout, es.GBd, J, cols,
-                         (const double *)nullptr, rows_per, (const double *)nullptr, (const double *)nullptr, -1,
-                         (double *)nullptr, Uout2, es.chkd, es.chkd + kEigOffResp, host_chk, es.Md, es.C2d, es.Hd);
+      if (by_flag) {
+        HIP_CHECK(hipStreamWaitValue64(st2_, handover_, seq, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+      } else {
+        // (measured, round 4: making this event the completion signal of the launch above —
+        // hipExtLaunchKernelGGL's stop event — instead of a marker packet leaves 30 us of idle main
+        // stream behind it instead of 6-8: profiles/r04v_ext_launch_event.txt)
+        HIP_CHECK(hipEventRecord(es.ev_h, st_));
+        HIP_CHECK(hipStreamWaitEvent(st2_, es.ev_h, 0));
+      }
+      if (own_gram) gemm_nn(G, J, Uout, J, nullptr, 0, es.GBd, J, Ji, cols, Ji, 1.0, 0.0, nullptr, 0, st2_);
+      hipLaunchKernelGGL(k_tn_small, dim3((cols * cols + 15) / 16), dim3(1024), 0, st2_, Uout, es.GBd, J, cols,
+                         es.Hd, (double *)nullptr);
+      hipLaunchKernelGGL(k_sub_residual, dim3(nblk), dim3(256), sizeof(double) * ((size_t)cols * cols + 17 + 128),
+                         st2_, Uout, es.GBd, J, cols, es.Hd, rows_per, (const double *)nullptr,
+                         (const double *)nullptr, -1, (double *)nullptr, Uout2, es.chkd, es.chkd + kEigOffResp,
+                         host_chk);
       HIP_CHECK(hipEventRecord(es.ev_chk, st2_));
       const int nthr_j = std::min(1024, std::max(192, (cols * cols / 2 + 63) / 64 * 64) + 64);
       hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(nthr_j), top_eig_small_lds(cols) + sizeof(int) * 64, st2_,
@@ -2609,6 +2650,9 @@ class HipOps : public Ops {
   size_t ws_jac_sz_ = 0;
   int sym_lds_min_ = 768;   // PPALS_SYM_LDS_MIN: rows from which the symmetric product is LDS-tiled
   int eig_defer_ok_ = 1;    // PPALS_EIG_DEFER=0: every projector step waits for its own checks
+  bool handover_ok_ = true;                 // second stream released by a value the kernel stores (else: events)
+  unsigned long long *handover_ = nullptr;  // [0] the sequence number published last, [1] workgroup counter
+  unsigned long long handover_seq_ = 0;
   int eig_defer_fail_ = 0;  // PPALS_EIG_DEFER_FAIL=n (tests): every n-th deferred check is reported as failed
   int eig_defer_count_ = 0;
   int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)

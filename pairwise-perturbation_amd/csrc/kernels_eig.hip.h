@@ -1042,15 +1042,15 @@ __global__ void k_tn_two(const double *__restrict__ Z, const double *__restrict_
   }
 }
 
-// ---- the tail of a deferred step in five launches (round 4): Z' = [q_D | P Omega_rest] | G Z' |
-// k_tn_pair | k_chol_h | k_rmult_pair. With the deflated vector in front of Z', ONE Cholesky QR of
-// all columns keeps it (the first column of a QR is the first column, normalised) and clears the
-// others of it; and H = B^T G B = M^T (Z'^T G Z') M needs no product with B: the 20 x 20 algebra
-// rides in the one-workgroup kernel that makes M, and B, G B are two right-multiplications by M in
-// one launch.
-// k_tn_pair: C1[p + cols q] = z_p^T z_q, C2[p + cols q] = z_p^T (G z)_q — one wave per entry. The last
-// workgroup instead adds up the sign iteration's check sums (np partials each) into chk_out[0],
-// chk_out[1] and carries the step's norm word [8] over into the slot's check block.
+// ---- the tail of a deferred step (round 4). On the sweep's stream only what the NEXT mode waits for:
+//   Z' = [q_D | P Omega_rest]  (thin GEMM)  |  k_tn_pair: C1 = Z'^T Z'  |  k_rmult_chol: B = Z' R^-1
+// With the deflated vector in front of Z', ONE Cholesky QR of all columns keeps it (the first column
+// of a QR is the first column, normalised) and clears the others of it. Everything the CHECKS read —
+// G B, H = B^T G B, the residual, the Jacobi of H — is formed from B on the second stream, from the
+// slot's own copy of the Gram (Ops::eig_gram), beside the next mode's tensor scan.
+// k_tn_pair: C1[p + cols q] = z_p^T z_q (and, with GZ, C2[p + cols q] = z_p^T (G z)_q) — one wave per
+// entry. The last workgroup instead adds up the sign iteration's check sums (np partials each) into
+// chk_out[0], chk_out[1] and carries the step's norm word [8] over into the slot's check block.
 __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict__ GZ, int64_t rows, int cols,
                           double *__restrict__ C1, double *__restrict__ C2,
                           const double *__restrict__ part_e2, const double *__restrict__ part_tr, int np,
@@ -1076,39 +1076,62 @@ __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict
   const int nw = (int)(((int64_t)(gridDim.x - 1) * blockDim.x) >> 6);
   for (int e = wid; e < cols * cols; e += nw) {
     const int p = e % cols, q = e / cols;
-    const double *a = Z + rows * p, *b = Z + rows * q, *c = GZ + rows * q;
+    const double *a = Z + rows * p, *b = Z + rows * q;
     double s1 = 0, s2 = 0;
-    for (int64_t i = lane; i < rows; i += 64) {
-      const double x = a[i];
-      s1 += x * b[i];
-      s2 += x * c[i];
+    if (GZ) {
+      const double *c = GZ + rows * q;
+      for (int64_t i = lane; i < rows; i += 64) {
+        const double x = a[i];
+        s1 += x * b[i];
+        s2 += x * c[i];
+      }
+      s2 = wave_sum(s2);
+    } else {
+      for (int64_t i = lane; i < rows; i += 64) s1 += a[i] * b[i];
     }
     s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
     if (lane == 0) {
       C1[e] = s1;
-      C2[e] = s2;
+      if (GZ) C2[e] = s2;
     }
   }
 }
-// k_chol_h (ONE workgroup): M = R^-1 with C1 = Z'^T Z' = R^T R, so that Z' M is orthonormal -> M and
-// M2 (the slot's copy: the second stream forms H = M^T sym(C2) M from it, k_sub_residual); the step's
-// status words into the slot's check block. The elimination of k_chol_m on ALL columns (two pivots
-// per barrier: ten dependent rounds at n = 20). *status: 1 = a pivot not safely positive, 2 = pivots
-// spread by more than 4, else 0. dynamic LDS: 4 n^2 + 8 doubles.
-// (Measured and not kept, round 4: the inverse square root by its series — Z' = P Omega is close to
-// orthonormal — needs ||I - C1|| <= 1e-3 for three terms; a HOOI sweep of cfg5 turns the subspace by
-// 0.03-0.07 rad, ||I - C1|| = 5e-4 ... 5e-3 with n = 20 columns: the series was taken in 1 step of 130.)
-__global__ __launch_bounds__(1024) void k_chol_h(const double *__restrict__ C1, int n,
-                                                 double *__restrict__ M, double *__restrict__ M2,
-                                                 int *__restrict__ status,
-                                                 const double *__restrict__ chk_src,
-                                                 double *__restrict__ chk_out) {
+// k_rmult_chol: B = Z R^-1 with C1 = Z^T Z = R^T R — the Cholesky factorisation INSIDE the
+// multiplication: every workgroup (1024 threads, 64 rows of Z) eliminates [C1 | I] for itself in LDS
+// while its rows of Z are on their way into the cache, then multiplies. One launch instead of
+// factorisation + multiplication, and no round trip of the n x n inverse through memory.
+// The elimination is the one of k_chol_m on ALL columns (two pivots per barrier: ten dependent
+// rounds at n = 20): C1 -> D L_1^T, I -> L_1^-1, R^-1[p][q] = L_1^-1[q][p] / sqrt(d_q).
+// Workgroup 0 leaves the step's status words in the slot's check block: 1 = a pivot not safely
+// positive (NOTHING is written to `out` then: the step is not accepted), 2 = pivots spread by more
+// than 4, else 0. dynamic LDS: 4 n^2 + 8 doubles.
+// flag != nullptr: see the end of the kernel (tools/waitvalue_bench.hip: the producing stream goes on
+// 2-4 us after the launch instead of 7.7 us after launch + event marker, the waiting stream starts
+// 3-4 us after the data is there instead of 11.8).
+// (Measured and not kept, round 4: (a) the inverse square root by its series — Z' = P Omega is close
+// to orthonormal — needs ||I - C1|| <= 1e-3 for three terms; a HOOI sweep of cfg5 turns the subspace
+// by 0.03-0.07 rad, ||I - C1|| = 5e-4 ... 5e-3 with n = 20 columns: taken in 1 step of 130.
+// (b) the factorisation by ONE wave in registers — lane j holds column j, a pivot is a v_readlane
+// per remaining row, fully unrolled for constant register indices: 59 KB of straight-line code that
+// runs once per launch out of a cold instruction cache, 22.7 us per launch: profiles/r04x_*.)
+__global__ __launch_bounds__(1024) void k_rmult_chol(const double *__restrict__ Z, int64_t rows, int n,
+                                                     const double *__restrict__ C1,
+                                                     double *__restrict__ out, int *__restrict__ status,
+                                                     const double *__restrict__ chk_src,
+                                                     double *__restrict__ chk_out,
+                                                     unsigned *__restrict__ done_count,
+                                                     unsigned long long *__restrict__ flag,
+                                                     unsigned long long seq) {
   extern __shared__ double lds[];
   const int w2 = 2 * n;
   double *E0 = lds, *E1 = E0 + n * w2;  // row-major n x 2n: [C | I] being eliminated
   double *sc = E1 + n * w2;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int nrow = (int)min((int64_t)64, rows - row0);
+  // this workgroup's rows of Z: requested now, multiplied after the elimination
+  double warm = 0;
+  for (int e = tid; e < nrow * n; e += nthr) warm += Z[row0 + e % nrow + rows * (e / nrow)];
   for (int e = tid; e < n * w2; e += nthr) {
     const int i = e / w2, j = e - i * w2;
     E0[e] = j < n ? 0.5 * (C1[i + n * j] + C1[j + n * i]) : ((j - n == i) ? 1.0 : 0.0);
@@ -1163,46 +1186,54 @@ __global__ __launch_bounds__(1024) void k_chol_h(const double *__restrict__ C1, 
   }
   lds_barrier();
   const bool bad = sc[2] != 0.0;
-  const int st = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
-  if (tid == 0) {
-    *status = st;
-    union {
-      int w[2];
-      double d;
-    } u;
-    u.w[0] = st;
-    u.w[1] = status[1];
-    chk_out[kEigOffStatus] = u.d;
-  } else if (tid < 4) {
-    chk_out[kEigOffStatus + tid] = chk_src[kEigOffStatus + tid];
+  if (blockIdx.x == 0) {
+    const int st = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
+    if (tid == 0) {
+      *status = st;
+      union {
+        int w[2];
+        double d;
+      } u;
+      u.w[0] = st;
+      u.w[1] = status[1];
+      chk_out[kEigOffStatus] = u.d;
+    } else if (tid < 4) {
+      chk_out[kEigOffStatus + tid] = chk_src[kEigOffStatus + tid];
+    }
   }
-  if (bad) return;
-  // src = [D L_1^T | L_1^-1]; M[p][q] = L_1^-1[q][p] / sqrt(d_q) for p <= q (upper triangular)
-  for (int e = tid; e < n * n; e += nthr) {
-    const int p = e % n, q = e / n;
-    const double v = (p <= q) ? src[q * w2 + n + p] / sqrt(src[q * w2 + q]) : 0.0;
-    M[e] = v;
-    M2[e] = v;
+  if (!bad) {
+    // src = [D L_1^T | L_1^-1]; R^-1[p][q] = L_1^-1[q][p] / sqrt(d_q) for p <= q -> dst[p + n q]
+    for (int e = tid; e < n * n; e += nthr) {
+      const int p2 = e % n, q = e / n;
+      dst[e] = (p2 <= q) ? src[q * w2 + n + p2] / sqrt(src[q * w2 + q]) : 0.0;
+    }
+    lds_barrier();
+    if (warm == 1.2345e300) out[0] = warm;  // (never: keeps the early loads alive)
+    const int r = tid & 63, part = tid >> 6, nparts = nthr >> 6;
+    if (r < nrow) {
+      const double *zr = Z + row0 + r;
+      for (int q = part; q < n; q += nparts) {
+        double a = 0;
+        for (int p2 = 0; p2 <= q; p2++) a += zr[rows * p2] * dst[p2 + n * q];
+        out[row0 + r + rows * q] = a;
+      }
+    }
   }
-}
-// k_rmult_pair: B = Z M -> out1, G B = GZ M -> out2 (rows x cols each, M cols x cols upper triangular)
-__global__ __launch_bounds__(256) void k_rmult_pair(const double *__restrict__ Z, const double *__restrict__ GZ,
-                                                    int64_t rows, int cols, const double *__restrict__ M,
-                                                    double *__restrict__ out1, double *__restrict__ out2) {
-  extern __shared__ double sM[];
-  for (int e = threadIdx.x; e < cols * cols; e += blockDim.x) sM[e] = M[e];
-  __syncthreads();
-  const int64_t total = 2 * rows * cols;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int which = (int)(e / (rows * cols));
-    const int64_t r = e - (int64_t)which * rows * cols;
-    const int64_t i = r % rows;
-    const int c = (int)(r / rows);
-    const double *src = which ? GZ : Z;
-    double a = 0;
-    for (int p = 0; p <= c; p++) a += src[i + rows * p] * sM[p + cols * c];  // (M is upper triangular)
-    (which ? out2 : out1)[i + rows * c] = a;
+  // Hand-over to the second stream without a packet on this one: the workgroup that finishes last
+  // publishes the launch's sequence number in `flag`; the second stream waits for that value
+  // (hipStreamWaitValue64). Every workgroup releases its rows first (agent scope: its XCD's L2).
+  if (flag) {
+    __threadfence();  // (every wave: its own stores have left for the L2 before the workgroup counts itself done)
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      const unsigned prev = atomicAdd(done_count, 1u);
+      if (prev == gridDim.x - 1) {
+        *done_count = 0;
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -1420,50 +1451,16 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
                                                       double *__restrict__ U, double *__restrict__ U2,
                                                       double *__restrict__ chk,
                                                       double *__restrict__ resp,
-                                                      double *__restrict__ host = nullptr,
-                                                      const double *__restrict__ Mq = nullptr,
-                                                      const double *__restrict__ C2 = nullptr,
-                                                      double *__restrict__ Hout = nullptr) {
-  // Mq / C2 != nullptr (deferred steps): H = Mq^T sym(C2) Mq is formed here, by every workgroup for
-  // itself in LDS (two cols^3 products), instead of being read from H; workgroup 0 leaves it in Hout
-  // for the Jacobi that follows on this stream. dynamic LDS then: 3 cols^2 + 17 + 128 doubles.
+                                                      double *__restrict__ host = nullptr) {
   // host != nullptr (deferred acceptance): everything the step's checks read — the sums, the
   // Gershgorin bounds, the status words of the Cholesky kernel, the residual shares — is ALSO
   // written straight into that pinned block of the slot (same layout as chk: no copy launch)
   extern __shared__ double sH[];  // cols x cols | red[17] | lo[64] | hi[64]
   double *red = sH + cols * cols;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  if (Mq) {
-    double *sM = sH + cols * cols + 17 + 128, *sT = sM + cols * cols;
-    for (int e = tid; e < cols * cols; e += nthr) {
-      const int i = e % cols, j = e / cols;
-      sM[e] = Mq[e];
-      sH[e] = 0.5 * (C2[i + cols * j] + C2[j + cols * i]);  // (sym(C2) for now)
-    }
-    __syncthreads();
-    for (int e = tid; e < cols * cols; e += nthr) {  // T = sym(C2) M
-      const int i = e % cols, j = e / cols;
-      double a = 0;
-      for (int p = 0; p < cols; p++) a += sH[i + cols * p] * sM[p + cols * j];
-      sT[e] = a;
-    }
-    __syncthreads();
-    for (int e = tid; e < cols * cols; e += nthr) {  // H = M^T T (upper and lower computed alike)
-      const int i = e % cols, j = e / cols;
-      double a = 0, b = 0;
-      for (int p = 0; p < cols; p++) {
-        a += sM[p + cols * i] * sT[p + cols * j];
-        b += sM[p + cols * j] * sT[p + cols * i];
-      }
-      const double h = 0.5 * (a + b);
-      sH[e] = h;  // (every thread reads only sM / sT here: sH may be overwritten)
-      if (Hout && blockIdx.x == 0) Hout[e] = h;
-    }
-  } else {
-    for (int e = tid; e < cols * cols; e += nthr) {
-      const int i = e % cols, j = e / cols;
-      sH[e] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
-    }
+  for (int e = tid; e < cols * cols; e += nthr) {
+    const int i = e % cols, j = e / cols;
+    sH[e] = 0.5 * (H[i + cols * j] + H[j + cols * i]);
   }
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * rows_per;

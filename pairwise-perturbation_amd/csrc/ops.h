@@ -299,6 +299,10 @@ class Ops {
   //       had before the step and takes the checked route next time).
   // discard = true: the pending step is dropped whatever its checks say (its input was wrong).
   virtual void eig_defer(int /*slot*/, bool /*on*/) {}
+  // A deferring slot finishes its checks on a second stream, from the Gram the step was given — so
+  // that Gram must outlive the call. eig_gram() hands out the slot's own J x J buffer to build the
+  // Gram in (after waiting for whatever still reads it), or nullptr: use your own workspace.
+  virtual double *eig_gram(int /*slot*/, int64_t /*J*/) { return nullptr; }
   virtual bool eig_deferred(int /*slot*/) { return false; }  // a step of the slot awaits eig_verify
   virtual int eig_verify(int /*slot*/, bool /*discard*/ = false) { return -1; }
   virtual const double *eig_pending_rotation(int /*slot*/) { return nullptr; }

@@ -561,8 +561,11 @@ void TuckerEngine::factor_update(int i, const double *Y, int64_t L, int64_t T) {
     ops_.ttm_keep(Ym, F64, s, c, 1, Vr, c, r_[i], W_[i]);
     if (ops_.orthonormalize(W_[i], s, r_[i])) return;
   }
-  ops_.unfold_gram(Y, F64, L, s, T, G_);
-  ops_.top_eigvecs_warm(G_, s, r_[i], W_[i], eig_base_ + i);
+  // (a slot that defers its checks keeps the Gram itself: they are finished on a second stream)
+  double *G = ops_.eig_gram(eig_base_ + i, s);
+  if (!G) G = G_;
+  ops_.unfold_gram(Y, F64, L, s, T, G);
+  ops_.top_eigvecs_warm(G, s, r_[i], W_[i], eig_base_ + i);
 }
 
 void TuckerEngine::sweep_dt() { sweep_body(nullptr); }

@@ -346,15 +346,17 @@ def test_thin_route_with_more_than_64_columns_needs_no_vendor_solver(pp, tmp_pat
     c2.close()
 
 
-@pytest.mark.parametrize("fail_every", [0, 2, 5])
-def test_deferred_eigen_step_checks(pp, fail_every, tmp_path, monkeypatch, capfd):
+@pytest.mark.parametrize("fail_every,handover", [(0, "value"), (2, "value"), (5, "value"), (0, "event"), (3, "event")])
+def test_deferred_eigen_step_checks(pp, fail_every, handover, tmp_path, monkeypatch, capfd):
     """Deferred acceptance (Ops::eig_defer / eig_verify, hip_ops.hip; TuckerEngine::settle_mode /
     rollback_and_redo): once a slot's steps go through as scheduled, a plain HOOI sweep no longer
     waits for their checks — they are read when the engine comes back to the mode, or before a row
     is printed. 14 sweeps on mode extents above 64 against the oracle's full eigen-decompositions
     (projectors, ||core||, CSV rows), with PPALS_EIG_DEFER_FAIL=n turning every n-th deferred check
     into a failure: the engine must put back every factor stepped since and repeat those steps. The
-    step log must show deferred checks (and the forced failures)."""
+    step log must show deferred checks (and the forced failures). The second stream that finishes the
+    checks is released by a value the last kernel of the step stores (hipStreamWaitValue64) or, with
+    PPALS_EIG_DEFER=2, by an event."""
     lens, ranks = [96, 80, 72], [5, 6, 4]
     V = _decaying_tensor(lens, [10, 9, 8], 5, 0.05)
     W0, c0 = O.hosvd(V, ranks)
@@ -365,6 +367,8 @@ def test_deferred_eigen_step_checks(pp, fail_every, tmp_path, monkeypatch, capfd
     monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
     if fail_every:
         monkeypatch.setenv("PPALS_EIG_DEFER_FAIL", str(fail_every))
+    if handover == "event":
+        monkeypatch.setenv("PPALS_EIG_DEFER", "2")
     c2 = pp.Context(0)
     t = pp.Tensor(c2, lens, 1).upload(V)
     s = pp.Tucker(c2, t, ranks)
