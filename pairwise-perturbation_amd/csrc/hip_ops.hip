@@ -1803,8 +1803,10 @@ class HipOps : public Ops {
       // step: profiles/r04c_cfg5_timeline_deferred_checks.txt, tools/waitvalue_bench.hip).
       const bool by_flag = own_gram && handover_ok_ && handover_;
       const unsigned long long seq = by_flag ? ++handover_seq_ : 0;
-      hipLaunchKernelGGL(k_rmult_chol, dim3((unsigned)((J + 63) / 64)), dim3(1024),
-                         sizeof(double) * (4 * (size_t)cols * cols + 8), st_, Z, J, cols, C1, Uout, status, chk,
+      const int rb = rmult_chol_rows(cols);
+      hipLaunchKernelGGL(k_rmult_chol, dim3((unsigned)((J + rb - 1) / rb)), dim3(rmult_chol_threads(cols)),
+                         rmult_chol_lds(cols), st_, Z, J, cols, m,
+                         C1, Uout, status, chk,
                          es.chkd, by_flag ? (unsigned *)(handover_ + 1) : (unsigned *)nullptr,
                          by_flag ? handover_ : (unsigned long long *)nullptr, seq);
       if (!own_gram) gemm_nn(G, J, Uout, J, nullptr, 0, es.GBd, J, Ji, cols, Ji, 1.0, 0.0);

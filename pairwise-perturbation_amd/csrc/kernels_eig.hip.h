@@ -1096,25 +1096,74 @@ __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict
     }
   }
 }
-// k_rmult_chol: B = Z R^-1 with C1 = Z^T Z = R^T R — the Cholesky factorisation INSIDE the
-// multiplication: every workgroup (1024 threads, 64 rows of Z) eliminates [C1 | I] for itself in LDS
-// while its rows of Z are on their way into the cache, then multiplies. One launch instead of
-// factorisation + multiplication, and no round trip of the n x n inverse through memory.
-// The elimination is the one of k_chol_m on ALL columns (two pivots per barrier: ten dependent
-// rounds at n = 20): C1 -> D L_1^T, I -> L_1^-1, R^-1[p][q] = L_1^-1[q][p] / sqrt(d_q).
+// k_rmult_chol: B = Z M with M^T (Z^T Z) M = I — the small factorisation INSIDE the multiplication:
+// every workgroup (1024 threads, 64 rows of Z) forms M for itself in LDS while its rows of Z are on
+// their way into the cache, then multiplies. One launch instead of factorisation + multiplication,
+// and no round trip of the n x n matrix through memory.
+//
+// Two ways to M. Z = [q_D | P Omega'] (m = 1: the deflated unit vector in front) or P Omega (m = 0)
+// with the PREVIOUS orthonormal basis Omega, so S = the Gram of the projected columns (after the
+// one-pivot elimination of q_D) is I - E with E = Omega^T (I - P) Omega: the squared sines of the
+// angles between the old and the new subspace — a HOOI sweep of cfg5 turns it by 0.03-0.07 rad,
+// ||E||_F = 5e-4 ... 5e-3.
+//  (a) ||E||_F <= kSeriesTol (and n <= kSeriesMax): S^-1/2 = sum_k c_k E^k, c_k = binom(2k, k) / 4^k, up to
+//      E^9 by Paterson-Stockmeyer — E^2, E^3 and two more products: FOUR dependent stages of (n-1)^2
+//      elements instead of ten elimination rounds; remainder 0.18 ||E||^10 < 1e-16.
+//      B = [z_0 c00^-1/2 | (Z' - z_0 t) S^-1/2], t = C1[0, 1:] / c00: q_D stays the first column (the
+//      power steps of the slot's next call start from it). status[1] = 3 marks the route in the log.
+//  (b) otherwise: the elimination of k_chol_m on ALL columns (two pivots per barrier: ten dependent
+//      rounds at n = 20): C1 -> D L_1^T, I -> L_1^-1, M[p][q] = L_1^-1[q][p] / sqrt(d_q) (upper
+//      triangular: Cholesky QR).
 // Workgroup 0 leaves the step's status words in the slot's check block: 1 = a pivot not safely
 // positive (NOTHING is written to `out` then: the step is not accepted), 2 = pivots spread by more
-// than 4, else 0. dynamic LDS: 4 n^2 + 8 doubles.
+// than 4, else 0. Launch: rmult_chol_threads(n) threads, rmult_chol_lds(n) bytes of dynamic LDS,
+// one workgroup per rmult_chol_rows(n) rows (the workgroup's rows of Z wait in LDS for M).
 // flag != nullptr: see the end of the kernel (tools/waitvalue_bench.hip: the producing stream goes on
 // 2-4 us after the launch instead of 7.7 us after launch + event marker, the waiting stream starts
 // 3-4 us after the data is there instead of 11.8).
-// (Measured and not kept, round 4: (a) the inverse square root by its series — Z' = P Omega is close
-// to orthonormal — needs ||I - C1|| <= 1e-3 for three terms; a HOOI sweep of cfg5 turns the subspace
-// by 0.03-0.07 rad, ||I - C1|| = 5e-4 ... 5e-3 with n = 20 columns: taken in 1 step of 130.
-// (b) the factorisation by ONE wave in registers — lane j holds column j, a pivot is a v_readlane
-// per remaining row, fully unrolled for constant register indices: 59 KB of straight-line code that
-// runs once per launch out of a cold instruction cache, 22.7 us per launch: profiles/r04x_*.)
-__global__ __launch_bounds__(1024) void k_rmult_chol(const double *__restrict__ Z, int64_t rows, int n,
+// (Measured and not kept, round 4: the factorisation by ONE wave in registers — lane j holds column
+// j, a pivot is a v_readlane per remaining row, fully unrolled for constant register indices: 59 KB
+// of straight-line code that runs once per launch out of a cold instruction cache, 22.7 us per
+// launch: profiles/r04z_cfg5_tail_on_second_stream.txt.)
+constexpr int kSeriesMax = 48;
+constexpr double kSeriesTol = 0.03;
+// (workgroup size by the number of columns, measured with tools/rmult_chol_bench.hip at n = 21: the launch
+// chain copy + Gram + this kernel 23.2 us with 256 threads, 19.1 with 512, 20.5 with 1024 — the stages of the
+// series are (n-1)^2 elements and a barrier each, a barrier of 16 waves costs ~0.4 us; the elimination of
+// many columns wants the threads)
+__host__ __device__ inline int rmult_chol_threads(int n) { return n <= 32 ? 512 : 1024; }
+__host__ __device__ inline int rmult_chol_rows(int n) { return n <= kSeriesMax ? 64 : 32; }
+__host__ __device__ inline size_t rmult_chol_lds(int n) {
+  return sizeof(double) * ((n <= kSeriesMax ? 6 : 4) * (size_t)n * n + (size_t)rmult_chol_rows(n) * n + 96);
+}
+#ifndef PPALS_RC_STAMP  // (tools/rmult_chol_bench.hip defines it: phase stamps of workgroup 0)
+#define PPALS_RC_STAMP(k)
+#endif
+// sum_k A[i + nn k] B[k + nn j] for symmetric nn x nn matrices in LDS (polynomials of one matrix: they
+// commute). The loads of eight terms are in flight together: a term at a time costs an LDS round trip each.
+__device__ __forceinline__ double lds_symm_dot(const double *A, const double *B, int nn, int i, int j) {
+  const double *ap = A + i, *bp = B + nn * j;
+  double a0 = 0, a1 = 0;
+  int k = 0;
+  for (; k + 8 <= nn; k += 8) {
+    double x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      x[u] = ap[nn * (k + u)];
+      y[u] = bp[k + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      a0 += x[u] * y[u];
+      a1 += x[u + 1] * y[u + 1];
+    }
+  }
+  // (a branch-free last batch — clamped addresses, zero factors — was measured slower: 4.2 vs 3.6 us for the
+  // four stages at n = 21, tools/rmult_chol_bench.hip)
+  for (; k < nn; k++) a0 += ap[nn * k] * bp[k];
+  return a0 + a1;
+}
+__global__ __launch_bounds__(1024) void k_rmult_chol(const double *__restrict__ Z, int64_t rows, int n, int m,
                                                      const double *__restrict__ C1,
                                                      double *__restrict__ out, int *__restrict__ status,
                                                      const double *__restrict__ chk_src,
@@ -1123,118 +1172,236 @@ __global__ __launch_bounds__(1024) void k_rmult_chol(const double *__restrict__ 
                                                      unsigned long long *__restrict__ flag,
                                                      unsigned long long seq) {
   extern __shared__ double lds[];
-  const int w2 = 2 * n;
-  double *E0 = lds, *E1 = E0 + n * w2;  // row-major n x 2n: [C | I] being eliminated
-  double *sc = E1 + n * w2;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const int nrow = (int)min((int64_t)64, rows - row0);
-  // this workgroup's rows of Z: requested now, multiplied after the elimination
-  double warm = 0;
-  for (int e = tid; e < nrow * n; e += nthr) warm += Z[row0 + e % nrow + rows * (e / nrow)];
-  for (int e = tid; e < n * w2; e += nthr) {
-    const int i = e / w2, j = e - i * w2;
-    E0[e] = j < n ? 0.5 * (C1[i + n * j] + C1[j + n * i]) : ((j - n == i) ? 1.0 : 0.0);
+  const int RB = rmult_chol_rows(n);  // rows of Z per workgroup
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const int nrow = (int)min((int64_t)RB, rows - row0);
+  const bool small = n <= kSeriesMax && n - m >= 4;
+  double *sc = lds + (n <= kSeriesMax ? 6 : 4) * n * n;  // [0..16] reductions | [17..19] | t[64] from 32
+  double *Zs = sc + 96;                                   // RB x n: this workgroup's rows of Z
+  // this workgroup's rows of Z: requested now (<= 8 per thread), parked in LDS once M is there
+  double zreg[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int e = tid + u * nthr;
+    zreg[u] = e < RB * n ? Z[min(row0 + (e % RB), rows - 1) + rows * (e / RB)] : 0.0;
   }
-  lds_barrier();
-  if (tid == 0) {
-    double dmax = 0;
-    for (int k = 0; k < n; k++) dmax = fmax(dmax, E0[k * w2 + k]);
-    sc[0] = dmax;
-    sc[1] = dmax;
-    sc[2] = 0.0;
-  }
-  lds_barrier();
-  double *src = E0, *dst = E1;
-  for (int k = 0; k < n; k += 2) {
-    const double d = src[k * w2 + k];
-    if (!(d > 1e-14 * sc[0])) {  // (uniform)
-      if (tid == 0) sc[2] = 1.0;
-      break;
-    }
-    const double dinv = 1.0 / d;
-    const bool two = k + 1 < n;
-    double d1 = d, d1inv = 0.0, lk1 = 0.0;
-    bool bad1 = false;
-    if (two) {
-      lk1 = src[(k + 1) * w2 + k] * dinv;
-      d1 = src[(k + 1) * w2 + (k + 1)] - lk1 * src[k * w2 + (k + 1)];
-      bad1 = !(d1 > 1e-14 * sc[0]);
-      d1inv = bad1 ? 0.0 : 1.0 / d1;
-    }
-    if (tid == 0) sc[1] = fmin(sc[1], (two && !bad1) ? fmin(d, d1) : d);
-    for (int e = tid; e < n * w2; e += nthr) {
-      const int i = e / w2, j = e - i * w2;
-      double v = src[e];
-      const double akj = src[k * w2 + j];
-      if (i > k) v -= (src[i * w2 + k] * dinv) * akj;
-      if (two && !bad1 && i > k + 1) {
-        const double aik1 = src[i * w2 + (k + 1)] - (src[i * w2 + k] * dinv) * src[k * w2 + (k + 1)];
-        const double ak1j = src[(k + 1) * w2 + j] - lk1 * akj;
-        v -= (aik1 * d1inv) * ak1j;
-      }
-      dst[e] = v;
+  const double *Mf = nullptr;  // what the rows are multiplied by, column-major in LDS
+  bool bad = false;
+  int st = 0, route = 0;
+  PPALS_RC_STAMP(0);
+  if (small) {
+    const int nn = n - m;
+    double *Cs = lds, *E = Cs + n * n, *E2 = E + nn * nn, *E3 = E2 + nn * nn, *T1 = E3 + nn * nn,
+           *T2 = T1 + nn * nn;
+    for (int e = tid; e < n * n; e += nthr) {
+      const int i = e % n, j = e / n;
+      Cs[e] = 0.5 * (C1[i + n * j] + C1[j + n * i]);
     }
     lds_barrier();
-    double *t0 = src;
-    src = dst;
-    dst = t0;
-    if (two && bad1) {
-      if (tid == 0) sc[2] = 1.0;
-      break;
+    PPALS_RC_STAMP(1);
+    const double c00 = m ? Cs[0] : 1.0;
+    const double rc00 = 1.0 / c00;
+    double e2 = 0;
+    for (int e = tid; e < nn * nn; e += nthr) {
+      const int a2 = e % nn, b2 = e / nn;
+      double sab = Cs[(a2 + m) + n * (b2 + m)];
+      if (m) sab -= Cs[n * (a2 + m)] * Cs[n * (b2 + m)] * rc00;
+      const double v = (a2 == b2 ? 1.0 : 0.0) - sab;
+      E[e] = v;
+      e2 += v * v;
+    }
+    if (m && tid < nn) sc[32 + tid] = Cs[n * (tid + m)] * rc00;  // t = C1[0, 1:] / c00
+    e2 = block_sum_lds(e2, sc);  // (its barrier also publishes E and t)
+    PPALS_RC_STAMP(2);
+    if (e2 <= kSeriesTol * kSeriesTol && c00 > 0.25 && c00 < 4.0) {  // (uniform)
+      route = 3;
+      constexpr double c0 = 1.0, c1 = 1.0 / 2, c2 = 3.0 / 8, c3 = 5.0 / 16, c4 = 35.0 / 128, c5 = 63.0 / 256,
+                       c6 = 231.0 / 1024, c7 = 429.0 / 2048, c8 = 6435.0 / 32768, c9 = 12155.0 / 65536;
+      // S^-1/2 = A0 + E^3 (A1 + E^3 (A2 + c9 E^3)), A_i = c_3i I + c_3i+1 E + c_3i+2 E^2: four stages
+      for (int e = tid; e < nn * nn; e += nthr) E2[e] = lds_symm_dot(E, E, nn, e % nn, e / nn);
+      lds_barrier();
+      for (int e = tid; e < nn * nn; e += nthr) {
+        const double e3 = lds_symm_dot(E2, E, nn, e % nn, e / nn);
+        E3[e] = e3;
+        T1[e] = ((e % nn == e / nn) ? c6 : 0.0) + c7 * E[e] + c8 * E2[e] + c9 * e3;
+      }
+      lds_barrier();
+      for (int e = tid; e < nn * nn; e += nthr)
+        T2[e] = ((e % nn == e / nn) ? c3 : 0.0) + c4 * E[e] + c5 * E2[e] + lds_symm_dot(E3, T1, nn, e % nn, e / nn);
+      lds_barrier();
+      for (int e = tid; e < nn * nn; e += nthr)  // (T1 is free again: the last stage read T2)
+        T1[e] = ((e % nn == e / nn) ? c0 : 0.0) + c1 * E[e] + c2 * E2[e] + lds_symm_dot(E3, T2, nn, e % nn, e / nn);
+      Mf = T1;  // = S^-1/2 (nn x nn); the barrier that parks the rows of Z below publishes it
+      if (m && tid == 0) sc[20] = 1.0 / sqrt(c00);
     }
   }
-  lds_barrier();
-  const bool bad = sc[2] != 0.0;
-  if (blockIdx.x == 0) {
-    const int st = bad ? 1 : (sc[0] > 4.0 * sc[1] ? 2 : 0);
+  if (!Mf) {
+    const int w2 = 2 * n;
+    double *E0 = lds, *E1 = E0 + n * w2;  // row-major n x 2n: [C | I] being eliminated
+    lds_barrier();
+    for (int e = tid; e < n * w2; e += nthr) {
+      const int i = e / w2, j = e - i * w2;
+      E0[e] = j < n ? 0.5 * (C1[i + n * j] + C1[j + n * i]) : ((j - n == i) ? 1.0 : 0.0);
+    }
+    lds_barrier();
     if (tid == 0) {
-      *status = st;
+      double dmax = 0;
+      for (int k = 0; k < n; k++) dmax = fmax(dmax, E0[k * w2 + k]);
+      sc[17] = dmax;
+      sc[18] = dmax;
+      sc[19] = 0.0;
+    }
+    lds_barrier();
+    double *src = E0, *dst = E1;
+    for (int k = 0; k < n; k += 2) {
+      const double d = src[k * w2 + k];
+      if (!(d > 1e-14 * sc[17])) {  // (uniform)
+        if (tid == 0) sc[19] = 1.0;
+        break;
+      }
+      const double dinv = 1.0 / d;
+      const bool two = k + 1 < n;
+      double d1 = d, d1inv = 0.0, lk1 = 0.0;
+      bool bad1 = false;
+      if (two) {
+        lk1 = src[(k + 1) * w2 + k] * dinv;
+        d1 = src[(k + 1) * w2 + (k + 1)] - lk1 * src[k * w2 + (k + 1)];
+        bad1 = !(d1 > 1e-14 * sc[17]);
+        d1inv = bad1 ? 0.0 : 1.0 / d1;
+      }
+      if (tid == 0) sc[18] = fmin(sc[18], (two && !bad1) ? fmin(d, d1) : d);
+      for (int e = tid; e < n * w2; e += nthr) {
+        const int i = e / w2, j = e - i * w2;
+        double v = src[e];
+        const double akj = src[k * w2 + j];
+        if (i > k) v -= (src[i * w2 + k] * dinv) * akj;
+        if (two && !bad1 && i > k + 1) {
+          const double aik1 = src[i * w2 + (k + 1)] - (src[i * w2 + k] * dinv) * src[k * w2 + (k + 1)];
+          const double ak1j = src[(k + 1) * w2 + j] - lk1 * akj;
+          v -= (aik1 * d1inv) * ak1j;
+        }
+        dst[e] = v;
+      }
+      lds_barrier();
+      double *t0 = src;
+      src = dst;
+      dst = t0;
+      if (two && bad1) {
+        if (tid == 0) sc[19] = 1.0;
+        break;
+      }
+    }
+    lds_barrier();
+    bad = sc[19] != 0.0;
+    st = bad ? 1 : (sc[17] > 4.0 * sc[18] ? 2 : 0);
+    if (!bad) {
+      // src = [D L_1^T | L_1^-1]; M[p][q] = L_1^-1[q][p] / sqrt(d_q) for p <= q -> dst[p + n q]
+      for (int e = tid; e < n * n; e += nthr) {
+        const int p2 = e % n, q = e / n;
+        dst[e] = (p2 <= q) ? src[q * w2 + n + p2] / sqrt(src[q * w2 + q]) : 0.0;
+      }
+      Mf = dst;
+    }
+  }
+  PPALS_RC_STAMP(3);
+  if (blockIdx.x == 0) {
+    if (tid == 0) {
+      status[0] = st;
+      status[1] = route;
       union {
         int w[2];
         double d;
       } u;
       u.w[0] = st;
-      u.w[1] = status[1];
+      u.w[1] = route;
       chk_out[kEigOffStatus] = u.d;
     } else if (tid < 4) {
       chk_out[kEigOffStatus + tid] = chk_src[kEigOffStatus + tid];
     }
   }
   if (!bad) {
-    // src = [D L_1^T | L_1^-1]; R^-1[p][q] = L_1^-1[q][p] / sqrt(d_q) for p <= q -> dst[p + n q]
-    for (int e = tid; e < n * n; e += nthr) {
-      const int p2 = e % n, q = e / n;
-      dst[e] = (p2 <= q) ? src[q * w2 + n + p2] / sqrt(src[q * w2 + q]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = tid + u * nthr;
+      if (e < RB * n) Zs[e] = zreg[u];
     }
     lds_barrier();
-    if (warm == 1.2345e300) out[0] = warm;  // (never: keeps the early loads alive)
-    const int r = tid & 63, part = tid >> 6, nparts = nthr >> 6;
+    const int r = tid % RB, part = tid / RB, nparts = nthr / RB;
     if (r < nrow) {
-      const double *zr = Z + row0 + r;
-      for (int q = part; q < n; q += nparts) {
-        double a = 0;
-        for (int p2 = 0; p2 <= q; p2++) a += zr[rows * p2] * dst[p2 + n * q];
-        out[row0 + r + rows * q] = a;
+      const double *zr = Zs + r;
+      if (route == 3) {
+        // B = [z_0 c00^-1/2 | (Z' - z_0 t) S^-1/2]: q_D stays the first column, the others are cleared of it
+        const int nn = n - m;
+        const double z0 = m ? zr[0] : 0.0;
+        for (int q = part; q < n; q += nparts) {
+          double a;
+          if (m && q == 0) {
+            a = z0 * sc[20];
+          } else {
+            const double *mq = Mf + nn * (q - m);
+            double a0 = 0, a1 = 0;
+            int i = 0;
+            for (; i + 4 <= nn; i += 4) {
+              double x[4], y[4], t[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                x[u] = zr[RB * (i + u + m)];
+                y[u] = mq[i + u];
+                t[u] = m ? sc[32 + i + u] : 0.0;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u += 2) {
+                a0 += (x[u] - t[u] * z0) * y[u];
+                a1 += (x[u + 1] - t[u + 1] * z0) * y[u + 1];
+              }
+            }
+            for (; i < nn; i++) a0 += (zr[RB * (i + m)] - (m ? sc[32 + i] : 0.0) * z0) * mq[i];
+            a = a0 + a1;
+          }
+          out[row0 + r + rows * q] = a;
+        }
+      } else {
+        for (int q = part; q < n; q += nparts) {  // (M upper triangular)
+          const double *mq = Mf + n * q;
+          double a0 = 0, a1 = 0;
+          int p2 = 0;
+          for (; p2 + 8 <= q + 1; p2 += 8) {
+            double x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              x[u] = zr[RB * (p2 + u)];
+              y[u] = mq[p2 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+              a0 += x[u] * y[u];
+              a1 += x[u + 1] * y[u + 1];
+            }
+          }
+          for (; p2 <= q; p2++) a0 += zr[RB * p2] * mq[p2];
+          out[row0 + r + rows * q] = a0 + a1;
+        }
       }
     }
   }
+  PPALS_RC_STAMP(4);
   // Hand-over to the second stream without a packet on this one: the workgroup that finishes last
   // publishes the launch's sequence number in `flag`; the second stream waits for that value
   // (hipStreamWaitValue64). Every workgroup releases its rows first (agent scope: its XCD's L2).
   if (flag) {
-    __threadfence();  // (every wave: its own stores have left for the L2 before the workgroup counts itself done)
+    // (every wave: its own stores are released at agent scope before the workgroup counts itself done)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
-      __threadfence();
-      const unsigned prev = atomicAdd(done_count, 1u);
+      const unsigned prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (prev == gridDim.x - 1) {
-        *done_count = 0;
-        __threadfence_system();
+        __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
+  PPALS_RC_STAMP(5);
 }
 
 // k_chol_m (ONE workgroup, cols x cols work only): the matrix M (cols x cols) with

@@ -393,6 +393,9 @@ def test_deferred_eigen_step_checks(pp, fail_every, handover, tmp_path, monkeypa
     nfail = err.count("NOT accepted (deferred check)")
     assert ndef >= 6, err[-3000:]
     assert (nfail >= 2) if fail_every else (nfail == 0), (fail_every, nfail, err[-3000:])
+    # slowly turning subspaces: the orthonormalising matrix comes from the series of S^-1/2
+    # (k_rmult_chol route 3 = the second status word), not from the elimination
+    assert err.count("chol 03") >= 3, err[-3000:]
     s.close()
     t.close()
     c2.close()
