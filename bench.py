@@ -235,6 +235,54 @@ def _median(x):
     return x[len(x) // 2] if x else None
 
 
+def live_pmc_traffic(args, timeout_s=240):
+    """HBM bytes per launch of the headline's tensor-scan kernel, counted in THIS run: two child runs
+    of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, no trace
+    domain beside them; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md's HBM section prescribes; both
+    in KiB), started BEFORE this process touches the GPU. A few sweeps of the same workload, schedule
+    and storage type; every launch of k_scan_suffix* in the child counts (the placement measurement
+    of session set-up launches the same kernel on the same bytes). Returns (bytes per launch or None,
+    a sentence saying where the figure comes from or why there is none)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "no rocprofv3 on PATH"
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--workload", args.workload, "--dtype", args.dtype,
+                   "--schedule", args.schedule or "msdt", "--no-cpu-baseline", "--no-pmc"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                    stderr=subprocess.STDOUT, timeout=timeout_s)
+            except Exception as e:
+                return None, f"rocprofv3 --pmc {counter} child: {e}"
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} child exited {pr.returncode}"
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_scan_suffix" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no k_scan_suffix rows"
+            got[counter] = (sum(vals) / len(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0),
+                            len(vals))
+    src = ("counted in this run: child passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` of this "
+           f"command (3 sweeps), mean over {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of "
+           f"k_scan_suffix*: fetch {got['FETCH_SIZE'][0]:.4e} B (FETCH_SIZE KiB x 2, gfx950) + write "
+           f"{got['WRITE_SIZE'][0]:.4e} B")
+    return got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0], src
+
+
 def _replayed_traffic(key):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json): replayed, not observed in this run"""
@@ -440,6 +488,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-records", action="store_true",
                     help="skip the cfg3 (PP) / cfg4 (s=400) / cfg5 (Tucker) sub_records at N = 1")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not count HBM bytes with rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -447,6 +497,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # HBM traffic of the scan kernel, counted by child passes under rocprofv3 --pmc BEFORE this
+    # process initialises the GPU (N = 1, the real engine only)
+    live_traffic, live_traffic_src = None, "not collected"
+    # (never from inside a profiled run: a profiler's preloaded library has initialised the GPU
+    # already and its environment would be inherited by the children)
+    profiled = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+                or any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ))
+    if profiled:
+        live_traffic_src = "not collected: this run is itself under a profiler"
+    elif (world == 1 and not args.no_pmc and os.environ.get("PPALS_BENCH_BACKEND") != "hostsim"
+            and os.environ.get("PPALS_FORCE_COMM", "0") != "1"):
+        live_traffic, live_traffic_src = live_pmc_traffic(args)
 
     import numpy as np
     import torch  # first: libppals.so then shares torch's libamdhip64 / librccl
@@ -753,10 +816,11 @@ def main():
         if "roofline" in head:
             rl = dict(head["roofline"])
             rl.update({
-                # `traffic` is null unless PMC counters were read in THIS run (they cannot be, from
-                # inside the process); `traffic_replayed` is the committed figure of the separate
+                # `traffic`: PMC counters of THIS run (child passes under rocprofv3 --pmc, see
+                # live_pmc_traffic) or null; `traffic_replayed` is the committed figure of earlier
                 # rocprofv3 --pmc passes of this same command
-                "traffic": None, "traffic_replayed": traffic, "traffic_source": traffic_src,
+                "traffic": live_traffic, "traffic_source": live_traffic_src,
+                "traffic_replayed": traffic, "traffic_replayed_source": traffic_src,
                 "kernel": ("k_scan_suffix_buf" if (R <= 16 or esz == 8) else "k_scan_suffix_fast")
                           + " (tensor scan: one mode contracted per launch under msdt, a mode half "
                             "under dt; _buf = persistent buffer-load form, one n-tile or fp64 storage; "

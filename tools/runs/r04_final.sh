@@ -8,7 +8,7 @@ CFG5="-model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -pp 0 -maxiter 40 -prec
 tools/gpu_steps.sh \
  "r04F_tests|1100|python -m pytest tests -m gpu -x -q --durations=8" \
  "r04F_bench|600|python bench.py --gpus 1 --steps 20 --warmup 5" \
- "r04F_prof_bench|600|$RP -d gpurun_out/r04F_prof_bench -o r04F -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-config-records" \
+ "r04F_prof_bench|600|$RP -d gpurun_out/r04F_prof_bench -o r04F -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-config-records --no-pmc" \
  "r04F_prof_cfg5|300|$RP -d gpurun_out/r04F_prof_cfg5 -o r04F -- $B/test_ALS $CFG5 -filename gpurun_out/r04F_cfg5_tucker_prof.csv" \
  "r04F_cfg5|200|$B/test_ALS $CFG5 -filename gpurun_out/r04F_cfg5_tucker.csv" \
  "r04F_cfg5_nodefer|200|PPALS_EIG_DEFER=0 $B/test_ALS $CFG5 -filename gpurun_out/r04F_cfg5_tucker_nodefer.csv" \
