@@ -547,11 +547,13 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
     bool live;
   };
   auto decode = [&](int64_t id, Tile &t) {
-    int64_t b = id;
-    const int mtile = (int)(b % n_mtiles);
-    b /= n_mtiles;
-    const int split = (int)(b % nsplit);
-    const int64_t batch = b / nsplit;
+    // (tile ids fit 31 bits — the launcher checks — so the three divisions are 32-bit ones: the 64-bit
+    // forms are ~100 instructions each, four of them per tile beside a main loop of 13 column blocks)
+    unsigned b = (unsigned)id;
+    const int mtile = (int)(b % (unsigned)n_mtiles);
+    b /= (unsigned)n_mtiles;
+    const int split = (int)(b % (unsigned)nsplit);
+    const int64_t batch = b / (unsigned)nsplit;
     const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
     t.live = m0 < M;  // wave-uniform
     t.m = m0 + (int64_t)VEC * j16;
