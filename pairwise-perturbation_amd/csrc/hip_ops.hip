@@ -1774,7 +1774,7 @@ class HipOps : public Ops {
     const int Ji = (int)J;
     const int nblk = (int)std::min<int64_t>(kTailBlocks, (J + 31) / 32);
     const int rows_per = (int)((J + nblk - 1) / nblk);
-    const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && cols <= 64;
+    const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && cols <= kSeriesMax;
     if (deferred) {
       // The tail of a DEFERRED step (kernels_eig.hip.h, k_tn_pair / k_rmult_chol). On the sweep's
       // stream only what the next mode waits for: Z' = [q_D | P Omega_rest], its Gram, B = Z' R^-1
@@ -1803,7 +1803,7 @@ class HipOps : public Ops {
       // step: profiles/r04c_cfg5_timeline_deferred_checks.txt, tools/waitvalue_bench.hip).
       const bool by_flag = own_gram && handover_ok_ && handover_;
       const unsigned long long seq = by_flag ? ++handover_seq_ : 0;
-      const int rb = rmult_chol_rows(cols);
+      const int rb = kRmultRows;
       hipLaunchKernelGGL(k_rmult_chol, dim3((unsigned)((J + rb - 1) / rb)), dim3(rmult_chol_threads(cols)),
                          rmult_chol_lds(cols), st_, Z, J, cols, m,
                          C1, Uout, status, chk,

@@ -1106,7 +1106,7 @@ __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict
 // one-pivot elimination of q_D) is I - E with E = Omega^T (I - P) Omega: the squared sines of the
 // angles between the old and the new subspace — a HOOI sweep of cfg5 turns it by 0.03-0.07 rad,
 // ||E||_F = 5e-4 ... 5e-3.
-//  (a) ||E||_F <= kSeriesTol (and n <= kSeriesMax): S^-1/2 = sum_k c_k E^k, c_k = binom(2k, k) / 4^k, up to
+//  (a) ||E||_F <= kSeriesTol: S^-1/2 = sum_k c_k E^k, c_k = binom(2k, k) / 4^k, up to
 //      E^9 by Paterson-Stockmeyer — E^2, E^3 and two more products: FOUR dependent stages of (n-1)^2
 //      elements instead of ten elimination rounds; remainder 0.18 ||E||^10 < 1e-16.
 //      B = [z_0 c00^-1/2 | (Z' - z_0 t) S^-1/2], t = C1[0, 1:] / c00: q_D stays the first column (the
@@ -1116,8 +1116,9 @@ __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict
 //      triangular: Cholesky QR).
 // Workgroup 0 leaves the step's status words in the slot's check block: 1 = a pivot not safely
 // positive (NOTHING is written to `out` then: the step is not accepted), 2 = pivots spread by more
-// than 4, else 0. Launch: rmult_chol_threads(n) threads, rmult_chol_lds(n) bytes of dynamic LDS,
-// one workgroup per rmult_chol_rows(n) rows (the workgroup's rows of Z wait in LDS for M).
+// than 4, else 0. n <= kSeriesMax (the callers' tails have at most 48 columns: rank + 16 <= 64).
+// Launch: rmult_chol_threads(n) threads, rmult_chol_lds(n) bytes of dynamic LDS, one workgroup per
+// kRmultRows rows (the workgroup's rows of Z wait in LDS for M).
 // flag != nullptr: see the end of the kernel (tools/waitvalue_bench.hip: the producing stream goes on
 // 2-4 us after the launch instead of 7.7 us after launch + event marker, the waiting stream starts
 // 3-4 us after the data is there instead of 11.8).
@@ -1132,9 +1133,9 @@ constexpr double kSeriesTol = 0.03;
 // series are (n-1)^2 elements and a barrier each, a barrier of 16 waves costs ~0.4 us; the elimination of
 // many columns wants the threads)
 __host__ __device__ inline int rmult_chol_threads(int n) { return n <= 32 ? 512 : 1024; }
-__host__ __device__ inline int rmult_chol_rows(int n) { return n <= kSeriesMax ? 64 : 32; }
+constexpr int kRmultRows = 64;  // rows of Z per workgroup
 __host__ __device__ inline size_t rmult_chol_lds(int n) {
-  return sizeof(double) * ((n <= kSeriesMax ? 6 : 4) * (size_t)n * n + (size_t)rmult_chol_rows(n) * n + 96);
+  return sizeof(double) * (6 * (size_t)n * n + (size_t)kRmultRows * n + 96);
 }
 #ifndef PPALS_RC_STAMP  // (tools/rmult_chol_bench.hip defines it: phase stamps of workgroup 0)
 #define PPALS_RC_STAMP(k)
@@ -1173,11 +1174,11 @@ __global__ __launch_bounds__(1024) void k_rmult_chol(const double *__restrict__ 
                                                      unsigned long long seq) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int RB = rmult_chol_rows(n);  // rows of Z per workgroup
+  constexpr int RB = kRmultRows;
   const int64_t row0 = (int64_t)blockIdx.x * RB;
   const int nrow = (int)min((int64_t)RB, rows - row0);
-  const bool small = n <= kSeriesMax && n - m >= 4;
-  double *sc = lds + (n <= kSeriesMax ? 6 : 4) * n * n;  // [0..16] reductions | [17..19] | t[64] from 32
+  const bool small = n - m >= 4;
+  double *sc = lds + 6 * n * n;  // [0..16] reductions | [17..19] | t[64] from 32
   double *Zs = sc + 96;                                   // RB x n: this workgroup's rows of Z
   // this workgroup's rows of Z: requested now (<= 8 per thread), parked in LDS once M is there
   double zreg[8];

@@ -275,6 +275,45 @@ def test_core_rank_above_64_stays_on_the_projector_route(pp, lens, ranks, inner,
     c2.close()
 
 
+@pytest.mark.parametrize("lens,ranks,inner,route", [
+    ([200, 44, 40], [40, 8, 6], [60, 12, 10], "chol 03"),
+    ([200, 44, 40], [48, 8, 8], [70, 12, 12], "chol 03"),   # the widest tail the fused step takes (rank + 16 <= 64)
+])
+def test_deferred_tail_between_32_and_64_columns(pp, lens, ranks, inner, route, tmp_path, monkeypatch, capfd):
+    """The deferred tail's one-launch orthonormalisation (k_rmult_chol) beyond the 21 columns of the
+    benchmark: 33 to 48 columns run with 1024 threads. 12 HOOI sweeps on a mode of 200 rows at core
+    ranks 40 and 48 against numpy's LAPACK reading: projectors, orthonormal factors, ||core||; the step log must show
+    deferred checks accepted on the route in question and no full solver after the start."""
+    import numpy_ref as NR
+    V = _slow_decay_tensor(lens, inner, [0.93, 0.8, 0.8], 33, 1e-5)
+    W0, c0 = NR.tucker_hosvd(V, ranks)
+    W_ref, core_ref = NR.tucker_hooi(V, W0, 12)
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    s.set_factors(W0)
+    s.set_core(c0)
+    capfd.readouterr()
+    s.sweeps_dt(12)
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
+        assert relerr(proj(a), proj(b)) < 1e-6, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    big = [ln for ln in err.splitlines() if f"rank {ranks[0]}:" in ln]
+    ok = [ln for ln in big if "accepted (deferred check)" in ln and "NOT" not in ln]
+    assert len(ok) >= 4, "\n".join(big[-20:])
+    assert sum(route in ln for ln in ok) >= 3, "\n".join(ok[-20:])
+    assert not any("full solver" in ln for ln in big[2:]), "\n".join(big)
+    s.close()
+    t.close()
+    c2.close()
+
+
 def test_core_rank_above_64_on_a_flat_spectrum(pp, tmp_path, monkeypatch, capfd):
     """A noise tensor (`-tensor r2`: U(0.5, 1), test_ALS.cxx:272) at core rank 70: below the mean
     component the Gram's spectrum is a flat bulk, Ritz values cannot place a shift, and the cold start

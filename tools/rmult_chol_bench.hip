@@ -80,7 +80,11 @@ int main(int argc, char **argv) {
   CK(hipFuncSetAttribute((const void *)k_rmult_chol, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  const int rb = rmult_chol_rows(n);
+  const int rb = kRmultRows;
+  if (n > kSeriesMax) {
+    printf("n <= %d\n", kSeriesMax);
+    return 1;
+  }
   const size_t lds = rmult_chol_lds(n);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
