@@ -247,7 +247,10 @@ class HipOps : public Ops {
     const int64_t npart = (int64_t)n_mtiles * nchunk;
     if (MODE != 0) part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
     prof_begin(1, (double)M * K * sizeof(TV));
-    if (RB <= 4)
+    if (RB <= 3)
+      hipLaunchKernelGGL((k_rank_mfma<TV, MODE, 3>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
+                         RB, per, nkb, part);
+    else if (RB <= 4)
       hipLaunchKernelGGL((k_rank_mfma<TV, MODE, 4>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
                          RB, per, nkb, part);
     else

@@ -939,8 +939,8 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
     double na[MAXRB];
     const int kn = min(kb + 1, kb1 - 1);
     PPALS_RANK_LOAD(kn, nv, na);
-    f64x4 d[VEC];
-    if constexpr (MODE != 2) {
+    if constexpr (MODE == 0) {
+      f64x4 d[VEC];
 #pragma unroll
       for (int jj = 0; jj < VEC; jj++) d[jj] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -951,27 +951,39 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
             d[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[rb], bq[jj][rb], d[jj], 0, 0, 0);
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int64_t k = (int64_t)kb * 16 + 4 * u + g;
-      const bool ok = k < K && row_ok;  // beyond K the loads were clamped: excluded here
-      if constexpr (MODE == 0) {
-        if (ok) {
+      for (int u = 0; u < 4; u++) {
+        const int64_t k = (int64_t)kb * 16 + 4 * u + g;
+        if (k < K && row_ok) {
           vec o;
 #pragma unroll
           for (int jj = 0; jj < VEC; jj++) o[jj] = (TV)d[jj][u];
           *reinterpret_cast<vec *>(V + m + k * M) = o;
         }
-      } else {
-        double e2 = 0.0;
+      }
+    } else {
+      // two rows of the lane at a time: two model accumulators live instead of VEC (16 registers
+      // fewer: with the three-step instantiation the residual of R <= 12 runs 4 waves per SIMD)
 #pragma unroll
-        for (int jj = 0; jj < VEC; jj++) {
-          double e = (double)cv[u][jj];
-          if constexpr (MODE == 1) e -= d[jj][u];
-          e2 += e * e;
+      for (int jp = 0; jp < VEC; jp += 2) {
+        f64x4 d0 = f64x4{0.0, 0.0, 0.0, 0.0}, d1 = d0;
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int rb = 0; rb < MAXRB; rb++) {
+            if (rb < RB) {
+              d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[rb], bq[jp][rb], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[rb], bq[jp + 1][rb], d1, 0, 0, 0);
+            }
+          }
         }
-        acc += ok ? e2 : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int64_t k = (int64_t)kb * 16 + 4 * u + g;
+          const bool ok = k < K && row_ok;  // beyond K the loads were clamped: excluded here
+          const double e0 = (double)cv[u][jp] - d0[u], e1 = (double)cv[u][jp + 1] - d1[u];
+          const double e2 = e0 * e0 + e1 * e1;
+          acc += ok ? e2 : 0.0;
+        }
       }
     }
 #pragma unroll
