@@ -223,16 +223,9 @@ class HipOps : public Ops {
     constexpr int VEC = ScanTraits<TV>::VEC;
     if (R > 32 || M % VEC != 0 || M < VEC || (((uintptr_t)V) & 15) != 0 || K < 1)
       return false;
-    const int RB = MODE == 2 ? 1 : (R + 3) / 4;
     const int64_t nkb64 = (K + 15) / 16;
     if (nkb64 > 0x7fffffff) return false;
     const int nkb = (int)nkb64;
-    double *Ppk = nullptr;
-    if (MODE != 2) {
-      Ppk = (double *)ensure(ws_pack_, ws_pack_sz_, sizeof(double) * (size_t)nkb * RB * 64);
-      hipLaunchKernelGGL(k_rank_pack, dim3(grid_for((int64_t)nkb * RB * 64, 256)), dim3(256), 0, st_,
-                         P, K, R, RB, nkb, Ppk);
-    }
     const int64_t n_mtiles = (M + 64 * VEC - 1) / (64 * VEC);
     // enough workgroups to fill the chip several times, chunks of >= 8 column blocks
     // (workgroups per CU x 4 .. 128 instead of 16: 1.60-1.73 ms for the whole [diffV] call at cfg2,
@@ -242,12 +235,44 @@ class HipOps : public Ops {
     per = std::max(per, std::min(nkb, 8));
     nchunk = (nkb + per - 1) / per;
     if (n_mtiles > 0x7fffffff || nchunk > 65535) return false;
+    // residual: a remainder of 1 or 2 ranks goes to the vector pipe instead of a padded matrix-core
+    // step (kernels_scan.hip.h, REM), its P columns in LDS — if a chunk's share of them fits
+    // (measured, tools/k10_probe.py at cfg2, profiles/r04I_k10_probe.txt: R = 10 1.28 -> 1.26 ms, R = 9
+    // 1.17 ms, R = 13 1.38 ms against ~1.5 ms with a padded fourth step; two ranks beside three or four
+    // steps — R = 14: 1.63 ms, R = 18: 1.78 ms — lose to padding: 2 waves per SIMD)
+    int rem = (MODE == 1 && R > 4 && R <= 17 && (R % 4 == 1 || (R % 4 == 2 && R <= 10))) ? R % 4 : 0;
+    if (sizeof(double) * (size_t)per * 16 * rem > 48 * 1024) rem = 0;
+    const int RB = MODE == 2 ? 1 : (R - rem + 3) / 4;
+    double *Ppk = nullptr;
+    if (MODE != 2) {
+      Ppk = (double *)ensure(ws_pack_, ws_pack_sz_, sizeof(double) * (size_t)nkb * RB * 64);
+      hipLaunchKernelGGL(k_rank_pack, dim3(grid_for((int64_t)nkb * RB * 64, 256)), dim3(256), 0, st_,
+                         P, K, R - rem, RB, nkb, Ppk);
+    }
     dim3 grid((unsigned)n_mtiles, (unsigned)nchunk);
     double *part = nullptr;
     const int64_t npart = (int64_t)n_mtiles * nchunk;
     if (MODE != 0) part = (double *)ensure(ws_part_, ws_part_sz_, npart * sizeof(double));
     prof_begin(1, (double)M * K * sizeof(TV));
-    if (RB <= 3)
+    const size_t lds_rem = sizeof(double) * (size_t)per * 16 * rem;
+    bool done = false;
+    if constexpr (MODE == 1) {
+      if (rem) {
+#define PPALS_RANK_REM(MRB, RM)                                                                        \
+  hipLaunchKernelGGL((k_rank_mfma<TV, 1, MRB, RM>), grid, dim3(256), lds_rem, st_, (TV *)V, M, K, Q, Ppk, R, \
+                     RB, per, nkb, part, P)
+        if (RB <= 2) {
+          if (rem == 1) PPALS_RANK_REM(2, 1);
+          else PPALS_RANK_REM(2, 2);
+        } else {
+          PPALS_RANK_REM(4, 1);
+        }
+#undef PPALS_RANK_REM
+        done = true;
+      }
+    }
+    if (done) {
+    } else if (RB <= 3)
       hipLaunchKernelGGL((k_rank_mfma<TV, MODE, 3>), grid, dim3(256), 0, st_, (TV *)V, M, K, Q, Ppk, R,
                          RB, per, nkb, part);
     else if (RB <= 4)

@@ -886,16 +886,24 @@ __global__ __launch_bounds__(256) void k_scan_prefix_fast(
 // 46 TFLOP/s this instruction sustains on an MI355X (tools/mfma64_rate.hip; not the data sheet's
 // 78.6) the pipe is busy 0.83 ms per 6.4 GB at R = 10, beside 0.96 ms for the read alone — the
 // kernel is bound by both (1.31 ms). Needs M % VEC == 0, R <= 32.
-template <typename TV, int MODE, int MAXRB>
+// REM (residual only): the last REM = R mod 4 (1 or 2) ranks are NOT padded to a fourth contraction step
+// on the matrix cores — a step costs 4 instructions of ~110 cycles per 1024 elements — but added by REM
+// multiply-adds per element on the vector pipe, their P columns waiting in LDS (16 * kb_per_chunk * REM
+// doubles of dynamic LDS), their Q columns in registers: R = 10 is two steps + two ranks instead of three
+// steps (the matrix pipe 0.57 ms instead of 0.86 ms per 6.4 GB). RB counts the matrix-core steps only.
+template <typename TV, int MODE, int MAXRB, int REM = 0>
 __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M, int64_t K,
                                                    const double *__restrict__ Q,
                                                    const double *__restrict__ Ppk, int R, int RB,
                                                    int kb_per_chunk, int nkb,
-                                                   double *__restrict__ partial) {
+                                                   double *__restrict__ partial,
+                                                   const double *__restrict__ Praw = nullptr) {
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   constexpr int VEC = TR::VEC;  // MAXRB: 4-wide contraction steps held in registers (R <= 4*MAXRB)
+  static_assert(REM == 0 || MODE == 1, "the vector-pipe remainder belongs to the residual");
   __shared__ double red[4];
+  extern __shared__ double rank_ps[];  // REM > 0: P[k, R - REM + t] at [(k - 16 kb0) * REM + t]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j16 = lane & 15;
   const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * VEC);
@@ -911,8 +919,20 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
 #pragma unroll
       for (int rb = 0; rb < MAXRB; rb++) {
         const int r = 4 * rb + g;
-        bq[jj][rb] = (rb < RB && r < R && live) ? Q[m_ld + jj + M * (int64_t)r] : 0.0;
+        bq[jj][rb] = (rb < RB && r < R - REM && live) ? Q[m_ld + jj + M * (int64_t)r] : 0.0;
       }
+  }
+  double qrem[VEC][REM > 0 ? REM : 1];
+  if constexpr (REM > 0) {
+#pragma unroll
+    for (int jj = 0; jj < VEC; jj++)
+#pragma unroll
+      for (int t = 0; t < REM; t++) qrem[jj][t] = live ? Q[m_ld + jj + M * (int64_t)(R - REM + t)] : 0.0;
+    for (int e = threadIdx.x; e < (kb1 - kb0) * 16 * REM; e += blockDim.x) {
+      const int64_t k = (int64_t)kb0 * 16 + e / REM;
+      rank_ps[e] = k < K ? Praw[k + K * (int64_t)(R - REM + e % REM)] : 0.0;
+    }
+    __syncthreads();
   }
   double acc = 0.0;
   TV *__restrict__ vp = V + m_ld;
@@ -980,7 +1000,15 @@ __global__ __launch_bounds__(256) void k_rank_mfma(TV *__restrict__ V, int64_t M
         for (int u = 0; u < 4; u++) {
           const int64_t k = (int64_t)kb * 16 + 4 * u + g;
           const bool ok = k < K && row_ok;  // beyond K the loads were clamped: excluded here
-          const double e0 = (double)cv[u][jp] - d0[u], e1 = (double)cv[u][jp + 1] - d1[u];
+          double e0 = (double)cv[u][jp] - d0[u], e1 = (double)cv[u][jp + 1] - d1[u];
+          if constexpr (REM > 0) {
+#pragma unroll
+            for (int t = 0; t < REM; t++) {
+              const double pk = rank_ps[((kb - kb0) * 16 + 4 * u + g) * REM + t];
+              e0 -= qrem[jp][t] * pk;
+              e1 -= qrem[jp + 1][t] * pk;
+            }
+          }
           const double e2 = e0 * e0 + e1 * e1;
           acc += ok ? e2 : 0.0;
         }

@@ -792,6 +792,9 @@ def test_long_run_factor_parity(pp, ctx, lens, R, dtype):
 @pytest.mark.parametrize("lens,R", [([8, 8, 8, 8], 3), ([12, 6, 7, 5], 10), ([20, 14, 9, 11], 20),
                                     ([4, 9, 3, 7], 32), ([68, 4, 5, 3], 1), ([16, 18, 50], 7),
                                     ([6, 10, 4, 3, 5, 2], 5),
+                                    # the residual's last one or two ranks on the vector pipe beside
+                                    # 1..4 matrix-core steps (k_rank_mfma<.., REM>): R = 6, 9, 13, 17
+                                    ([8, 7, 9], 6), ([7, 9, 8, 6], 9), ([9, 11, 10, 8], 13), ([20, 19, 18], 17),
                                     # ranks above 32: the rank-split residual (k_rank_split), with
                                     # 4 / 8 / 16 rank blocks per wave and ragged last blocks
                                     ([40, 36, 34, 33], 33), ([70, 66, 65], 64), ([120, 101, 103], 100),
