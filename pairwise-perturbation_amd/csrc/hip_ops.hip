@@ -112,6 +112,7 @@ class HipOps : public Ops {
   ~HipOps() override {
     hipSetDevice(dev_);
     hipStreamSynchronize(st_);
+    if (st2_) hipStreamSynchronize(st2_);  // (checks of deferred steps still read the slots' buffers)
     for (auto &ev : events_) {
       hipEventDestroy(ev.a);
       hipEventDestroy(ev.b);
@@ -1573,6 +1574,7 @@ class HipOps : public Ops {
   // c x c route and its s x s fallback inside one factor update, which use different slots of the
   // block) never see each other's bases, gaps or eigenvalue scales.
   void free_lazy(EigState &es) {
+    if (st2_) hipStreamSynchronize(st2_);  // (nothing on the second stream reads the slot's buffers any more)
     if (es.Hd) hipFree(es.Hd);
     if (es.Yd) hipFree(es.Yd);
     if (es.evd) hipFree(es.evd);
