@@ -1806,7 +1806,7 @@ class HipOps : public Ops {
     const int rows_per = (int)((J + nblk - 1) / nblk);
     const bool deferred = lazy && host_chk && rounds == 1 && m <= 1 && cols <= kSeriesMax;
     if (deferred) {
-      // The tail of a DEFERRED step (kernels_eig.hip.h, k_tn_pair / k_rmult_chol). On the sweep's
+      // The tail of a DEFERRED step (kernels_eig.hip.h, k_tn_gram / k_rmult_chol). On the sweep's
       // stream only what the next mode waits for: Z' = [q_D | P Omega_rest], its Gram, B = Z' R^-1
       // straight into the caller's buffer — three launches. Everything the CHECKS read (G B,
       // H = B^T G B, the subspace residual, the Jacobi of H) is formed from B on the second stream,
@@ -1825,8 +1825,8 @@ class HipOps : public Ops {
       // (a Jacobi of this slot that is still in flight — a step that was not accepted — must be through
       // with the slot's buffers before they are written again)
       if (es.jacobi_launched) HIP_CHECK(hipStreamWaitEvent(st_, es.ev_done, 0));
-      hipLaunchKernelGGL(k_tn_pair, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, Z, (const double *)nullptr,
-                         J, cols, C1, (double *)nullptr, pe2, ptr_, np, chk, es.chkd);
+      hipLaunchKernelGGL(k_tn_gram, dim3((cols * cols + 15) / 16 + 1), dim3(1024), 0, st_, Z, J, cols, C1, pe2, ptr_,
+                         np, chk, es.chkd);
       // The second stream takes over from the kernel itself when it reads the slot's own Gram: the
       // last workgroup of k_rmult_chol publishes a sequence number, the second stream waits for the
       // value — no marker packet on the sweep's stream (an event record + wait costs it 6-8 us per

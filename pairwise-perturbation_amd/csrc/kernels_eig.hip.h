@@ -1043,16 +1043,15 @@ __global__ void k_tn_two(const double *__restrict__ Z, const double *__restrict_
 }
 
 // ---- the tail of a deferred step (round 4). On the sweep's stream only what the NEXT mode waits for:
-//   Z' = [q_D | P Omega_rest]  (thin GEMM)  |  k_tn_pair: C1 = Z'^T Z'  |  k_rmult_chol: B = Z' R^-1
+//   Z' = [q_D | P Omega_rest]  (thin GEMM)  |  k_tn_gram: C1 = Z'^T Z'  |  k_rmult_chol: B = Z' M
 // With the deflated vector in front of Z', ONE Cholesky QR of all columns keeps it (the first column
 // of a QR is the first column, normalised) and clears the others of it. Everything the CHECKS read —
 // G B, H = B^T G B, the residual, the Jacobi of H — is formed from B on the second stream, from the
 // slot's own copy of the Gram (Ops::eig_gram), beside the next mode's tensor scan.
-// k_tn_pair: C1[p + cols q] = z_p^T z_q (and, with GZ, C2[p + cols q] = z_p^T (G z)_q) — one wave per
-// entry. The last workgroup instead adds up the sign iteration's check sums (np partials each) into
-// chk_out[0], chk_out[1] and carries the step's norm word [8] over into the slot's check block.
-__global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict__ GZ, int64_t rows, int cols,
-                          double *__restrict__ C1, double *__restrict__ C2,
+// k_tn_gram: C1[p + cols q] = z_p^T z_q — one wave per entry. The last workgroup instead adds up the
+// sign iteration's check sums (np partials each) into chk_out[0], chk_out[1] and carries the step's norm
+// word [8] over into the slot's check block.
+__global__ void k_tn_gram(const double *__restrict__ Z, int64_t rows, int cols, double *__restrict__ C1,
                           const double *__restrict__ part_e2, const double *__restrict__ part_tr, int np,
                           const double *__restrict__ chk_src, double *__restrict__ chk_out) {
   const int lane = threadIdx.x & 63;
@@ -1077,23 +1076,10 @@ __global__ void k_tn_pair(const double *__restrict__ Z, const double *__restrict
   for (int e = wid; e < cols * cols; e += nw) {
     const int p = e % cols, q = e / cols;
     const double *a = Z + rows * p, *b = Z + rows * q;
-    double s1 = 0, s2 = 0;
-    if (GZ) {
-      const double *c = GZ + rows * q;
-      for (int64_t i = lane; i < rows; i += 64) {
-        const double x = a[i];
-        s1 += x * b[i];
-        s2 += x * c[i];
-      }
-      s2 = wave_sum(s2);
-    } else {
-      for (int64_t i = lane; i < rows; i += 64) s1 += a[i] * b[i];
-    }
+    double s1 = 0;
+    for (int64_t i = lane; i < rows; i += 64) s1 += a[i] * b[i];
     s1 = wave_sum(s1);
-    if (lane == 0) {
-      C1[e] = s1;
-      if (GZ) C2[e] = s2;
-    }
+    if (lane == 0) C1[e] = s1;
   }
 }
 // k_rmult_chol: B = Z M with M^T (Z^T Z) M = I — the small factorisation INSIDE the multiplication:

@@ -1,5 +1,5 @@
 // Phase stamps of k_rmult_chol (tools only). A chain like the tail of a deferred eigen-step: a thin
-// product writes Z (J x n), k_tn_pair its Gram, k_rmult_chol B = Z M; repeated, timed by events, and the
+// product writes Z (J x n), k_tn_gram its Gram, k_rmult_chol B = Z M; repeated, timed by events, and the
 // phases of workgroup 0 (thread 0) by the 100 MHz clock: 0 entry | 1 Gram in LDS | 2 ||E|| known |
 // 3 M ready | 4 rows multiplied and stored | 5 hand-over done.
 // build: hipcc --offload-arch=gfx950 -O3 -o rmult_chol_bench tools/rmult_chol_bench.hip
@@ -103,8 +103,8 @@ int main(int argc, char **argv) {
       CK(hipEventRecord(e0, st));
       for (int r = 0; r < reps; r++) {
         hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, Z0, Z, (int64_t)J * n);  // (another kernel wrote Z)
-        hipLaunchKernelGGL(k_tn_pair, dim3((n * n + 15) / 16 + 1), dim3(1024), 0, st, Z, (const double *)nullptr,
-                           (int64_t)J, n, C1, (double *)nullptr, chk, chk, 0, chk, chk + 2048);
+        hipLaunchKernelGGL(k_tn_gram, dim3((n * n + 15) / 16 + 1), dim3(1024), 0, st, Z, (int64_t)J, n, C1, chk, chk, 0, chk,
+                           chk + 2048);
         hipLaunchKernelGGL(k_rmult_chol, dim3((J + rb - 1) / rb), dim3(threads ? threads : rmult_chol_threads(n)), lds, st, Z, (int64_t)J, n, 1, C1, out,
                            status, chk, chk + 2048, (unsigned *)(hand + 1), hand, ++seq);
       }
@@ -125,7 +125,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < J; i++) d += hout[(size_t)J * a + i] * hout[(size_t)J * b + i];
         worst = std::max(worst, std::fabs(d - (a == b ? 1.0 : 0.0)));
       }
-    printf("J=%d n=%d threads %d %s: copy + k_tn_pair + k_rmult_chol %.2f us per round; status %d route %d; max |B^T B - I| %.2e\n", J,
+    printf("J=%d n=%d threads %d %s: copy + k_tn_gram + k_rmult_chol %.2f us per round; status %d route %d; max |B^T B - I| %.2e\n", J,
            n, threads ? threads : rmult_chol_threads(n), variant ? "one column pair turned by 0.4" : "columns turned by the angle", 1e3 * ms / reps, hst[0], hst[1],
            worst);
     printf("   phases of workgroup 0 (us): Gram in LDS %.2f | ||E|| %.2f | M %.2f | multiply + store %.2f | hand-over %.2f\n",
