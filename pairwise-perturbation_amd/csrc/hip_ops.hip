@@ -1193,7 +1193,10 @@ class HipOps : public Ops {
       // K13 at size (the HOSVD Grams of the full tensor): the tiled SYRK, upper triangle only
       const int nt = (int)((J + 63) / 64);
       const int ntri = nt * (nt + 1) / 2;
-      int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)ncu_ * 3 + ntri - 1) / ntri),
+      // (three workgroups per CU are resident — 134 registers, 40 KB of LDS —: the split is rounded DOWN
+      // so that tiles x splits fit one round; rounded up, cfg5's 28 x 28 = 784 workgroups ran as 768 +
+      // 16, i.e. two rounds: 1.10 ms per Gram)
+      int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)ncu_ * 3) / ntri),
                                           std::max<int64_t>(1, C / 1024));
       nsplit = std::min(nsplit, 512);
       int64_t per = ((C + nsplit - 1) / nsplit + 31) / 32 * 32;
