@@ -46,3 +46,50 @@ def test_pmc_traffic_applies_the_fetch_correction(tmp_path):
     write = [ln for ln in lines if "WRITE_SIZE" in ln][0].split()
     assert float(fetch[-1]) == 2000 * 1024 * 2.0 and int(fetch[-3]) == 2
     assert float(write[-1]) == 500 * 1024.0
+
+
+def test_bench_live_pmc_traffic_units(tmp_path, monkeypatch):
+    """bench.py's live_pmc_traffic(): two child passes under `rocprofv3 --pmc` (one counter each, no
+    trace domain beside it), every k_scan_suffix* dispatch of the child counted, FETCH_SIZE (KiB)
+    doubled on gfx950 and WRITE_SIZE (KiB) taken as is — checked with a stand-in for the child that
+    writes what the profiler would."""
+    import argparse
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    def fake_run(cmd, cwd=None, env=None, stdout=None, stderr=None, timeout=None):
+        calls.append(cmd)
+        counter = cmd[cmd.index("--pmc") + 1]
+        out = cmd[cmd.index("-d") + 1]
+        os.makedirs(os.path.join(out, "host", "123"), exist_ok=True)
+        val = {"FETCH_SIZE": 3155000.0, "WRITE_SIZE": 312500.0}[counter]
+        rows = ["Kernel_Name,Counter_Name,Counter_Value",
+                f'"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*, long)",{counter},{val}',
+                f'"void ppals::k_scan_suffix_buf<float, 1, 5>(float const*, long)",{counter},{val + 2.0}',
+                f'"void ppals::k_mttv_vec<float>(float const*)",{counter},999999.0']
+        with open(os.path.join(out, "host", "123", "pmc_counter_collection.csv"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        return argparse.Namespace(returncode=0, stdout=b"")
+
+    import shutil
+    import subprocess as sp
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    monkeypatch.setattr(sp, "run", fake_run)
+    args = argparse.Namespace(workload="cp4_s200_r10", dtype="f32", schedule=None)
+    traffic, src = bench.live_pmc_traffic(args)
+    assert len(calls) == 2
+    for cmd, counter in zip(calls, ("FETCH_SIZE", "WRITE_SIZE")):
+        assert cmd[1:3] == ["--pmc", counter]
+        assert not any(a in cmd for a in ("--kernel-trace", "--sys-trace", "--hip-trace", "--stats"))
+        # the program itself follows `--`: the interpreter, then this script, never a shell or `env`
+        tail = cmd[cmd.index("--") + 1:]
+        assert tail[0] == sys.executable and tail[1].endswith("bench.py") and "--no-pmc" in tail
+    want = (3155001.0 * 1024.0 * 2.0) + (312501.0 * 1024.0)
+    assert abs(traffic - want) < 1.0, (traffic, want)
+    assert "FETCH_SIZE KiB x 2" in src and "2 / 2 launches" in src
+    # no profiler on PATH: no figure, and the reason is said
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    traffic, src = bench.live_pmc_traffic(args)
+    assert traffic is None and "rocprofv3" in src
