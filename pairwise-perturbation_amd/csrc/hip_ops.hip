@@ -1606,6 +1606,14 @@ class HipOps : public Ops {
       HIP_CHECK(hipMalloc(&handover_, 16));
       HIP_CHECK(hipMemset(handover_, 0, 16));
       HIP_CHECK(hipDeviceSynchronize());
+      // (a runtime without stream memory operations: the event hand-over takes its place. The probe is
+      // a wait that is satisfied at once.)
+      if (handover_ok_ &&
+          (hipStreamWaitValue64(st2_, handover_, 0, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull) != hipSuccess ||
+           hipStreamSynchronize(st2_) != hipSuccess)) {
+        (void)hipGetLastError();
+        handover_ok_ = false;
+      }
     }
     if (!es.Hd) {
       HIP_CHECK(hipMalloc(&es.Hd, sizeof(double) * 64 * 64));
