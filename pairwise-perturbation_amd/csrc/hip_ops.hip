@@ -83,10 +83,12 @@ class HipOps : public Ops {
     HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_mode_update<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (const char *v = getenv("PPALS_FORCE_JACOBI")) force_jacobi_ = atoi(v);
-    if (const char *v = getenv("PPALS_EIG_FAST")) eig_fast_ = atoi(v);
+    if (const char *v = getenv("PPALS_EIG_FAST")) {
+      eig_fast_ = atoi(v);  // 0: always the full solver; 2: warm steps as usual, cold starts on the full solver
+      eig_cold_ = eig_fast_ != 2;
+    }
     if (const char *v = getenv("PPALS_EIG_DEBUG")) eig_debug_ = atoi(v);
     if (const char *v = getenv("PPALS_EIG_SIGMA_SCALE")) eig_sigma_scale_ = atof(v);
-    if (const char *v = getenv("PPALS_EIG_COLD")) eig_cold_ = atoi(v);
     if (const char *v = getenv("PPALS_FORCE_EIGINV")) force_eiginv_ = atoi(v);
     HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_rinv,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
@@ -2698,7 +2700,7 @@ class HipOps : public Ops {
   unsigned long long handover_seq_ = 0;
   int eig_defer_fail_ = 0;  // PPALS_EIG_DEFER_FAIL=n (tests): every n-th deferred check is reported as failed
   int eig_defer_count_ = 0;
-  int eig_cold_ = 1;  // PPALS_EIG_COLD=0: cold starts go straight to the full solver (A/B, tests)
+  int eig_cold_ = 1;  // PPALS_EIG_FAST=2: cold starts go straight to the full solver (A/B, tests)
   void *ws_cold_ = nullptr;
   size_t ws_cold_sz_ = 0;
   double eig_sigma_scale_ = 0;  // PPALS_EIG_SIGMA_SCALE=f: shift = f * (estimate of the next eigenvalue) (tests)

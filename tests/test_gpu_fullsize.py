@@ -285,14 +285,14 @@ def _eig_lines(err):
 @pytest.mark.parametrize("dtype,env", [
     (0, {}), (1, {}),
     (1, {"PPALS_EIG_FAST": "0"}),      # every eigen-step on the full solver
-    (1, {"PPALS_EIG_COLD": "0"}),      # cold starts on the full solver, warm steps on the projector
+    (1, {"PPALS_EIG_FAST": "2"}),      # cold starts on the full solver, warm steps on the projector
 ])
 def test_cfg5_tucker_full_size_r2(pp, cfg5_r2, dtype, env, tmp_path, monkeypatch, capfd):
     """configs[4] on its own input: Tucker order-3 s = 400, core 20^3, `-tensor r2`; hosvd +
     alsTucker_DT (als_Tucker.cxx:12-70,240-424, common.cxx:205-223) against the oracle at full
     size: the HOSVD factors as subspaces (to what each Gram's gap allows), ||core||, every CSV row
     of 6 HOOI sweeps, the final factors and core; with the spectral-projector eigen-step (default)
-    and with it switched off (`PPALS_EIG_FAST=0`, `PPALS_EIG_COLD=0`). The log of the default run
+    and with it switched off (`PPALS_EIG_FAST=0`, `PPALS_EIG_FAST=2`). The log of the default run
     must show projector steps — cold starts included — and no full eigen-decomposition inside the
     HOOI loop."""
     c = cfg5_r2
