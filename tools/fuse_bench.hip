@@ -52,7 +52,7 @@ __global__ void k_zero_tail(float *P, int nblk, int K) {
 }
 
 // float, one n-tile, non-temporal result stores, slab-aligned tiles
-template <int GROUPED, int FUSE>
+template <int GROUPED, int FUSE, int STORE = 0>
 __global__ __launch_bounds__(256) void k_scan_fused(const float *__restrict__ V, int64_t M, int64_t K,
                                                     const float *__restrict__ P, int nkb, float *__restrict__ out,
                                                     int ncols, int64_t slab_rows, int nslab, int nab, int ncg,
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_scan_fused(const float *__restrict__ V,
   typedef f32x4 vec;
   constexpr int VEC = 4, KB = 16, FLUSH = 4;
   __shared__ double Ts[FUSE ? 4 : 1][FUSE ? 16 : 1][4][16];
+  __shared__ float Xs[STORE ? 16 : 1][STORE ? 256 : 1];  // STORE: the workgroup's result tile, column by column
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j16 = lane & 15;
   const int voffP = (int)((g * 16 + j16) * VEC * (int)sizeof(float));
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_scan_fused(const float *__restrict__ V,
   const int64_t ntiles = (int64_t)nab * nslab;
   struct Tile {
     int64_t m;
-    int voff, c;
+    int voff, c, ab;
     bool live;
   };
   auto decode = [&](int64_t k, Tile &t) -> bool {  // k-th tile of this workgroup
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void k_scan_fused(const float *__restrict__ V,
     const int64_t r0 = ((int64_t)ab * 4 + wave) * (16 * VEC);
     t.live = r0 < slab_rows;
     t.c = c;
+    t.ab = ab;
     t.m = (int64_t)c * slab_rows + (t.live ? r0 : 0) + (int64_t)VEC * j16;
     t.voff = (int)(((int64_t)g * M + t.m) * 4);
     return true;
@@ -159,7 +161,31 @@ __global__ __launch_bounds__(256) void k_scan_fused(const float *__restrict__ V,
           acc[a][r] = 0;
         }
     }
-    if (cur.live) {
+    if constexpr (STORE == 1) {
+      // (the four waves of the workgroup meet: a column of the tile leaves as ONE 1 KB store instruction)
+      typedef float ovec_t __attribute__((ext_vector_type(VEC)));
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = g * 4 + r;
+        if (n < ncols) {
+          ovec_t ov;
+#pragma unroll
+          for (int jj = 0; jj < VEC; jj++) ov[jj] = cur.live ? (float)acc64[jj][r] : 0.f;
+          *reinterpret_cast<ovec_t *>(&Xs[n][wave * 64 + VEC * j16]) = ov;
+        }
+      }
+      __syncthreads();
+      const int64_t wg_m = (int64_t)cur.c * slab_rows + (int64_t)cur.ab * 256;  // first row of the workgroup's tile
+      const int64_t slab_end = ((int64_t)cur.c + 1) * slab_rows;
+      for (int n = wave; n < ncols; n += 4) {
+        const int64_t mm = wg_m + 4 * lane;
+        if (mm < slab_end) {
+          const ovec_t ov = *reinterpret_cast<const ovec_t *>(&Xs[n][4 * lane]);
+          __builtin_nontemporal_store(ov, reinterpret_cast<ovec_t *>(out + (int64_t)n * M + mm));
+        }
+      }
+    } else if (cur.live) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = g * 4 + r;
@@ -257,11 +283,16 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL((k_scan_fused<0, 0>), dim3(grid_lib), dim3(256), 50 * 1024, 0, V, M, (int64_t)K, P, nkb, X, R, slab,
                        nslab, nab, ncg, cper, Wc, Ts);
   };
-  constexpr int NV = 7;
-  std::function<void()> vs[NV] = {v0, v1, v2, v3, v4, v5, v6};
+  auto v7 = [&]() {  // (the copy with the result tile gathered in LDS and stored as 1 KB pieces)
+    hipLaunchKernelGGL((k_scan_fused<0, 0, 1>), dim3(grid_lib), dim3(256), 0, 0, V, M, (int64_t)K, P, nkb, X, R, slab, nslab,
+                       nab, ncg, cper, Wc, Ts);
+  };
+  constexpr int NV = 8;
+  std::function<void()> vs[NV] = {v0, v1, v2, v3, v4, v5, v6, v7};
   const char *names[NV] = {"library k_scan_suffix_buf<float,1,5> -> X", "copy, same order, slab-aligned tiles -> X2",
                            "copy, c-grouped order -> X2", "copy, c-grouped order + fused first consumer -> X2",
-                           "library kernel -> X2", "copy, same order -> X", "copy, same order, 3 workgroups per CU -> X"};
+                           "library kernel -> X2", "copy, same order -> X", "copy, same order, 3 workgroups per CU -> X",
+                           "copy, same order, result through LDS in 1 KB pieces -> X"};
   std::vector<float> ms[NV];
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
