@@ -1299,6 +1299,7 @@ class HipOps : public Ops {
     double lamR = 0, lamR1 = 0, rho = 0;  // rank-th / next eigenvalue, largest eigenvalue
     double rho_frob = 0;  // 1.0001 ||G - deflation - sigma I||_F of the last projector step (0: none)
     double head = 4.0;    // head room of the spectral-bound scale (projector_step, fused form)
+    double dom_move = -1;  // sine between the dominant eigenvector of the last two steps (< 0: not measured)
     // lazy Rayleigh-Ritz (eig_lazy): the Jacobi of H runs on the second stream
     bool lazy = false;          // the session allows it for this slot
     bool lazy_pending = false;  // eigenvalues of the last step still to be read (evd)
@@ -1325,7 +1326,7 @@ class HipOps : public Ops {
     size_t GBd_elems = 0, Gd_elems = 0;
     struct {
       double sigma = 0, rho = 0, ell0 = 0;
-      int m = 0, iters = 0;
+      int m = 0, iters = 0, pow = 0;
     } dp;
     int n_deferred = 0, n_defer_failed = 0;
   };
@@ -1714,9 +1715,10 @@ class HipOps : public Ops {
       const int *hs = (const int *)(hc + kEigOffStatus);
       fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: lamR %.6e lamR1 %.6e deflated %d rho %.3e "
                       "(now %.3e) ell0 %.2e iters %d | ||X^2-I||^2 %.3e count %.6f residual %.3e "
-                      "(gap %.3e) chol %d%d%d%d -> %s (fast %d full %d)\n",
+                      "(gap %.3e) dominant vector moved %.1e after %d power steps chol %d%d%d%d -> %s (fast %d full %d)\n",
               slot, (long long)es.J, es.rank, es.lamR, es.lamR1, es.dp.m, es.dp.rho, c.rho_now, es.dp.ell0,
-              es.dp.iters, hc[0], c.cnt, c.res, c.gap_now, hs[0], hs[1], hs[2], hs[3],
+              es.dp.iters, hc[0], c.cnt, c.res, c.gap_now, es.dp.m == 1 ? std::sqrt(std::max(0.0, hc[9])) : 0.0, es.dp.pow,
+              hs[0], hs[1], hs[2], hs[3],
               ok ? "accepted (deferred check)" : (discard ? "dropped (its input was withdrawn)"
                                                           : "NOT accepted (deferred check): the caller repeats the step"),
               es.fast, es.full);
@@ -1729,12 +1731,14 @@ class HipOps : public Ops {
       es.lazy_m = es.dp.m;
       es.lazy_strict = false;
       es.rho_frob = c.rho_now;
+      es.dom_move = es.dp.m == 1 ? std::sqrt(std::max(0.0, hc[9])) : -1.0;
       es.fast++;
       es.stable++;
       return 0;
     }
     std::swap(es.Q, es.Qn);  // (the step had put its basis in front)
     es.stable = 0;
+    es.dom_move = -1;
     es.n_defer_failed++;
     return 1;
   }
@@ -2013,7 +2017,7 @@ class HipOps : public Ops {
     // comes out short and the step is repeated on the measured Frobenius norm (top_eigvecs_warm).
     const bool fused_scale = !strict && m <= 1 && eig_sigma_scale_ <= 0 && !eig_frob_once_;
     const double *pow_y = nullptr, *pow_p = nullptr;
-    int pow_n = 0;
+    int pow_n = 0, pow_steps = 0;
     if (m == 1) {
       // one dominant eigenpair (a tensor with a mean component): power steps on one vector. The
       // previous vector is off by at most ~1e-2 (one HOOI sweep); each step gains `ratio`. The
@@ -2022,7 +2026,13 @@ class HipOps : public Ops {
       // target 1e-14 needs ratio^k <= 1e-12 — two steps at the 1e-6 of a tensor with a mean component,
       // where counting from 1e-14 itself took three; a vector that was further off shows in the
       // residual of the step, which is then repeated cold)
-      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-12) / std::log(ratio))));
+      // (round 4: the 1e-2 is an assumption only until the slot has MEASURED how far its dominant vector
+      // moved from one step to the next — k_ns_prepare leaves the sine in the step's check block —: the
+      // next step starts from 8 x that, so a converging HOOI run drops from three launches to two)
+      double start = 1e-2;
+      if (es.dom_move >= 0) start = std::min(1e-2, std::max(1e-8, 8.0 * es.dom_move));
+      const int nsteps = std::min(14, std::max(2, (int)std::ceil(std::log(1e-14 / start) / std::log(ratio))));
+      pow_steps = nsteps;
       const int nb = (int)((J + 7) / 8);
       double *pw = (double *)ensure(ws_pow_, ws_pow_sz_, sizeof(double) * 4 * (size_t)nb);
       double *pbuf[2] = {pw, pw + 2 * (size_t)nb};
@@ -2071,7 +2081,8 @@ class HipOps : public Ops {
       rho = es.head * std::max(sigma, next - sigma);
       if (!(rho > 0) || !std::isfinite(rho)) return false;
       hipLaunchKernelGGL(k_ns_prepare, dim3(gdef), dim3(256), 0, st_, G, J, pow_y, pow_p, pow_n, m, tau,
-                         sigma, 1.0 / rho, X, QD, lamD, zero8);
+                         sigma, 1.0 / rho, X, QD, lamD, zero8, m == 1 ? (const double *)es.Q : (const double *)nullptr,
+                         m == 1 ? chk + 9 : (double *)nullptr);
     } else {
       hipLaunchKernelGGL(k_deflate_shift, dim3(gdef), dim3(256), 0, st_, G, J, QD, m, lamD, tau, sigma,
                          X, part, zero8);
@@ -2178,6 +2189,7 @@ class HipOps : public Ops {
         es.dp.ell0 = ell0;
         es.dp.m = m;
         es.dp.iters = iters;
+        es.dp.pow = pow_steps;
         std::swap(es.Q, es.Qn);  // (eig_verify swaps back when the step is not accepted)
         return true;
       }
@@ -2202,6 +2214,7 @@ class HipOps : public Ops {
         es.lazy_m = m;
         es.lazy_strict = strict;
         es.rho_frob = rho_now;
+        es.dom_move = (m == 1 && fused_scale) ? std::sqrt(std::max(0.0, hc[9])) : -1.0;
         std::swap(es.Q, es.Qn);
         es.fast++;
         return true;
@@ -2210,6 +2223,7 @@ class HipOps : public Ops {
         // not accepted: the Jacobi on the second stream is of no use (its buffers are the slot's own)
         lazy_used = false;
       }
+      if (!good) es.dom_move = -1;
       if (good) {
         {
           const int mi = std::min(m, rank - 1);
@@ -2221,6 +2235,7 @@ class HipOps : public Ops {
         es.lamR = evn[rank - 1];
         es.lamR1 = std::min(std::max(0.0, es.lamR1 + shift), es.lamR);
         es.rho_frob = rho_now;
+        es.dom_move = (m == 1 && fused_scale) ? std::sqrt(std::max(0.0, hc[9])) : -1.0;
         if (strict) es.lamR1 = std::min(es.lamR1, es.lamR * (1 - 1e-6));  // (a rough estimate)
         if (!(es.lamR > es.lamR1 * (1 + 1e-9))) es.valid = false;  // next call: full solver
         if (fused_tail)

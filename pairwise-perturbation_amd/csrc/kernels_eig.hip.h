@@ -670,7 +670,12 @@ __global__ __launch_bounds__(256) void k_ns_prepare(const double *__restrict__ G
                                                     double *__restrict__ X,
                                                     double *__restrict__ q_out,
                                                     double *__restrict__ lam_out,
-                                                    int *__restrict__ zero8 = nullptr) {
+                                                    int *__restrict__ zero8 = nullptr,
+                                                    const double *__restrict__ q_prev = nullptr,
+                                                    double *__restrict__ move_out = nullptr) {
+  // q_prev / move_out: *move_out = 1 - (q_prev^T q)^2, the squared sine between the vector the power
+  // steps started from and the one they ended in — how far the dominant eigenvector moved since the
+  // slot's previous step; the host counts the next step's power launches from it
   __shared__ double lds[17];
   // (the step's status words are cleared here instead of by a memset launch of their own)
   if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
@@ -686,8 +691,17 @@ __global__ __launch_bounds__(256) void k_ns_prepare(const double *__restrict__ G
     inv = 1.0 / sqrt(n2);
     lam = rq;
     if (blockIdx.x == 0) {
-      for (int64_t i = threadIdx.x; i < J; i += blockDim.x) q_out[i] = y[i] * inv;
+      double dot = 0;
+      for (int64_t i = threadIdx.x; i < J; i += blockDim.x) {
+        const double qi = y[i] * inv;
+        q_out[i] = qi;
+        if (q_prev) dot += qi * q_prev[i];
+      }
       if (threadIdx.x == 0) *lam_out = lam;
+      if (move_out) {
+        dot = block_sum(dot, lds);
+        if (threadIdx.x == 0) *move_out = fmax(0.0, 1.0 - dot * dot);
+      }
     }
   }
   const double w = (lam - tau) * inv * inv;
@@ -1068,6 +1082,7 @@ __global__ void k_tn_gram(const double *__restrict__ Z, int64_t rows, int cols, 
       chk_out[0] = e2;
       chk_out[1] = tr;
       chk_out[8] = chk_src[8];
+      chk_out[9] = chk_src[9];  // (how far the dominant eigenvector moved: k_ns_prepare)
     }
     return;
   }
@@ -1679,6 +1694,7 @@ __global__ __launch_bounds__(256) void k_sub_residual(const double *__restrict__
         host[5] = l;
         host[6] = h;
         host[8] = chk[8];
+        host[9] = chk[9];
       }
     }
   }

@@ -359,6 +359,12 @@ def test_cfg5_tucker_full_size_r2(pp, cfg5_r2, dtype, env, tmp_path, monkeypatch
         ncold = sum("cold start" in ln and "projector step" in ln for ln in lines)
         assert 3 <= ncold <= 6, "\n".join(lines)   # (a second one while the first sweeps move the spectrum)
         assert not any("full solver" in ln for ln in lines), "\n".join(lines)
+        # the mean component's eigenvector is refined by power steps counted from how far it MOVED over
+        # the slot's last step (measured on the device, read with the deferred checks): two launches
+        # once the sweeps settle, three while only the 1e-2 assumption is there
+        import re
+        pw = [int(m.group(1)) for m in (re.search(r"after (\d+) power steps", ln) for ln in acc) if m]
+        assert pw and min(pw) == 2 and max(pw) <= 3, (pw, "\n".join(acc[-12:]))
     elif env.get("PPALS_EIG_FAST") == "0":
         assert not lines, lines[:3]
     else:
