@@ -70,8 +70,68 @@ TuckerEngine::TuckerEngine(Ops &ops, Comm &comm, const TensorDesc &V, const int 
     for (int m = mid + 1; m < N_; m++) cols *= ext(m);
     VT_ = ops_.try_alloc((size_t)rows * cols * dtype_size(V_.dtype));
     if (VT_) ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
+    // the third rotation [1 2 | 0] for the order-3 multi-sweep schedule (tucker.h), room permitting
+    const char *chain = std::getenv("PPALS_TUCKER_CHAIN");
+    if (N_ == 3 && !dist_ && VT_ && !(chain && std::string(chain) == "tree")) {
+      const size_t bytes = (size_t)V_.nloc * dtype_size(V_.dtype);
+      const size_t avail = ops_.mem_available();
+      if (avail == (size_t)-1 || (double)avail > 2.0 * (double)bytes + 2e9) VT2_ = ops_.try_alloc(bytes);
+      if (VT2_) {
+        ops_.transpose2d(V_.data, V_.dtype, ext(0), ext(1) * ext(2), VT2_);
+        ms3_ = true;
+      }
+    }
   }
   if (V_.generation) tensor_gen_ = *V_.generation;
+}
+
+// The leaf of mode i, [s_i | the other two ranks], from the order-3 multi-sweep schedule; nullptr: the
+// back end has no leading-mode product for this shape — the schedule is switched off for the session.
+double *TuckerEngine::ms3_leaf(int i, int64_t *T) {
+  check_tensor_generation();
+  if (ms3_root_ < 0 || ms3_root_ == i || ms3_left_ <= 0) {
+    // root = the mode updated last before i: serves i and the mode after it
+    const int r = (i + 2) % 3;
+    const void *lay = r == 2 ? V_.data : (r == 1 ? VT_ : VT2_);  // storage order (r+1, r+2, r)
+    const int64_t d0 = ext((r + 1) % 3), d1 = ext((r + 2) % 3);
+    const size_t need = dtype_size(V_.dtype) * (size_t)(d0 * d1 * r_[r]);
+    if (ms3_cap_ < need) {
+      ops_.free(ms3_X_);
+      ms3_X_ = ops_.alloc(need);
+      ms3_cap_ = need;
+    }
+    FactorRef f;
+    f.ptr = wptr(r);
+    f.rows = ext(r);
+    f.ld = V_.glens[r];
+    ops_.scan_contract(lay, V_.dtype, d0 * d1, ext(r), 1, &f, 1, r_[r], ms3_X_, V_.dtype, d0 * d1 * r_[r], d0 * d1);
+    ms3_root_ = r;
+    ms3_left_ = 2;
+  }
+  const int r = ms3_root_, m0 = (r + 1) % 3, m1 = (r + 2) % 3;  // X[s_m0, s_m1, rank_r]
+  const int64_t d0 = ext(m0), d1 = ext(m1);
+  const int64_t elems = (int64_t)V_.glens[i] * (i == m0 ? r_[m1] : r_[m0]) * r_[r];
+  if (ms3_Ycap_[i] < elems) {
+    ops_.free(ms3_Y_[i]);
+    ms3_Y_[i] = (double *)ops_.alloc(sizeof(double) * elems);
+    ms3_Ycap_[i] = elems;
+  }
+  if (i == m0) {  // keep the first mode in front, contract the second: [s_m0 | rank_m1, rank_r]
+    ops_.ttm_keep(ms3_X_, V_.dtype, d0, d1, r_[r], wptr(m1), V_.glens[m1], r_[m1], ms3_Y_[i]);
+    *T = (int64_t)r_[m1] * r_[r];
+  } else {        // contract the leading mode, the second one comes to the front: [s_m1 | rank_m0, rank_r]
+    if (!ops_.ttm_lead_front(ms3_X_, V_.dtype, d0, d1, r_[r], wptr(m0), V_.glens[m0], r_[m0], ms3_Y_[i])) {
+      ms3_ = false;
+      ms3_invalidate();
+      return nullptr;
+    }
+    *T = (int64_t)r_[m0] * r_[r];
+  }
+  // rank indices behind the mode: (other, root). Ascending mode order — what ensure_core() reads — when
+  // other < root
+  ms3_perm_ = (i == m0 ? m1 : m0) > r;
+  ms3_left_--;
+  return ms3_Y_[i];
 }
 
 // see CpEngine::check_tensor_generation: the tensor handle stays writable while sessions exist
@@ -85,6 +145,8 @@ void TuckerEngine::check_tensor_generation() {
     for (int m = mid + 1; m < N_; m++) cols *= ext(m);
     ops_.transpose2d(V_.data, V_.dtype, rows, cols, VT_);
   }
+  if (VT2_) ops_.transpose2d(V_.data, V_.dtype, ext(0), ext(1) * ext(2), VT2_);
+  ms3_invalidate();
   for (auto &n : nodes_) n.valid = false;
   pp_clear();
 }
@@ -114,6 +176,9 @@ TuckerEngine::~TuckerEngine() {
   ops_.free(chain_[0]);
   ops_.free(chain_[1]);
   ops_.free(VT_);
+  ops_.free(VT2_);
+  ops_.free(ms3_X_);
+  for (auto p : ms3_Y_) ops_.free(p);
   for (auto p : Wprev_) ops_.free(p);
   for (auto p : Winit_) ops_.free(p);
   for (auto p : dW_) ops_.free(p);
@@ -411,6 +476,10 @@ int64_t TuckerEngine::ttmc(int skip, double *Yhost) {
 
 void TuckerEngine::ensure_core() {
   if (!core_owed_) return;
+  if (!yend_src_) {
+    compute_core_full();
+    return;
+  }
   core_owed_ = false;
   const int64_t Lc = ncore_ / r_[N_ - 1], sN = V_.glens[N_ - 1];
   const int rN = r_[N_ - 1];
@@ -455,6 +524,7 @@ void TuckerEngine::finalize_rotations() {
     ops_.sync();
     ops_.free(tmp);
     ops_.eig_rotation_done(eig_base_ + i);
+    ms3_invalidate();  // (the multi-sweep intermediate may carry this mode's rank index in the old basis)
   }
 }
 void TuckerEngine::drop_rotations() {
@@ -463,7 +533,12 @@ void TuckerEngine::drop_rotations() {
 }
 
 void TuckerEngine::set_factors(const double *Wflat) {
+  settle_all();
+  // (the core the last sweep owes belongs to the factors that are about to be replaced: the core object
+  // travels on through a caller's repetitions, pp_bench.cxx:321-345)
+  ensure_core();
   drop_rotations();  // (they belonged to the factors being replaced)
+  ms3_invalidate();
   const double *w = Wflat;
   for (int i = 0; i < N_; i++) {
     size_t n = (size_t)V_.glens[i] * r_[i];
@@ -498,6 +573,7 @@ void TuckerEngine::get_factors(double *Wflat, double *core) {
 // V (K13), then core = V x_i W_i^T
 void TuckerEngine::hosvd() {
   settle_all();
+  ms3_invalidate();
   for (int i = 0; i < N_; i++) {
     int64_t L = 1, T = 1;
     for (int q = 0; q < i; q++) L *= ext(q);
@@ -583,16 +659,21 @@ void TuckerEngine::sweep_body(const std::vector<double *> *align_ref) {
 }
 
 void TuckerEngine::mode_step(int i, const std::vector<double *> *align_ref, bool may_defer) {
-  compute_node(leaf_[i]);
-  const Node &lf = nodes_[leaf_[i]];
   int64_t L = 1, T = 1;
-  for (int q = 0; q < i; q++) L *= r_[q];
-  for (int q = i + 1; q < N_; q++) T *= r_[q];
-  if (lf.front) {  // [s_i | ranks of the other modes] (compute_left_half_on_vt)
-    T = L * T;
-    L = 1;
+  double *Y = ms3_ ? ms3_leaf(i, &T) : nullptr;
+  const bool from_ms3 = Y != nullptr;
+  if (!from_ms3) {
+    compute_node(leaf_[i]);
+    const Node &lf = nodes_[leaf_[i]];
+    for (int q = 0; q < i; q++) L *= r_[q];
+    T = 1;
+    for (int q = i + 1; q < N_; q++) T *= r_[q];
+    if (lf.front) {  // [s_i | ranks of the other modes] (compute_left_half_on_vt)
+      T = L * T;
+      L = 1;
+    }
+    Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
   }
-  double *Y = complete_leaf(i, lf.buf, L * V_.glens[i] * T);
   if (i == N_ - 1) {  // als_Tucker.cxx:395
     yend_T_ = T;
     // (one GPU: the leaf's own buffer stays as it is until this mode is stepped again — no copy)
@@ -600,7 +681,9 @@ void TuckerEngine::mode_step(int i, const std::vector<double *> *align_ref, bool
       ops_.d2d(Yend_, Y, sizeof(double) * yend_elems_);
       yend_src_ = Yend_;
     } else {
-      yend_src_ = Y;
+      // (a multi-sweep leaf with its rank indices in descending mode order: the core is recomputed from
+      // the tensor when somebody asks for it)
+      yend_src_ = (from_ms3 && ms3_perm_) ? nullptr : Y;
     }
   }
   ops_.eig_lazy(eig_base_ + i, align_ref == nullptr && !dist_);
@@ -654,6 +737,7 @@ void TuckerEngine::rollback_and_redo() {
   const std::vector<int> steps = defer_log_;
   defer_log_.clear();
   defer_rollbacks_++;
+  ms3_invalidate();
   ops_.sync();
   for (size_t k = 0; k < steps.size(); k++) {
     const int j = steps[k];
@@ -663,8 +747,10 @@ void TuckerEngine::rollback_and_redo() {
   }
   for (int j : steps) {
     for (auto &n : nodes_) n.valid = false;
+    ms3_invalidate();
     mode_step(j, nullptr, false);
   }
+  ms3_invalidate();
   // (whatever the sweep in progress needs of the tree is rebuilt from the factors as they are now:
   // a leaf left valid here would be taken for this sweep's by the step that comes to it)
   for (auto &n : nodes_) n.valid = false;
@@ -834,6 +920,7 @@ void TuckerEngine::pp_clear() {
 
 // one approximate sweep (als_Tucker.cxx:824-891): Y_i = Y_i^0 + sum_{j != i} T_ij x_j dW_j
 void TuckerEngine::sweep_pp() {
+  ms3_invalidate();  // (PP moves the factors without touching the multi-sweep intermediate)
   for (int i = 0; i < N_; i++) {
     const PPOp &Y0 = pp_get(tk_all_but(N_, i));
     if (yacc_cap_ < Y0.elems) {

@@ -83,6 +83,25 @@ class TuckerEngine {
   void drop_rotations();
   bool thin_enabled_ = true;  // PPALS_TUCKER_THIN=0: always the s_i x s_i Gram (A/B, tests)
   void *VT_ = nullptr;  // second resident layout [(right modes), (left modes)], nullptr: not held
+  // Order 3, one GPU: the multi-sweep dimension tree (as the CP engine's, cp_msdt_optimizer.cxx:172-207).
+  // ONE first-level intermediate X_r = V x_r W_r serves the TWO mode updates that follow mode r's, then
+  // the root moves on to the mode updated last: 3 tensor scans per 2 HOOI sweeps instead of 4, the same
+  // factors in the same order (every product of a step sees exactly the factor versions alsTucker_DT's
+  // tree gives it). Needs the tensor in all three rotations (V, VT_ = [2 | 0 1], VT2_ = [1 2 | 0]) so
+  // that every root is contracted by a row-contiguous scan. PPALS_TUCKER_CHAIN=tree: the per-sweep tree.
+  bool ms3_ = false;
+  void *VT2_ = nullptr;
+  void *ms3_X_ = nullptr;
+  size_t ms3_cap_ = 0;
+  int ms3_root_ = -1, ms3_left_ = 0;
+  bool ms3_perm_ = false;  // the leaf just served has its two rank indices in descending mode order
+  double *ms3_Y_[3] = {nullptr, nullptr, nullptr};
+  int64_t ms3_Ycap_[3] = {0, 0, 0};
+  double *ms3_leaf(int i, int64_t *T);
+  void ms3_invalidate() {
+    ms3_root_ = -1;
+    ms3_left_ = 0;
+  }
   uint64_t tensor_gen_ = 0;  // generation of the tensor contents VT_ and the caches were built from
   void check_tensor_generation();
   void *chain_[2] = {nullptr, nullptr};  // ping-pong scratch of the mode-product chains

@@ -252,6 +252,18 @@ class HostOps : public Ops {
           out[l + L * (k + (int64_t)Kc * t)] = acc;
         }
   }
+  // out[s + S*(k + Kc*t)] = sum_j X[j + J*(s + S*t)] * W[j + ldw*k]  (ops.h: the leading-mode product)
+  bool ttm_lead_front(const void *X, int dt, int64_t J, int64_t S, int64_t T, const double *W, int64_t ldw,
+                      int Kc, double *out) override {
+    for (int64_t t = 0; t < T; t++)
+      for (int k = 0; k < Kc; k++)
+        for (int64_t s2 = 0; s2 < S; s2++) {
+          double acc = 0;
+          for (int64_t j = 0; j < J; j++) acc += ld(X, dt, j + J * (s2 + S * t)) * W[j + ldw * k];
+          out[s2 + S * (k + (int64_t)Kc * t)] = acc;
+        }
+    return true;
+  }
   void mttv(const void *X, int xdt, int64_t L, int64_t J, int64_t T, const FactorRef *f, int nf,
             int R, double *out, int64_t rs, int accumulate, const double *out_scale) override {
     const double sc = out_scale ? *out_scale : 1.0;

@@ -608,6 +608,48 @@ def test_chain_order_of_the_first_level_products(pp, ctx, order, monkeypatch):
         t.close()
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("lens,ranks", [([96, 80, 72], [5, 6, 4]), ([40, 17, 33], [4, 4, 5])])
+def test_order3_multi_sweep_schedule(pp, lens, ranks, dtype, monkeypatch):
+    """Order 3 on one GPU: the multi-sweep dimension tree (TuckerEngine::ms3_leaf) — ONE first-level
+    intermediate X_r = V x_r W_r serves the two mode updates after mode r's, the root rotates 2, 1, 0
+    over three resident rotations of the tensor: 3 tensor scans per 2 HOOI sweeps, the same factor
+    versions in every product as alsTucker_DT's per-sweep tree (als_Tucker.cxx:340-408), hence the same
+    iterates. Both schedules (PPALS_TUCKER_CHAIN=tree: the per-sweep tree) against the oracle after 1 to
+    4 sweeps, the scan launches counted by the profile slots."""
+    V = _decaying_tensor(lens, [r + 4 for r in ranks], 17, 0.02)
+    W0, c0 = O.hosvd(V, ranks)
+    scans = {}
+    for sched in ("ms", "tree"):
+        if sched == "tree":
+            monkeypatch.setenv("PPALS_TUCKER_CHAIN", "tree")
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, dtype).upload(V)
+        s = pp.Tucker(c2, t, ranks)
+        for sweeps in (1, 2, 3, 4):
+            s.set_factors(W0)
+            s.set_core(c0)
+            c2.profile_enable(1)
+            c2.profile_reset()
+            s.sweeps_dt(sweeps)
+            c2.sync()
+            scans[(sched, sweeps)] = c2.profile_read(0)[0]
+            c2.profile_enable(0)
+            W, core = s.get_factors()
+            _, _, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=sweeps - 1, resprint=10 ** 6)
+            for a, b, r in zip(W, W_ref, ranks):
+                assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+                assert relerr(proj(a), proj(b)) < (1e-7 if dtype == 1 else 2e-4), (sched, sweeps)
+            assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < (1e-9 if dtype == 1 else 1e-5) * np.linalg.norm(core_ref)
+        s.close()
+        t.close()
+        c2.close()
+    big = min(lens) >= 16  # (the leading-mode product of the back end wants 16 rows: else the per-sweep tree)
+    for sweeps in (1, 2, 3, 4):
+        assert scans[("tree", sweeps)] == 2 * sweeps, scans
+        assert scans[("ms", sweeps)] == ((3 * sweeps + 1) // 2 if big else 2 * sweeps), scans
+
+
 def test_eigen_step_wide_tail(pp, tmp_path, monkeypatch, capfd):
     """a shift that has slipped below a few more eigenvalues than wanted (forced here:
     PPALS_EIG_SIGMA_SCALE puts it at 0.4 x the next eigenvalue, under the two that follow in this
