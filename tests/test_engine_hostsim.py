@@ -116,6 +116,38 @@ def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
         assert (a == b).all() and (a == d).all()
 
 
+@pytest.mark.parametrize("sched", ["ms", "tree"])
+@pytest.mark.parametrize("lens,ranks", [([14, 14, 14], [3, 3, 3]), ([9, 12, 10], [2, 3, 4])])
+def test_tucker_order3_multi_sweep_schedule(pp, lens, ranks, sched, monkeypatch):
+    """Order 3, one rank: the multi-sweep dimension tree (TuckerEngine::ms3_leaf; three rotations of the
+    tensor, one first-level intermediate serving two mode updates, the root rotating) and the per-sweep
+    tree (PPALS_TUCKER_CHAIN=tree) give the oracle's iterates after 1 .. 5 sweeps — with deferred steps
+    that fail every third check on the way, so that the schedule is rebuilt in the middle of its cycle."""
+    import numpy as np
+    import oracle_lib as O
+    if sched == "tree":
+        monkeypatch.setenv("PPALS_TUCKER_CHAIN", "tree")
+    monkeypatch.setenv("PPALS_HOSTSIM_DEFER", "1")
+    monkeypatch.setenv("PPALS_HOSTSIM_DEFER_FAIL", "3")
+    V = O.fill_uniform(int(np.prod(lens)), 13, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W0, c0 = O.hosvd(V, ranks)
+    c = pp.Context(0)
+    t = pp.Tensor(c, lens, 1).upload(V)
+    s = pp.Tucker(c, t, ranks)
+    for n in (1, 2, 3, 4, 5):
+        s.set_factors(W0)
+        s.set_core(c0)
+        s.sweeps_dt(n)
+        W, core = s.get_factors()
+        _, _, W_ref, core_ref = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=n - 1, resprint=10 ** 9)
+        for a, b in zip(W, W_ref):
+            assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-10, (sched, n)
+        assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-11 * np.linalg.norm(core_ref)
+    s.close()
+    t.close()
+    c.close()
+
+
 @pytest.mark.parametrize("lens,ranks", [([12, 10, 9], [3, 4, 2]), ([9, 8, 7, 6], [3, 2, 3, 2])])
 @pytest.mark.parametrize("fail_every", [0, 1, 2, 3, 7])
 def test_tucker_deferred_eigen_steps_roll_back(pp, lens, ranks, fail_every, monkeypatch, tmp_path):
