@@ -196,7 +196,7 @@ def cpu_baseline(lens, R, budget_s=25.0):
             f"(fp64 tensor, {8e-9 * float(np.prod(lens)):.1f} GB in host memory)" if s == s_full else
             f"{k} sweeps at reduced size s={s}, scaled by (s/{s})^4 = {scale:.1f} to s={s_full} "
             "(host memory cannot hold the full tensor)")
-    return {
+    port = {
         "value": 1.0 / (per_sweep * scale),
         "unit": "sweeps/s",
         "cores": nthreads,
@@ -204,10 +204,18 @@ def cpu_baseline(lens, R, budget_s=25.0):
         "sample": what + f": fp64 OpenMP oracle with the reference's TTM-by-TTM contraction order, "
                          f"{per_sweep:.3f} s/sweep on {nthreads} threads, print blocks "
                          f"({t_print:.2f} s each) subtracted as in als_CP.cxx:167,189",
-        # the same contraction sequence with its two big TTMs on the host's BLAS (the reference runs
-        # them as CTF contractions over MKL dgemm, common.cxx:56,83) — the stronger CPU number
-        "blas": blas,
     }
+    # `value` is the STRONGEST CPU number measured here: the same contraction sequence with its two big
+    # TTMs on the host's BLAS (the reference runs them as CTF contractions over MKL dgemm,
+    # common.cxx:56,83) when that beats the plain OpenMP port, which stays beside it under `openmp_port`
+    if blas and blas.get("value") and blas["value"] > port["value"]:
+        out = dict(blas)
+        out["sample"] = (f"s={s_full}" if s == s_full else f"s={s} scaled by (s/{s})^4 to s={s_full}") + \
+            ": " + blas["sample"]
+        out["openmp_port"] = port
+        return out
+    port["blas"] = blas
+    return port
 
 
 def _csv_rows(path):
@@ -633,10 +641,32 @@ def main():
     if args.schedule:
         cp.set_schedule(args.schedule)
     schedule = cp.schedule
+    # The engine chooses where each root's first-level intermediate lies ONLINE: the first ~20 visits
+    # of a root run the sweep's own scan at a different candidate (engine.h, PlaceExplore). The
+    # headline is the steady state, so the session is run until every root has settled — untimed, like
+    # the warm-up, and reported: `placement.settle_sweeps` / `settle_s`; what the choice is worth on a
+    # run of the reference's length, exploration included, is sub_records.time_to_250_sweeps.
+    settle_sweeps, settle_s = 0, 0.0
+    try:
+        t0 = time.perf_counter()
+        while settle_sweeps < 120:
+            rep = cp.placement_report()
+            if rep.get("mode") != "online" or (rep["roots"] and all(r["settled"] for r in rep["roots"])):
+                break
+            if not rep["roots"] and settle_sweeps >= 8:
+                break        # nothing to choose for this shape
+            cp.sweeps_dt(8)
+            settle_sweeps += 8
+        ctx.sync()
+        settle_s = time.perf_counter() - t0
+    except Exception:
+        pass
     head = measure(cp, args.steps, args.warmup)
     try:
         placement = cp.placement_report()
         placement["session_setup_s"] = session_setup_s
+        placement["settle_sweeps"] = settle_sweeps
+        placement["settle_s"] = settle_s
     except Exception as e:  # reported, never required
         placement = {"error": str(e)}
     gradnorm = cp.gradnorm()
@@ -689,6 +719,36 @@ def main():
             del os.environ["PPALS_PLACE_TUNE"]
         else:
             os.environ["PPALS_PLACE_TUNE"] = old
+    if world == 1 and not args.schedule and schedule == "msdt" and not hostsim:
+        # wall time from session creation to 250 sweeps done (the reference's scripts run 250,
+        # script/script_synthetic.py:18) with the online placement choice and without, same tensor,
+        # same process, alternating, the faster of two runs each
+        try:
+            t250 = {"tuned_s": [], "untuned_s": []}
+            old = os.environ.get("PPALS_PLACE_TUNE")
+            for rep_ in range(2):
+                for name, env in (("untuned_s", "0"), ("tuned_s", "1")):
+                    os.environ["PPALS_PLACE_TUNE"] = env
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    c_ = ppals.CP(ctx, V, R)
+                    c_.set_factors(W0, G0)
+                    c_.sweeps_dt(250)
+                    ctx.sync()
+                    t250[name].append(time.perf_counter() - t0)
+                    c_.close()
+            if old is None:
+                del os.environ["PPALS_PLACE_TUNE"]
+            else:
+                os.environ["PPALS_PLACE_TUNE"] = old
+            sub["time_to_250_sweeps"] = {
+                "tuned_s": min(t250["tuned_s"]), "untuned_s": min(t250["untuned_s"]),
+                "all_runs": t250,
+                "note": "ppals_cp_create (second resident layout included) + set_factors + 250 exact sweeps + "
+                        "sync, wall clock; tuned = online placement choice (explores during the first ~60 "
+                        "sweeps), untuned = PPALS_PLACE_TUNE=0"}
+        except Exception as e:
+            sub["time_to_250_sweeps"] = {"error": str(e)}
     if world > 1:
         # the plan north_star names (reduce-scatter of the s x R partials + row-block solve +
         # all-gather) beside the default for these message sizes (one all-reduce + redundant fused

@@ -128,17 +128,18 @@ int ppals_cp_get_factors(ppals_cp *s, double *Wflat, double *gradWflat /*may be 
 /* How an exact sweep walks the tensor — the ALS iterates are identical either way.
  * PPALS_SCHEDULE_DT: the two first-level nodes of alsCP_DT (mttkrp_map_DT, common.cxx:20-133), two
  * tensor scans per sweep. PPALS_SCHEDULE_MSDT (default): the multi-sweep tree of the class API
- * (cp_msdt_optimizer.cxx:172-207), N/(N-1) scans per sweep. The environment variable
- * PPALS_DT_SCHEDULE=dt|msdt sets the default of new sessions. */
+ * (cp_msdt_optimizer.cxx:172-207), N/(N-1) scans per sweep. */
 #define PPALS_SCHEDULE_DT 0
 #define PPALS_SCHEDULE_MSDT 1
 int ppals_cp_set_schedule(ppals_cp *s, int schedule);
 int ppals_cp_get_schedule(const ppals_cp *s);
-/* What the session's set-up measured when it placed the multi-sweep schedule's first-level
- * intermediates (no counterpart in the reference: CTF places its own buffers): one JSON object
- * {"measured", "setup_s", "roots": [{"root", "layout", "block", "offset_mb", "store", "candidates",
- * "best_ms", "worst_ms"}]} written to buf (NUL-terminated). PPALS_PLACE_TUNE=0 switches the
- * measurement off ("measured": false). */
+/* Where the multi-sweep schedule's first-level intermediates lie (no counterpart in the reference:
+ * CTF places its own buffers). The choice is made ONLINE: the first ~20 visits of a root run the
+ * sweep's own scan at a different offset / store kind of the result, timed on the stream; then the
+ * root keeps the fastest. No set-up time, the results do not depend on it. One JSON object
+ * {"mode": "online"|"off", "setup_s": 0, "roots": [{"root", "layout", "settled", "visits",
+ * "offset_mb", "store", "best_ms", "worst_ms"}]} written to buf (NUL-terminated).
+ * PPALS_PLACE_TUNE=0 switches the choice off (offset 0, store kind by size). */
 int ppals_cp_placement_report(const ppals_cp *s, char *buf, int cap);
 /* The operator builds of the PP phases (Build_mttkrp_map + the N full MTTKRPs, als_CP.cxx:678-694)
  * since the last reset: their number and — while timing is on — their duration, the stream

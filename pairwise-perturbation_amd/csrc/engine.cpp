@@ -283,35 +283,18 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     lay_.push_back(nat);
   }
   ensure_transposed();
-  for (int r = 0; r < MAX_ORDER; r++) ms_X_nt_[r] = -1;
   if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
-    // placement of the first-level intermediate, measured per root with the factors at hand
-    // (zeros: the timing does not depend on the values); nothing is kept but the offsets.
-    // The block is sized ONCE, for the largest root set, before the first measurement: growing it
-    // later would move every root's result and void what was measured (unequal mode extents,
-    // [s/P, s, s, s] shards). Tuning happens here and nowhere else — never inside a timed sweep.
+    // The block of the first-level intermediate is sized ONCE, for the largest root set plus the
+    // slack the online placement choice moves inside (ms_start_step): growing it later would move
+    // every root's result and void what the first visits measured (unequal mode extents,
+    // [s/P, s, s, s] shards). Nothing is launched or measured here.
     size_t xmax = 0;
     for (int r = 0; r < N_; r++) {
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
       xmax = std::max(xmax, ms_X_bytes(r, ms_k_));
     }
-    const double t_tune0 = now();
     ms_X_base_ = big_alloc(xmax + ms_X_slack());
     ms_X_cap_ = xmax + ms_X_slack();
-    ms_alloc_candidates(ms_X_cap_);
-    ms_tuning_now_ = true;
-    for (int r = 0; r < N_; r++) {
-      if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;
-      ms_start_step(r);
-    }
-    ms_release_unchosen();
-    ms_tune_second_layout();
-    ms_cand_.clear();
-    ms_tuning_now_ = false;
-    ops_.sync();
-    ms_place_setup_s_ = now() - t_tune0;
-    ms_invalidate();
-    ms_X_.valid = false;
   }
   for (int i = 0; i < MAX_ORDER; i++) grad_replicated_[i] = !dist_;
   build_tree(0, N_ - 1, -1);
@@ -358,8 +341,9 @@ CpEngine::~CpEngine() {
   ops_.free(Pbuf_);
   for (auto &l : lay_)
     if (l.owned) ops_.free(l.ptr);
+  for (auto &ex : ms_place_)
+    if (ex.timer >= 0) ops_.timer_read(ex.timer);
   ops_.free(ms_X_base_);
-  for (void *p : ms_X_alt_) ops_.free(p);
   ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
     ops_.free(n.t.buf);
@@ -875,122 +859,50 @@ size_t CpEngine::ms_X_slack() const {
   return bytes >= place_min_bytes() ? ((size_t)64 << 20) + 4096 : 0;
 }
 
-// Candidate result blocks for the placement measurement, spread over the device memory: between two
-// candidates a spacer of a few GB is allocated and freed again afterwards (blocks allocated back to
-// back land in one region and behave alike: profiles/r03q_place6_pairs.txt, second process).
-// Candidates are optional: none are taken when the device is short of room.
-void CpEngine::ms_alloc_candidates(size_t cap) {
-  int nb = 4;
-  // (a lowered PPALS_PLACE_MIN_MB means small tensors — the CPU tests of this machinery: a token spacer)
-  const size_t spacer = std::getenv("PPALS_PLACE_MIN_MB") ? ((size_t)1 << 20) : ((size_t)6 << 30);
-  const double tensor_bytes = (double)V_.nloc * dtype_size(V_.dtype);
-  if (tensor_bytes >= 2.5e10) nb = std::min(nb, 3);  // scans of >= 4 ms: fewer measurements
-  std::vector<void *> spacers;
-  for (int b = 1; b < nb; b++) {
-    const size_t avail = ops_.mem_available();
-    // what the session must still allocate (PP scratch, tree nodes: a few X) stays free
-    if (avail != (size_t)-1 && (double)avail < (double)(cap + spacer) + 4.0 * (double)cap + 8e9) break;
-    void *sp = spacer ? ops_.try_alloc(spacer) : nullptr;
-    void *p = ops_.try_alloc(cap);
-    if (sp) spacers.push_back(sp);
-    if (!p) break;
-    ms_X_alt_.push_back(p);
-  }
-  for (void *sp : spacers) ops_.free(sp);
+// ---- online placement choice (engine.h, PlaceExplore) ----
+// the sample of the visit in flight, if any, goes to its candidate
+void CpEngine::ms_place_collect(PlaceExplore &ex) {
+  if (ex.timer < 0) return;
+  const double t = ops_.timer_read(ex.timer);
+  ex.timer = -1;
+  if (t <= 0 || ex.timer_cand < 0 || ex.timer_cand >= (int)ex.cands.size()) return;
+  PlaceCand &c = ex.cands[ex.timer_cand];
+  c.best = std::min(c.best, t);
+  c.samples++;
+  ex.worst = std::max(ex.worst, t);
 }
 
-// The second resident layout is the session's own buffer, so its place can be chosen as well: with
-// the result block fixed (chosen above with the roots that read the tensor's own buffer weighing
-// in), a few further copies of the layout are tried elsewhere in the device memory and the one the
-// roots that read it scan fastest is kept (tools/runs/r03_p.sh, a box where those two roots ran at
-// 1.21-1.25 ms against 1.08-1.11 ms of the other two whatever the result block). Candidates stay
-// allocated until the choice is made, so that each lands somewhere else; all but one are freed.
-void CpEngine::ms_tune_second_layout() {
-  if (lay_.size() < 2 || !lay_[1].owned || lay_[1].bytes == 0) return;
-  const int nc = 3;
-  const size_t bytes = lay_[1].bytes;
-  if ((double)bytes > 1.7e10) return;  // larger layouts span the regions anyway
-  std::vector<int> roots;
-  double cur = 0;
-  for (int r = 0; r < N_; r++)
-    if (ms_tuned_[r] && ms_root_layout_[r] == 1 && ms_tuned_ms_[r] > 0) {
-      roots.push_back(r);
-      cur += ms_tuned_ms_[r];
-    }
-  if (roots.empty()) return;
-  struct Cand {
-    void *p;
-    double sum;
-    int64_t off[MAX_ORDER];
-    int nt[MAX_ORDER];
-  };
-  auto snapshot = [&](void *p, double sum) {
-    Cand c;
-    c.p = p;
-    c.sum = sum;
-    for (int r = 0; r < MAX_ORDER; r++) {
-      c.off[r] = ms_X_off_[r];
-      c.nt[r] = ms_X_nt_[r];
-    }
-    return c;
-  };
-  Cand best = snapshot(lay_[1].ptr, cur);
-  std::vector<void *> rejected;
-  for (int c = 1; c < nc; c++) {
-    const size_t avail = ops_.mem_available();
-    if (avail != (size_t)-1 && (double)avail < 2.0 * (double)bytes + 4.0 * (double)ms_X_cap_ + 8e9) break;
-    void *p = ops_.try_alloc(bytes);
-    if (!p) break;
-    ops_.d2d(p, best.p, bytes);
-    lay_[1].ptr = p;
-    double sum = 0;
-    for (int r : roots) {
-      ms_tuned_[r] = false;
-      ms_start_step(r);
-      sum += ms_tuned_ms_[r];
-    }
-    if (sum < best.sum * 0.99) {
-      rejected.push_back(best.p);
-      best = snapshot(p, sum);
-    } else {
-      rejected.push_back(p);
-    }
+// at the head of a visit: the candidate this visit runs (-1: none, the root has settled). Phase 0
+// walks the offsets once (store kind by the back end's rule), phase 1 runs the three fastest
+// offsets with both store kinds, then the root keeps the fastest sample of all; a later candidate
+// must win by more than the timing noise. The sample of the previous visit is a whole cycle of the
+// schedule old when it is read here: nothing waits.
+int CpEngine::ms_place_pick(PlaceExplore &ex) {
+  ms_place_collect(ex);
+  if (ex.phase == 0 && ex.next >= ex.cands.size()) {
+    std::vector<int> idx(ex.cands.size());
+    for (size_t q = 0; q < idx.size(); q++) idx[q] = (int)q;
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](int a, int b) { return ex.cands[a].best < ex.cands[b].best; });
+    const size_t nfin = std::min<size_t>(3, idx.size());
+    for (size_t q = 0; q < nfin; q++)
+      for (int kind = 0; kind < 2; kind++) {
+        PlaceCand c;
+        c.off = ex.cands[idx[q]].off;
+        c.nt = kind;
+        ex.cands.push_back(c);
+      }
+    ex.phase = 1;
   }
-  ops_.sync();
-  lay_[1].ptr = best.p;
-  for (int r : roots) {
-    ms_X_off_[r] = best.off[r];
-    ms_X_nt_[r] = best.nt[r];
+  if (ex.phase == 1 && ex.next >= ex.cands.size()) {
+    int best = -1;
+    for (size_t q = 0; q < ex.cands.size(); q++)
+      if (ex.cands[q].samples > 0 && (best < 0 || ex.cands[q].best < ex.cands[best].best * 0.995))
+        best = (int)q;
+    ex.chosen = best;  // (-1: no stopwatch ever answered — offset 0, store kind by size)
+    ex.phase = 2;
   }
-  for (void *p : rejected) ops_.free(p);
-}
-
-void CpEngine::ms_release_unchosen() {
-  // all roots in one further block: it becomes the primary one
-  void *common = ms_X_root_[0];
-  bool all = common != nullptr;
-  for (int r = 0; r < N_; r++)
-    if (ms_tuned_[r]) all = all && ms_X_root_[r] == common;
-  if (all) {
-    ops_.sync();
-    ops_.free(ms_X_base_);
-    ms_X_base_ = common;
-    for (int r = 0; r < MAX_ORDER; r++) ms_X_root_[r] = nullptr;
-    for (void *p : ms_X_alt_)
-      if (p != common) ops_.free(p);
-    ms_X_alt_.clear();
-    return;
-  }
-  std::vector<void *> keep;
-  for (void *p : ms_X_alt_) {
-    bool used = false;
-    for (int r = 0; r < N_; r++) used = used || ms_X_root_[r] == p;
-    if (used)
-      keep.push_back(p);
-    else
-      ops_.free(p);
-  }
-  ms_X_alt_.swap(keep);
+  return ex.phase < 2 ? (int)ex.next++ : -1;
 }
 
 // bytes of the first-level intermediate of the root set first .. first+k-1 (layout-independent)
@@ -1036,16 +948,16 @@ void CpEngine::ms_start_step(int first) {
   const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;
   // (an override — the LR optimizers' per-root caches — receives the scan's result itself: no block)
   if (!ms_X_override_ && ms_X_cap_ < xbytes + slack) {
+    // (the block moves: what the roots measured so far is void, they start over)
+    for (auto &ex : ms_place_) {
+      if (ex.timer >= 0) ops_.timer_read(ex.timer);
+      ex = PlaceExplore();
+    }
     ops_.free(ms_X_base_);
     ms_X_base_ = nullptr;
     ms_X_cap_ = 0;
-    for (void *p : ms_X_alt_) ops_.free(p);
-    ms_X_alt_.clear();
-    for (int r = 0; r < MAX_ORDER; r++) ms_X_root_[r] = nullptr;
     ms_X_base_ = big_alloc(xbytes + slack);
     ms_X_cap_ = xbytes + slack;
-    // (the offsets measured at session set-up stay valid — they are bounded by the slack — but
-    // nothing is re-measured here: this may be a timed sweep)
   }
   ScanPlan pl;
   if (!plan_scan(first, k, false, pl)) {
@@ -1069,86 +981,48 @@ void CpEngine::ms_start_step(int first) {
   ms_X_.contracted = mask;
   if ((size_t)L * T * R_ * dtype_size(ms_X_.dt) != xbytes)
     throw std::runtime_error("ppals: internal error (first-level intermediate size)");
-  auto launch_scan = [&](void *base, int64_t off) {
-    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)base + off;
-    ops_.scan_store_mode(ms_X_nt_[first]);
+  auto launch_scan = [&](int64_t off, int nt) {
+    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)ms_X_base_ + off;
+    ops_.scan_store_mode(nt);
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
     ops_.scan_store_mode(-1);
   };
-  if (slack > 0 && !ms_tuned_[first] && ms_tuning_now_ && !ms_X_override_) {
-    // one-off per root: time the real scan at a few placements, keep the fastest. Host-timed with
-    // a stream sync on both sides: only done when a launch is long against that (>= ~0.3 ms).
-    ms_tuned_[first] = true;
-    ms_X_off_[first] = 0;
-    ms_X_root_[first] = nullptr;
-    ms_X_nt_[first] = -1;
+  PlaceExplore &ex = ms_place_[first];
+  if (slack > 0 && !ms_X_override_ && ex.phase < 0) {
+    // first visit of the root: is its placement worth choosing? Only where the result stream
+    // matters — an HBM-bound scan (up to two n-tiles) of a tensor large enough for a launch to be
+    // long against the stopwatch, that writes at least 1 % of what it reads.
     static const int64_t cand_small[] = {0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64};
-    static const int64_t cand_alt[] = {0, 4, 16, 64};  // in each further block
     static const int64_t cand_large[] = {0, 3, 5, 12, 16, 24, 48, 64};
-    static const int64_t cand_large_alt[] = {0, 12, 48};
     const double bytes = (double)L * J * T * dtype_size(V_.dtype);
-    // (worth measuring only where the result stream matters: an HBM-bound scan — up to two
-    // n-tiles — that writes at least 1 % of what it reads)
+    ex.phase = 3;
+    ex.layout = (int)(pl.lay - lay_.data());
     if (bytes >= place_min_bytes() && R_ <= 32 && (double)xbytes >= 0.01 * bytes) {
-      const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates, one run each
-      const int reps = large ? 1 : 2;
-      double best = 1e300;
-      for (size_t b = 0; b <= ms_X_alt_.size(); b++) {
-        void *base = b == 0 ? ms_X_base_ : ms_X_alt_[b - 1];
-        const int64_t *cand_mb = b == 0 ? (large ? cand_large : cand_small) : (large ? cand_large_alt : cand_alt);
-        const int ncand = b == 0 ? (large ? 8 : 14) : (large ? 3 : 4);
-        for (int ci = 0; ci < ncand; ci++) {
-          const int64_t mb = cand_mb[ci];
-          const int64_t off = mb << 20;
-          if ((size_t)off > slack) break;
-          double tmin = 1e300;
-          for (int rep = 0; rep < reps; rep++) {
-            ops_.sync();
-            const double t0 = now();
-            launch_scan(base, off);
-            ops_.sync();
-            tmin = std::min(tmin, now() - t0);
-          }
-          // (tests: odd roots are made to prefer the given further block, so that the paths that
-          // keep, share and free candidate blocks run on the CPU stand-in as well)
-          if (const char *e = std::getenv("PPALS_PLACE_PREFER_BLOCK"))
-            if ((first & 1) && (int)b == std::atoi(e)) tmin *= 1e-3;
-          ms_place_worst_[first] = std::max(ms_place_worst_[first], tmin);
-          ms_place_ncand_[first]++;
-          if (tmin < best * 0.995) {  // a later candidate must win by more than the timing noise
-            best = tmin;
-            ms_X_off_[first] = off;
-            ms_X_root_[first] = b == 0 ? nullptr : base;
-            ms_place_block_[first] = (int)b;
-          }
-          if ((int)ms_cand_.size() <= first) ms_cand_.resize(first + 1);
-          if (ms_cand_[first].size() <= b) ms_cand_[first].resize(b + 1, {1e300, 0});
-          if (tmin < ms_cand_[first][b].first * 0.995) ms_cand_[first][b] = {tmin, off};
-        }
+      const bool large = bytes >= 2e10;  // a scan takes >= 4 ms: fewer candidates
+      const int64_t *mb = large ? cand_large : cand_small;
+      for (int ci = 0; ci < (large ? 8 : 14); ci++) {
+        if ((size_t)(mb[ci] << 20) > slack) break;
+        PlaceCand c;
+        c.off = mb[ci] << 20;
+        ex.cands.push_back(c);
       }
-      // the other kind of result store at the chosen placement (see hip_ops.hip, nt_store)
-      if (xbytes >= ((size_t)32 << 20)) {
-        double t_alt[2] = {1e300, 1e300};
-        void *base = ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_;
-        for (int kind = 0; kind < 2; kind++) {
-          ms_X_nt_[first] = kind;
-          for (int rep = 0; rep < reps + 1; rep++) {
-            ops_.sync();
-            const double t0 = now();
-            launch_scan(base, ms_X_off_[first]);
-            ops_.sync();
-            t_alt[kind] = std::min(t_alt[kind], now() - t0);
-          }
-        }
-        ms_X_nt_[first] = t_alt[1] < t_alt[0] ? 1 : 0;
-        best = std::min(t_alt[0], t_alt[1]);
-      }
-      ms_tuned_ms_[first] = best;
-      ms_root_layout_[first] = (int)(pl.lay - lay_.data());
+      ex.phase = 0;
     }
   }
-  launch_scan(ms_X_root_[first] ? ms_X_root_[first] : ms_X_base_, ms_X_off_[first]);
+  const int cand = (slack > 0 && !ms_X_override_ && ex.phase >= 0 && ex.phase < 2) ? ms_place_pick(ex) : -1;
+  if (cand >= 0) {
+    // an exploring visit: the sweep's own scan, at this candidate, under the stopwatch
+    ex.visits++;
+    ex.timer_cand = cand;
+    ex.timer = ops_.timer_begin();
+    launch_scan(ex.cands[cand].off, ex.cands[cand].nt);
+    if (ex.timer >= 0) ops_.timer_end(ex.timer);
+  } else if (ex.phase == 2 && ex.chosen >= 0 && slack > 0 && !ms_X_override_) {
+    launch_scan(ex.cands[ex.chosen].off, ex.cands[ex.chosen].nt);
+  } else {
+    launch_scan(0, -1);
+  }
   ms_X_.pending = false;
   ms_X_.valid = true;
   if (const char *tr = std::getenv("PPALS_TRACE_STEPS")) {  // tests: which root sets were scanned
@@ -1961,22 +1835,25 @@ void CpEngine::pp_build_all() {
   }
 }
 std::string CpEngine::placement_report() const {
-  char buf[256];
-  std::string out = "{\"measured\": ";
-  out += (ms_place_setup_s_ > 0 ? "true" : "false");
-  snprintf(buf, sizeof buf, ", \"setup_s\": %.4f, \"result_blocks_kept\": %d, \"roots\": [", ms_place_setup_s_,
-           (int)ms_X_alt_.size() + (ms_X_base_ ? 1 : 0));
-  out += buf;
+  char buf[320];
+  std::string out = "{\"mode\": ";
+  out += ms_tune_enabled_ && ms_X_slack() > 0 ? "\"online\"" : "\"off\"";
+  out += ", \"setup_s\": 0.0, \"roots\": [";
   bool firstrow = true;
   for (int r = 0; r < N_; r++) {
-    if (!ms_tuned_[r] || ms_place_ncand_[r] == 0) continue;
+    const PlaceExplore &ex = ms_place_[r];
+    if (ex.phase < 0 || ex.phase == 3 || ex.cands.empty()) continue;
+    const PlaceCand *c = ex.chosen >= 0 ? &ex.cands[ex.chosen] : nullptr;
+    double best = 1e300;
+    for (const auto &q : ex.cands)
+      if (q.samples > 0) best = std::min(best, q.best);
     snprintf(buf, sizeof buf,
-             "%s{\"root\": %d, \"layout\": \"%s\", \"block\": %d, \"offset_mb\": %lld, \"store\": \"%s\", "
-             "\"candidates\": %d, \"best_ms\": %.4f, \"worst_ms\": %.4f}",
-             firstrow ? "" : ", ", r, ms_root_layout_[r] == 1 ? "second (transposed) copy" : "tensor",
-             ms_place_block_[r], (long long)(ms_X_off_[r] >> 20),
-             ms_X_nt_[r] == 1 ? "non-temporal" : (ms_X_nt_[r] == 0 ? "ordinary" : "by size"), ms_place_ncand_[r],
-             ms_tuned_ms_[r] * 1e3, ms_place_worst_[r] * 1e3);
+             "%s{\"root\": %d, \"layout\": \"%s\", \"settled\": %s, \"visits\": %d, \"offset_mb\": %lld, "
+             "\"store\": \"%s\", \"best_ms\": %.4f, \"worst_ms\": %.4f}",
+             firstrow ? "" : ", ", r, ex.layout == 1 ? "second (transposed) copy" : "tensor",
+             ex.phase == 2 ? "true" : "false", ex.visits, c ? (long long)(c->off >> 20) : 0LL,
+             !c || c->nt < 0 ? "by size" : (c->nt == 1 ? "non-temporal" : "ordinary"),
+             best < 1e299 ? best * 1e3 : 0.0, ex.worst * 1e3);
     out += buf;
     firstrow = false;
   }

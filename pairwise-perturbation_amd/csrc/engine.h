@@ -176,36 +176,41 @@ class CpEngine {
   // Placement of the first-level intermediate: the scan reads the tensor and writes X at the same
   // time, and how the two streams fall onto the HBM channels depends on where X lies relative to
   // the tensor buffer — 6-9 % of the launch between placements of one and the same kernel
-  // (profiles/r02l_place_bench_*.txt), and 15 % between result blocks several GB apart: which block
-  // suits which source is a property of the PAIR (profiles/r03q_place6_pairs.txt: source x block
-  // matrix, 1.14 .. 1.33 ms). X lives at a per-root offset inside a per-root block chosen among a
-  // few candidate blocks spread over the device memory; block and offset are measured once per
-  // session, with the real scan, at set-up. Blocks no root chose are freed again.
-  void *ms_X_base_ = nullptr;            // primary block (every root's default)
-  std::vector<void *> ms_X_alt_;         // further candidate blocks of the same capacity
-  void *ms_X_root_[MAX_ORDER] = {nullptr};  // block chosen for a root (nullptr: the primary one)
+  // (profiles/r02l_place_bench_*.txt) — and on the kind of store. X lives at a per-root offset
+  // inside ONE block that is over-allocated by a slack of 64 MB. The offset and the store kind are
+  // found ONLINE: the first visits of a root run the sweep's REAL scan at one candidate each, timed
+  // by a pair of events on the stream (Ops::timer_*), read when the root comes round again; after
+  // ~20 visits the root keeps the fastest. No trial launches, no set-up time, the results do not
+  // depend on where X lies. PPALS_PLACE_TUNE=0: offset 0, store kind by size.
+  struct PlaceCand {
+    int64_t off = 0;
+    int nt = -1;           // store kind: -1 the back end's rule, 0 ordinary, 1 non-temporal
+    double best = 1e300;   // fastest sample, seconds
+    int samples = 0;
+  };
+  struct PlaceExplore {
+    int phase = -1;        // -1 not started, 0 offsets, 1 finalists x store kinds, 2 settled, 3 not worth it
+    size_t next = 0;       // candidate of the next visit
+    int timer = -1;        // stopwatch of the visit in flight (Ops::timer_begin)
+    int timer_cand = -1;
+    int chosen = -1;
+    int layout = 0;        // which resident layout the root's scan reads
+    double worst = 0;      // slowest sample seen, seconds
+    int visits = 0;
+    std::vector<PlaceCand> cands;
+  };
+  PlaceExplore ms_place_[MAX_ORDER];
+  void ms_place_collect(PlaceExplore &ex);
+  int ms_place_pick(PlaceExplore &ex);
+  void *ms_X_base_ = nullptr;
   size_t ms_X_cap_ = 0;
-  int64_t ms_X_off_[MAX_ORDER] = {0};
-  void ms_alloc_candidates(size_t cap);
-  void ms_release_unchosen();
-  int ms_X_nt_[MAX_ORDER];  // store kind of the root's scan: -1 the back end's rule, 0 ordinary, 1 non-temporal
-  void ms_tune_second_layout();
-  double ms_tuned_ms_[MAX_ORDER] = {0};   // the chosen placement's scan time, seconds
-  int ms_root_layout_[MAX_ORDER] = {0};   // which resident layout the root's scan reads
-  std::vector<std::vector<std::pair<double, int64_t>>> ms_cand_;  // [root][block] -> (ms, offset)
-  // what the measurement saw, for the caller's records (placement_report)
-  double ms_place_worst_[MAX_ORDER] = {0};  // slowest candidate of the root, seconds
-  int ms_place_ncand_[MAX_ORDER] = {0}, ms_place_block_[MAX_ORDER] = {0};
-  double ms_place_setup_s_ = 0;
   int64_t pp_builds_ = 0;
   double pp_build_s_ = 0;
   bool pp_build_timed_ = false;
-  bool ms_tuned_[MAX_ORDER] = {false};
   bool ms_tune_enabled_ = true;
   size_t ms_X_slack() const;
   static double place_min_bytes();
   size_t ms_X_bytes(int first, int k) const;
-  bool ms_tuning_now_ = false;  // placement is measured at session set-up only
   void *big_alloc(size_t bytes);  // gives optional resident layouts back when the device is full
   std::vector<MsNode> ms_nodes_;
   // ---- low-rank-update optimizers of the class API (CPDTLROptimizer / CPMSDTLROptimizer,

@@ -119,6 +119,10 @@ class HipOps : public Ops {
       hipEventDestroy(ev.a);
       hipEventDestroy(ev.b);
     }
+    for (auto &t : timers_) {
+      hipEventDestroy(t.a);
+      hipEventDestroy(t.b);
+    }
     if (ws_pack_) hipFree(ws_pack_);
     if (ws_slab_) hipFree(ws_slab_);
     if (ws_krp_) hipFree(ws_krp_);
@@ -2625,6 +2629,45 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
 
+  // ------------------------------------------------------------------ stopwatch (ops.h)
+  int timer_begin() override {
+    int h = -1;
+    for (size_t q = 0; q < timers_.size(); q++)
+      if (!timers_[q].busy) h = (int)q;
+    if (h < 0) {
+      if (timers_.size() >= 64) return -1;
+      Timer t;
+      if (hipEventCreate(&t.a) != hipSuccess) return -1;
+      if (hipEventCreate(&t.b) != hipSuccess) {
+        hipEventDestroy(t.a);
+        return -1;
+      }
+      timers_.push_back(t);
+      h = (int)timers_.size() - 1;
+    }
+    timers_[h].busy = true;
+    timers_[h].ended = false;
+    if (hipEventRecord(timers_[h].a, st_) != hipSuccess) {
+      timers_[h].busy = false;
+      return -1;
+    }
+    return h;
+  }
+  void timer_end(int h) override {
+    if (h < 0 || h >= (int)timers_.size() || !timers_[h].busy) return;
+    timers_[h].ended = hipEventRecord(timers_[h].b, st_) == hipSuccess;
+  }
+  double timer_read(int h) override {
+    if (h < 0 || h >= (int)timers_.size() || !timers_[h].busy) return -1.0;
+    Timer &t = timers_[h];
+    t.busy = false;
+    float ms = 0;
+    if (!t.ended || hipEventSynchronize(t.b) != hipSuccess ||
+        hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess)
+      return -1.0;
+    return 1e-3 * (double)ms;
+  }
+
   // ------------------------------------------------------------------ profiling
   void profile_enable(int level) override { profiling_ = level; }
   void profile_collect() override {
@@ -2658,6 +2701,11 @@ class HipOps : public Ops {
     return rs_;
   }
   RocSolver rs_;
+  struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool busy = false, ended = false;
+  };
+  std::vector<Timer> timers_;
   struct Ev {
     hipEvent_t a, b;
     int slot;

@@ -332,6 +332,14 @@ class Ops {
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
 
 
+  // A stopwatch on the launch stream (the online placement choice of the multi-sweep schedule):
+  // timer_begin() marks the stream and returns a handle (-1: no stopwatch to be had), timer_end(h)
+  // marks it again, timer_read(h) returns the seconds between the two marks once both have been
+  // reached — waiting for them if need be — and gives the handle back. Nothing else synchronises.
+  virtual int timer_begin() { return -1; }
+  virtual void timer_end(int /*h*/) {}
+  virtual double timer_read(int /*h*/) { return -1.0; }
+
   // profiling of the scan kernels (HIP events on the launch stream)
   virtual void profile_enable(int /*level*/) {}
   virtual void profile_collect() {}

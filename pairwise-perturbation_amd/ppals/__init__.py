@@ -288,7 +288,7 @@ class CP:
         return {0: "dt", 1: "msdt"}[_check(lib().ppals_cp_get_schedule(self._h))]
 
     def placement_report(self):
-        """what the set-up's placement measurement chose per root of the multi-sweep schedule (dict)"""
+        """where the online placement choice put each root's first-level intermediate (dict)"""
         import json
         buf = C.create_string_buffer(8192)
         _check(lib().ppals_cp_placement_report(self._h, buf, 8192))

@@ -91,6 +91,16 @@ class HostOps : public Ops {
   void d2d(void *d, const void *s, size_t n) override { std::memmove(d, s, n); }
   void zero(void *p, size_t n) override { std::memset(p, 0, n); }
   void sync() override {}
+  // the stopwatch of the online placement choice: a deterministic pseudo-duration per call, so that
+  // the roots of a test session settle on DIFFERENT candidates (offsets, store kinds) run after run
+  int timer_begin() override { return (int)(timer_calls_++ & 0x3fffffff); }
+  void timer_end(int) override {}
+  double timer_read(int h) override {
+    if (h < 0) return -1.0;
+    const uint32_t x = (uint32_t)h * 2654435761u;
+    return 1e-3 * (1.0 + 0.1 * (double)((x >> 16) & 15) / 15.0);
+  }
+  uint64_t timer_calls_ = 0;
 
   void fill_uniform(void *V, int dt, int64_t l0, int64_t g0, int64_t row0, int64_t rest,
                     uint64_t seed, double lo, double hi) override {

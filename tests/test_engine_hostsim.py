@@ -85,23 +85,26 @@ def test_context_destroyed_before_its_children(pp):
 
 
 def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
-    """the set-up measurement of the multi-sweep schedule (candidate result blocks, copies of the
-    second resident layout, store kind per root: engine.cpp ms_alloc_candidates /
-    ms_tune_second_layout) only chooses WHERE buffers lie: with the size threshold lowered so that a
-    small tensor goes through all of it, sweeps give bit-identical factors to a session that
-    measured nothing — and the machinery runs under the sanitizer build (test_sanitizers.py)"""
+    """the ONLINE placement choice of the multi-sweep schedule (engine.cpp ms_place_pick: the first
+    ~20 visits of every root run the sweep's own scan at a different offset / store kind of the
+    result, under a stopwatch) only chooses WHERE a buffer lies: with the size threshold lowered so
+    that a small tensor goes through all of it, sweeps give bit-identical factors to a session that
+    explores nothing, every root settles, and nothing was spent at set-up — and the machinery runs
+    under the sanitizer build (test_sanitizers.py)"""
     lens, R = [9, 8, 7, 6], 3
     W0 = pp.init_factors(lens, R, 5)
+    reports = {}
 
-    def run(env):
+    def run(name, env, sweeps):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = pp.Context(0)
         t = pp.Tensor(c, lens, 1).fill_uniform(11)
         s = pp.CP(c, t, R)
         s.set_factors(W0)
-        s.sweeps_dt(4)
+        s.sweeps_dt(sweeps)
         out = [w.copy() for w in s.get_factors()]
+        reports[name] = s.placement_report()
         s.close()
         t.close()
         c.close()
@@ -109,11 +112,18 @@ def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
             monkeypatch.delenv(k)
         return out
 
-    plain = run({"PPALS_PLACE_TUNE": "0"})
-    tuned = run({"PPALS_PLACE_MIN_MB": "0"})
-    mixed = run({"PPALS_PLACE_MIN_MB": "0", "PPALS_PLACE_PREFER_BLOCK": "2"})   # odd roots elsewhere
-    for a, b, d in zip(plain, tuned, mixed):
-        assert (a == b).all() and (a == d).all()
+    for sweeps in (4, 64):      # in the middle of the exploration / after every root has settled
+        plain = run("plain", {"PPALS_PLACE_TUNE": "0"}, sweeps)
+        tuned = run("tuned", {"PPALS_PLACE_MIN_MB": "0"}, sweeps)
+        for a, b in zip(plain, tuned):
+            assert (a == b).all()
+    assert reports["plain"]["mode"] == "off" and reports["plain"]["roots"] == []
+    rep = reports["tuned"]
+    assert rep["mode"] == "online" and rep["setup_s"] == 0.0 and len(rep["roots"]) in (2, 4)  # (root sets of 2 or 1 modes)
+    for r in rep["roots"]:
+        assert r["settled"] and r["visits"] == 14 + 6 and r["worst_ms"] >= r["best_ms"] > 0
+    # (the stand-in's stopwatch is a hash of the call count: the roots do not all agree)
+    assert len({(r["offset_mb"], r["store"]) for r in rep["roots"]}) > 1
 
 
 @pytest.mark.parametrize("sched", ["ms", "tree"])
