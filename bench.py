@@ -483,6 +483,108 @@ def shard_probe_record(ppals, torch, local_rank):
     return out
 
 
+def sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure, barrier):
+    """N > 1: BASELINE configs[3] (CP order-4 s=400 R=20 block-partitioned over the N ranks, both
+    collective plans: script/script_strongscaling.py:10,45-46 is the reference's analogue) and the
+    N-GPU leg of configs[4] (Tucker order-3 s=400 core 20^3 sharded: hosvd + alsTucker_DT sweeps,
+    als_Tucker.cxx:12-70,240-424). Times are max over ranks between barriers; the scan roofline is
+    per rank (its own shard's bytes; the slowest rank's average launch). The CPU rehearsal
+    (PPALS_BENCH_BACKEND=hostsim) runs the same code on shrunken shapes."""
+    out = {}
+
+    def max_over_ranks(x, op=None):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=op or dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn):
+        barrier()
+        t0 = time.perf_counter()
+        fn()
+        ctx.sync()
+        if not hostsim:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return max_over_ranks(dt)
+
+    # ---- configs[3]
+    lens4, R4 = ([12, 12, 12, 12], 3) if hostsim else WORKLOADS["cp4_s400_r20"]
+    f32 = ppals.F64 if hostsim else ppals.F32
+    try:
+        V4 = ppals.Tensor(ctx, lens4, f32).fill_cp(ppals.init_factors(lens4, R4, 1000))
+        W4, G4 = ppals.init_factors(lens4, R4, 2000), ppals.init_factors(lens4, R4, 3000)
+        rec = {"config": f"BASELINE configs[3]: CP order-4 s={lens4[0]} R={R4} -tensor r, leading-mode blocks "
+                         f"over {world} ranks, 2 warm-up + 5 timed exact sweeps per collective plan",
+               "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32"}
+        for plan, small in (("allreduce_plan", None), ("reduce_scatter_plan", "0")):
+            old = os.environ.get("PPALS_COMM_SMALL_BYTES")
+            if small is not None:
+                os.environ["PPALS_COMM_SMALL_BYTES"] = small
+            try:
+                cp4 = ppals.CP(ctx, V4, R4)
+                r = measure(cp4, 5, 2, W4, G4)
+                r["sweep_flops"] = sweep_flops(lens4, R4, cp4.schedule)
+                r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
+                r["comm_plan"] = ("one all-reduce of the s x R partials per mode + redundant fused update"
+                                  if small is None else "reduce-scatter + row-block update + all-gather per mode")
+                if "roofline" in r:
+                    rl = r["roofline"]
+                    rl["avg_launch_ms_slowest_rank"] = max_over_ranks(rl["avg_launch_ms"])
+                    rl["avg_launch_ms_fastest_rank"] = max_over_ranks(rl["avg_launch_ms"], dist.ReduceOp.MIN)
+                    rl["frac_slowest_rank"] = (rl["algorithmic_bytes_per_launch"] /
+                                               (rl["avg_launch_ms_slowest_rank"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                    rl["note"] = "rank 0's shard: bytes of ITS scans / ITS average launch; *_slowest_rank over all ranks"
+                r["final_gradnorm"] = cp4.gradnorm()
+                rec[plan] = r
+                cp4.close()
+            finally:
+                if small is not None:
+                    if old is None:
+                        del os.environ["PPALS_COMM_SMALL_BYTES"]
+                    else:
+                        os.environ["PPALS_COMM_SMALL_BYTES"] = old
+        V4.close()
+        out["cfg4_sharded"] = rec
+    except Exception as e:  # reported, never required
+        out["cfg4_sharded"] = {"error": str(e)}
+
+    # ---- configs[4], N-GPU leg
+    lens5, ranks5, nsw = ([14, 12, 10], [3, 3, 3], 4) if hostsim else ([400, 400, 400], [20, 20, 20], 20)
+    try:
+        V5 = ppals.Tensor(ctx, lens5, f32).fill_uniform(7)
+        tk = ppals.Tucker(ctx, V5, ranks5)
+        tk.hosvd()                      # warm-up of the one-off paths
+        tk.close()
+        tk = ppals.Tucker(ctx, V5, ranks5)   # a new session: nothing known about the Grams
+        hosvd_s = timed(tk.hosvd)
+        tk.sweeps_dt(2)
+        ctx.profile_reset()
+        ctx.profile_enable(1)
+        sweeps_s = timed(lambda: tk.sweeps_dt(nsw))
+        ctx.profile_enable(0)
+        ls, scan_ms, scan_bytes = ctx.profile_read(0)
+        rec = {"config": f"BASELINE configs[4] on {world} ranks: Tucker order-3 s={lens5[0]} core "
+                         f"{'x'.join(map(str, ranks5))}, -tensor r2, leading-mode blocks; hosvd + 2 warm-up + "
+                         f"{nsw} timed HOOI sweeps (alsTucker_DT)",
+               "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32",
+               "hosvd_ms": 1e3 * hosvd_s, "ms_per_hooi_sweep": 1e3 * sweeps_s / nsw, "sweeps": nsw}
+        if ls > 0 and scan_ms > 0:
+            avg = scan_ms / ls
+            rec["roofline"] = {"bound": "hbm", "achieved": scan_bytes / ls / (avg * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": scan_bytes / ls / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "launches": ls, "avg_launch_ms": avg,
+                               "avg_launch_ms_slowest_rank": max_over_ranks(avg),
+                               "algorithmic_bytes_per_launch": scan_bytes / ls,
+                               "kernel": "tensor scans of the TTMc chain (K11), rank 0's shard"}
+        tk.close()
+        V5.close()
+        out["cfg5_tucker_sharded"] = rec
+    except Exception as e:  # reported, never required
+        out["cfg5_tucker_sharded"] = {"error": str(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,7 +597,8 @@ def main():
                     help="sweep schedule (default: the engine's, msdt); same ALS iterates either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-records", action="store_true",
-                    help="skip the cfg3 (PP) / cfg4 (s=400) / cfg5 (Tucker) sub_records at N = 1")
+                    help="skip the cfg3 (PP) / cfg4 (s=400) / cfg5 (Tucker) sub_records (N = 1) and the sharded "
+                         "cfg4 / cfg5 sub_records (N > 1)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not count HBM bytes with rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -535,7 +638,13 @@ def main():
     config_records = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_config_records
                       and args.workload == "cp4_s200_r10" and args.dtype == "f32"
                       and not args.schedule)
-    if config_records:
+    # N > 1: the sharded records of configs[3] / configs[4] (the driver's scaling runs use the default flags)
+    # (PPALS_FORCE_COMM=1: the same records on a one-rank communicator — the rehearsal on a 1-GPU box)
+    sharded_records = ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PPALS_FORCE_COMM", "0") == "1")
+                       and not args.no_config_records
+                       and not args.schedule
+                       and ((args.workload == "cp4_s200_r10" and args.dtype == "f32") or hostsim))
+    if (config_records or sharded_records) and not hostsim:
         # the Tucker record's HOSVD uses rocSOLVER: its libraries must enter the process before the
         # HIP runtime is up (include/ppals.h, ppals_preload_eigensolver)
         ppals.preload_eigensolver()
@@ -767,6 +876,8 @@ def main():
         else:
             os.environ["PPALS_COMM_SMALL_BYTES"] = old
     cp.close()
+    if sharded_records:
+        sub.update(sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure, barrier))
     if config_records:
         import tempfile
         with tempfile.TemporaryDirectory() as tmpdir:

@@ -282,17 +282,25 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     for (int m = 0; m < N_; m++) nat.order.push_back(m);
     lay_.push_back(nat);
   }
-  ensure_transposed();
-  if (schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0) {
-    // The block of the first-level intermediate is sized ONCE, for the largest root set plus the
-    // slack the online placement choice moves inside (ms_start_step): growing it later would move
-    // every root's result and void what the first visits measured (unequal mode extents,
-    // [s/P, s, s, s] shards). Nothing is launched or measured here.
-    size_t xmax = 0;
+  // The block of the first-level intermediate is sized ONCE, for the largest root set plus the
+  // slack the online placement choice moves inside (ms_start_step): growing it later would move
+  // every root's result and void what the first visits measured (unequal mode extents,
+  // [s/P, s, s, s] shards). A second candidate block is taken BEFORE the second resident layout, the
+  // primary one after it: the layout's bytes lie between them. Nothing is launched or measured here.
+  size_t xmax = 0;
+  const bool place = schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0;
+  if (place) {
     for (int r = 0; r < N_; r++) {
       if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
       xmax = std::max(xmax, ms_X_bytes(r, ms_k_));
     }
+    const size_t avail = ops_.mem_available();
+    const double tensor_bytes = (double)V_.nloc * dtype_size(V_.dtype);
+    if (avail == (size_t)-1 || (double)avail > 2.0 * tensor_bytes + 6.0 * (double)(xmax + ms_X_slack()) + 8e9)
+      ms_X_alt_ = ops_.try_alloc(xmax + ms_X_slack());
+  }
+  ensure_transposed();
+  if (place) {
     ms_X_base_ = big_alloc(xmax + ms_X_slack());
     ms_X_cap_ = xmax + ms_X_slack();
   }
@@ -344,6 +352,7 @@ CpEngine::~CpEngine() {
   for (auto &ex : ms_place_)
     if (ex.timer >= 0) ops_.timer_read(ex.timer);
   ops_.free(ms_X_base_);
+  ops_.free(ms_X_alt_);
   ops_.free(ms_scales_);
   for (auto &n : ms_nodes_) {
     ops_.free(n.t.buf);
@@ -888,6 +897,7 @@ int CpEngine::ms_place_pick(PlaceExplore &ex) {
     for (size_t q = 0; q < nfin; q++)
       for (int kind = 0; kind < 2; kind++) {
         PlaceCand c;
+        c.blk = ex.cands[idx[q]].blk;
         c.off = ex.cands[idx[q]].off;
         c.nt = kind;
         ex.cands.push_back(c);
@@ -901,8 +911,31 @@ int CpEngine::ms_place_pick(PlaceExplore &ex) {
         best = (int)q;
     ex.chosen = best;  // (-1: no stopwatch ever answered — offset 0, store kind by size)
     ex.phase = 2;
+    ms_place_release_unchosen();
   }
   return ex.phase < 2 ? (int)ex.next++ : -1;
+}
+
+// once every exploring root has settled: a candidate block nobody chose goes back to the device
+void CpEngine::ms_place_release_unchosen() {
+  if (!ms_X_alt_) return;
+  bool use[2] = {false, false};
+  for (const auto &ex : ms_place_) {
+    if (ex.phase == 0 || ex.phase == 1) return;  // somebody still explores
+    if (ex.phase == 2) use[ex.chosen >= 0 ? ex.cands[ex.chosen].blk : 0] = true;
+  }
+  if (use[0] && use[1]) return;
+  ops_.sync();
+  if (!use[1]) {
+    ops_.free(ms_X_alt_);
+  } else {  // every root prefers the block in front of the layout: it becomes the only one
+    ops_.free(ms_X_base_);
+    ms_X_base_ = ms_X_alt_;
+    for (auto &ex : ms_place_)
+      for (auto &c : ex.cands) c.blk = 0;
+  }
+  ms_X_alt_ = nullptr;
+  // (called at the head of a step, before its scan: no first-level intermediate is alive)
 }
 
 // bytes of the first-level intermediate of the root set first .. first+k-1 (layout-independent)
@@ -954,7 +987,8 @@ void CpEngine::ms_start_step(int first) {
       ex = PlaceExplore();
     }
     ops_.free(ms_X_base_);
-    ms_X_base_ = nullptr;
+    ops_.free(ms_X_alt_);
+    ms_X_base_ = ms_X_alt_ = nullptr;
     ms_X_cap_ = 0;
     ms_X_base_ = big_alloc(xbytes + slack);
     ms_X_cap_ = xbytes + slack;
@@ -981,8 +1015,9 @@ void CpEngine::ms_start_step(int first) {
   ms_X_.contracted = mask;
   if ((size_t)L * T * R_ * dtype_size(ms_X_.dt) != xbytes)
     throw std::runtime_error("ppals: internal error (first-level intermediate size)");
-  auto launch_scan = [&](int64_t off, int nt) {
-    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_ : (char *)ms_X_base_ + off;
+  auto launch_scan = [&](int blk, int64_t off, int nt) {
+    ms_X_.buf = ms_X_override_ ? (char *)ms_X_override_
+                               : (char *)(blk == 1 && ms_X_alt_ ? ms_X_alt_ : ms_X_base_) + off;
     ops_.scan_store_mode(nt);
     ops_.scan_contract(src, V_.dtype, pl.L, J, T, f.data(), (int)f.size(), R_, ms_X_.buf, ms_X_.dt,
                        L, L * T, pl.pad);
@@ -1007,6 +1042,14 @@ void CpEngine::ms_start_step(int first) {
         c.off = mb[ci] << 20;
         ex.cands.push_back(c);
       }
+      static const int64_t cand_alt[] = {0, 4, 16, 64};  // in the second block
+      for (int ci = 0; ms_X_alt_ && ci < 4; ci++) {
+        if ((size_t)(cand_alt[ci] << 20) > slack) break;
+        PlaceCand c;
+        c.blk = 1;
+        c.off = cand_alt[ci] << 20;
+        ex.cands.push_back(c);
+      }
       ex.phase = 0;
     }
   }
@@ -1016,12 +1059,12 @@ void CpEngine::ms_start_step(int first) {
     ex.visits++;
     ex.timer_cand = cand;
     ex.timer = ops_.timer_begin();
-    launch_scan(ex.cands[cand].off, ex.cands[cand].nt);
+    launch_scan(ex.cands[cand].blk, ex.cands[cand].off, ex.cands[cand].nt);
     if (ex.timer >= 0) ops_.timer_end(ex.timer);
   } else if (ex.phase == 2 && ex.chosen >= 0 && slack > 0 && !ms_X_override_) {
-    launch_scan(ex.cands[ex.chosen].off, ex.cands[ex.chosen].nt);
+    launch_scan(ex.cands[ex.chosen].blk, ex.cands[ex.chosen].off, ex.cands[ex.chosen].nt);
   } else {
-    launch_scan(0, -1);
+    launch_scan(0, 0, -1);
   }
   ms_X_.pending = false;
   ms_X_.valid = true;
@@ -1838,7 +1881,9 @@ std::string CpEngine::placement_report() const {
   char buf[320];
   std::string out = "{\"mode\": ";
   out += ms_tune_enabled_ && ms_X_slack() > 0 ? "\"online\"" : "\"off\"";
-  out += ", \"setup_s\": 0.0, \"roots\": [";
+  out += ", \"setup_s\": 0.0, \"candidate_blocks_held\": ";
+  out += ms_X_alt_ ? "2" : "1";
+  out += ", \"roots\": [";
   bool firstrow = true;
   for (int r = 0; r < N_; r++) {
     const PlaceExplore &ex = ms_place_[r];
@@ -1848,10 +1893,10 @@ std::string CpEngine::placement_report() const {
     for (const auto &q : ex.cands)
       if (q.samples > 0) best = std::min(best, q.best);
     snprintf(buf, sizeof buf,
-             "%s{\"root\": %d, \"layout\": \"%s\", \"settled\": %s, \"visits\": %d, \"offset_mb\": %lld, "
+             "%s{\"root\": %d, \"layout\": \"%s\", \"settled\": %s, \"visits\": %d, \"block\": %d, \"offset_mb\": %lld, "
              "\"store\": \"%s\", \"best_ms\": %.4f, \"worst_ms\": %.4f}",
              firstrow ? "" : ", ", r, ex.layout == 1 ? "second (transposed) copy" : "tensor",
-             ex.phase == 2 ? "true" : "false", ex.visits, c ? (long long)(c->off >> 20) : 0LL,
+             ex.phase == 2 ? "true" : "false", ex.visits, c ? c->blk : 0, c ? (long long)(c->off >> 20) : 0LL,
              !c || c->nt < 0 ? "by size" : (c->nt == 1 ? "non-temporal" : "ordinary"),
              best < 1e299 ? best * 1e3 : 0.0, ex.worst * 1e3);
     out += buf;

@@ -177,12 +177,16 @@ class CpEngine {
   // time, and how the two streams fall onto the HBM channels depends on where X lies relative to
   // the tensor buffer — 6-9 % of the launch between placements of one and the same kernel
   // (profiles/r02l_place_bench_*.txt) — and on the kind of store. X lives at a per-root offset
-  // inside ONE block that is over-allocated by a slack of 64 MB. The offset and the store kind are
-  // found ONLINE: the first visits of a root run the sweep's REAL scan at one candidate each, timed
+  // inside one of TWO blocks over-allocated by a slack of 64 MB — one taken before the session's
+  // second resident layout, one after it, so that they lie several GB apart at no cost (which block
+  // suits which source is a property of the pair, profiles/r03_place_regions.md). Block, offset and
+  // store kind are found ONLINE: the first visits of a root run the sweep's REAL scan at one candidate each, timed
   // by a pair of events on the stream (Ops::timer_*), read when the root comes round again; after
-  // ~20 visits the root keeps the fastest. No trial launches, no set-up time, the results do not
-  // depend on where X lies. PPALS_PLACE_TUNE=0: offset 0, store kind by size.
+  // ~24 visits the root keeps the fastest; a block no root chose is freed. No trial launches, no
+  // set-up time, the results do not depend on where X lies. PPALS_PLACE_TUNE=0: one block, offset 0,
+  // store kind by size.
   struct PlaceCand {
+    int blk = 0;           // 0: the block allocated behind the second resident layout, 1: the one in front of it
     int64_t off = 0;
     int nt = -1;           // store kind: -1 the back end's rule, 0 ordinary, 1 non-temporal
     double best = 1e300;   // fastest sample, seconds
@@ -203,6 +207,8 @@ class CpEngine {
   void ms_place_collect(PlaceExplore &ex);
   int ms_place_pick(PlaceExplore &ex);
   void *ms_X_base_ = nullptr;
+  void *ms_X_alt_ = nullptr;  // the second candidate block (nullptr: none / released)
+  void ms_place_release_unchosen();
   size_t ms_X_cap_ = 0;
   int64_t pp_builds_ = 0;
   double pp_build_s_ = 0;

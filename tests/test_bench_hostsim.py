@@ -56,6 +56,17 @@ def test_bench_multi_rank_path_on_the_host_stand_in(world):
     assert f"x{world}" in d["config"]["sharding"]
     rs = d["sub_records"]["reduce_scatter_plan"]
     assert rs["value"] > 0 and "reduce-scatter" in rs["comm_plan"]
+    # the N > 1 line carries BASELINE configs[3] and the N-GPU leg of configs[4] (shrunken here)
+    c4 = d["sub_records"]["cfg4_sharded"]
+    assert "error" not in c4, c4
+    assert c4["rccl_ranks"] == world
+    for plan in ("allreduce_plan", "reduce_scatter_plan"):
+        assert c4[plan]["steps"] == 5 and c4[plan]["value"] > 0 and c4[plan]["ms_per_step"] > 0
+    g = [c4[p_]["final_gradnorm"] for p_ in ("allreduce_plan", "reduce_scatter_plan")]
+    assert abs(g[0] - g[1]) < 1e-8 * abs(g[0])       # same iterates on both collective plans
+    c5 = d["sub_records"]["cfg5_tucker_sharded"]
+    assert "error" not in c5, c5
+    assert c5["rccl_ranks"] == world and c5["hosvd_ms"] > 0 and c5["ms_per_hooi_sweep"] > 0
     # the same ALS iterates on every shard plan: the run ends at the same gradient norm as one rank
     env = dict(os.environ, PPALS_BENCH_BACKEND="hostsim", OMP_NUM_THREADS="2")
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
