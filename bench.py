@@ -254,6 +254,7 @@ def live_pmc_traffic(args, timeout_s=240):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     rp = shutil.which("rocprofv3")
@@ -266,12 +267,26 @@ def live_pmc_traffic(args, timeout_s=240):
             cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
                    "--workload", args.workload, "--dtype", args.dtype,
-                   "--schedule", args.schedule or "msdt", "--no-cpu-baseline", "--no-pmc"]
+                   "--schedule", args.schedule or "msdt", "--no-cpu-baseline", "--no-pmc", "--pmc-child"]
             env = dict(os.environ, TMPDIR="/tmp")
+            # (its own session / process group: on a timeout the profiled python grandchild is killed
+            # with the launcher — it would otherwise keep the GPU busy under the headline's timed region)
             try:
-                pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
-                                    stderr=subprocess.STDOUT, timeout=timeout_s)
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, start_new_session=True)
             except Exception as e:
+                return None, f"rocprofv3 --pmc {counter} child: {e}"
+            try:
+                pr.communicate(timeout=timeout_s)
+            except Exception as e:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+                try:
+                    pr.communicate(timeout=30)
+                except Exception:
+                    pass
                 return None, f"rocprofv3 --pmc {counter} child: {e}"
             if pr.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} child exited {pr.returncode}"
@@ -285,7 +300,7 @@ def live_pmc_traffic(args, timeout_s=240):
             got[counter] = (sum(vals) / len(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0),
                             len(vals))
     src = ("counted in this run: child passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` of this "
-           f"command (3 sweeps), mean over {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of "
+           f"command (1 warm-up + 2 sweeps, nothing else), mean over {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of "
            f"k_scan_suffix*: fetch {got['FETCH_SIZE'][0]:.4e} B (FETCH_SIZE KiB x 2, gfx950) + write "
            f"{got['WRITE_SIZE'][0]:.4e} B")
     return got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0], src
@@ -599,6 +614,7 @@ def main():
     ap.add_argument("--no-config-records", action="store_true",
                     help="skip the cfg3 (PP) / cfg4 (s=400) / cfg5 (Tucker) sub_records (N = 1) and the sharded "
                          "cfg4 / cfg5 sub_records (N > 1)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # live_pmc_traffic's child runs
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not count HBM bytes with rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -756,6 +772,14 @@ def main():
     # the warm-up, and reported: `placement.settle_sweeps` / `settle_s`; what the choice is worth on a
     # run of the reference's length, exploration included, is sub_records.time_to_250_sweeps.
     settle_sweeps, settle_s = 0, 0.0
+    if args.pmc_child:
+        # the counted pass: the sweeps of the workload and nothing else, so that the counter rows are
+        # the scan launches of exactly (warmup + steps) sweeps
+        measure(cp, args.steps, args.warmup)
+        cp.close()
+        V.close()
+        ctx.close()
+        return
     try:
         t0 = time.perf_counter()
         while settle_sweeps < 120:

@@ -2,6 +2,7 @@
 // launched on one engine-owned stream. No CPU fallback: construction throws without a HIP device.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstdio>
@@ -1613,13 +1614,39 @@ class HipOps : public Ops {
       HIP_CHECK(hipMalloc(&handover_, 16));
       HIP_CHECK(hipMemset(handover_, 0, 16));
       HIP_CHECK(hipDeviceSynchronize());
-      // (a runtime without stream memory operations: the event hand-over takes its place. The probe is
-      // a wait that is satisfied at once.)
-      if (handover_ok_ &&
-          (hipStreamWaitValue64(st2_, handover_, 0, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull) != hipSuccess ||
-           hipStreamSynchronize(st2_) != hipSuccess)) {
+      // A runtime without stream memory operations, or one on which a value stored by a KERNEL is not
+      // seen by the waiting stream, gets the event hand-over instead. The probe is the real thing once:
+      // a one-workgroup kernel on the sweep's stream publishes 1, the second stream waits for it and
+      // records an event, which must arrive within a deadline. If it does not, the second stream is
+      // released from the host and the flag is never waited on again.
+      if (handover_ok_) {
+        hipEvent_t probe = nullptr;
+        bool ok = hipEventCreateWithFlags(&probe, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamWaitValue64(st2_, handover_, 1, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull) == hipSuccess;
+        if (ok) {
+          ok = hipEventRecord(probe, st2_) == hipSuccess;
+          hipLaunchKernelGGL(k_handover_probe, dim3(1), dim3(64), 0, st_, handover_, 1ull);
+          ok = ok && hipGetLastError() == hipSuccess;
+          const auto t0 = std::chrono::steady_clock::now();
+          bool arrived = false;
+          while (ok && !arrived) {
+            const hipError_t q = hipEventQuery(probe);
+            if (q == hipSuccess) arrived = true;
+            else if (q != hipErrorNotReady) ok = false;
+            else if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) break;
+          }
+          if (!arrived) {
+            // release the waiting stream whatever went wrong (the wait is queued already)
+            const unsigned long long one = 1;
+            (void)hipMemcpy(handover_, &one, sizeof one, hipMemcpyHostToDevice);
+            (void)hipStreamSynchronize(st2_);
+            ok = false;
+          }
+        }
+        if (probe) hipEventDestroy(probe);
         (void)hipGetLastError();
-        handover_ok_ = false;
+        if (!ok) handover_ok_ = false;
+        handover_seq_ = 1;  // (sequence numbers go on from the probe's)
       }
     }
     if (!es.Hd) {
@@ -1860,6 +1887,11 @@ class HipOps : public Ops {
                          C1, Uout, status, chk,
                          es.chkd, by_flag ? (unsigned *)(handover_ + 1) : (unsigned *)nullptr,
                          by_flag ? handover_ : (unsigned long long *)nullptr, seq);
+      // (a launch that failed never publishes its number: nothing may be queued behind it)
+      if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+        if (by_flag) --handover_seq_;
+        throw std::runtime_error(std::string("ppals: k_rmult_chol launch failed: ") + hipGetErrorString(le));
+      }
       if (!own_gram) gemm_nn(G, J, Uout, J, nullptr, 0, es.GBd, J, Ji, cols, Ji, 1.0, 0.0);
       es.jacobi_launched = true;
       if (by_flag) {

@@ -645,6 +645,15 @@ __global__ __launch_bounds__(256) void k_unfold_syrk_f32(const float *__restrict
     }
 }
 
+// the probe of the stored-value hand-over (HipOps::lazy_prepare): publishes `seq` the way the last
+// workgroup of k_rmult_chol does
+__global__ void k_handover_probe(unsigned long long *flag, unsigned long long seq) {
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // X = (G - sigma I) / rho   (J x J)
 __global__ void k_shift_scale(const double *__restrict__ G, int64_t J, double sigma, double inv_rho,
                               double *__restrict__ X) {

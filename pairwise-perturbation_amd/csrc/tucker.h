@@ -89,6 +89,9 @@ class TuckerEngine {
   // factors in the same order (every product of a step sees exactly the factor versions alsTucker_DT's
   // tree gives it). Needs the tensor in all three rotations (V, VT_ = [2 | 0 1], VT2_ = [1 2 | 0]) so
   // that every root is contracted by a row-contiguous scan. PPALS_TUCKER_CHAIN=tree: the per-sweep tree.
+  // Cost: 3 x the tensor's bytes resident for the session's life (the third rotation is taken only with
+  // 2 x the tensor + 2 GB free at creation); X_r is kept in the TENSOR's precision, so with fp32 storage
+  // the two schedules agree to ~1e-7 (X_r rounded like the tensor), with fp64 storage to rounding.
   bool ms3_ = false;
   void *VT2_ = nullptr;
   void *ms3_X_ = nullptr;

@@ -8,6 +8,15 @@ import hostsim_util
 import test_gpu_cp as G
 
 
+def core_from_factors(V, W):
+    """V x_i W_i^T entry by entry (als_Tucker.cxx:408: the core belongs to the RETURNED factors)"""
+    import numpy as np
+    core = V
+    for m, w in enumerate(W):
+        core = np.moveaxis(np.tensordot(w.T, core, axes=(1, m)), 0, m)
+    return core
+
+
 @pytest.fixture(scope="module")
 def pp():
     return hostsim_util.load()
@@ -144,7 +153,7 @@ def test_tucker_order3_multi_sweep_schedule(pp, lens, ranks, sched, monkeypatch)
     c = pp.Context(0)
     t = pp.Tensor(c, lens, 1).upload(V)
     s = pp.Tucker(c, t, ranks)
-    for n in (1, 2, 3, 4, 5):
+    for n in (1, 2, 3, 4, 5, 6, 7):   # (every position of the 2-sweep root cycle ends a call once)
         s.set_factors(W0)
         s.set_core(c0)
         s.sweeps_dt(n)
@@ -153,6 +162,11 @@ def test_tucker_order3_multi_sweep_schedule(pp, lens, ranks, sched, monkeypatch)
         for a, b in zip(W, W_ref):
             assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-10, (sched, n)
         assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-11 * np.linalg.norm(core_ref)
+        # the lazily computed core (TuckerEngine::ensure_core: the live leaf borrowed, a transposition for
+        # front-stored leaves, a recompute when the multi-sweep root permuted the leaf) entry by entry
+        # against V x_i W_i^T of the RETURNED factors — the norm alone would not see a permuted core
+        want = core_from_factors(V, W)
+        assert core.shape == want.shape and np.abs(core - want).max() < 1e-10 * np.abs(want).max(), (sched, n)
     s.close()
     t.close()
     c.close()
@@ -187,6 +201,8 @@ def test_tucker_deferred_eigen_steps_roll_back(pp, lens, ranks, fail_every, monk
     for a, b in zip(W, W_ref):
         assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9
     assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-10 * np.linalg.norm(core_ref)
+    want = core_from_factors(V, W)     # entry by entry, from the returned factors (orders 3 and 4)
+    assert core.shape == want.shape and np.abs(core - want).max() < 1e-10 * np.abs(want).max()
     _, r1 = O.read_csv(c_ref)
     _, r2 = O.read_csv(c_got)
     assert len(r1) == len(r2)
@@ -199,10 +215,12 @@ def test_tucker_deferred_eigen_steps_roll_back(pp, lens, ranks, fail_every, monk
         s.set_factors(W0)
         s.set_core(None)
         s.sweeps_dt(n)
-        Wn, _ = s.get_factors()
+        Wn, core_n = s.get_factors()
         _, _, Wn_ref, _ = O.als_tucker_dt(V, W0, c0, tol=0.0, maxiter=n - 1, resprint=10 ** 9)
         for a, b in zip(Wn, Wn_ref):
             assert np.linalg.norm(a @ a.T - b @ b.T) < 1e-9, (n, fail_every)
+        want = core_from_factors(V, Wn)
+        assert np.abs(core_n - want).max() < 1e-10 * np.abs(want).max(), (n, fail_every)
     s.close()
     t.close()
     c.close()

@@ -32,6 +32,15 @@ def relerr(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
 
 
+def core_from_factors(V, W):
+    """V x_i W_i^T entry by entry (als_Tucker.cxx:408): what the returned core must be for the RETURNED
+    factors — a permuted or transposed core has the same norm"""
+    core = V
+    for m, w in enumerate(W):
+        core = np.moveaxis(np.tensordot(w.T, core, axes=(1, m)), 0, m)
+    return core
+
+
 CASES = [([12, 10, 9], [3, 4, 2]), ([9, 8, 7, 6], [3, 2, 3, 2]), ([20, 16, 24], [5, 5, 5])]
 
 
@@ -74,6 +83,10 @@ def test_hosvd_and_dt_sweeps(pp, ctx, lens, ranks, dtype, tmp_path):
     assert it == it_ref
     for a, b in zip(W_dt, W_dt_ref):
         assert np.linalg.norm(proj(a) - proj(b)) < tol * 100
+    # orders 3 and 4: the returned core is V x_i W_i^T of the returned factors, entry by entry
+    want = core_from_factors(V, W_dt)
+    assert core_dt.shape == want.shape
+    assert np.abs(core_dt - want).max() < (2e-6 if dtype == 0 else 1e-10) * np.abs(want).max()
     h1, r1 = O.read_csv(c_ref)
     h2, r2 = O.read_csv(c_got)
     assert h1 == h2 and len(r1) == len(r2)
@@ -423,6 +436,8 @@ def test_deferred_eigen_step_checks(pp, fail_every, handover, tmp_path, monkeypa
         assert np.allclose(a.T @ a, np.eye(r), atol=1e-10)
         assert relerr(proj(a), proj(b)) < 1e-7, (fail_every, relerr(proj(a), proj(b)))
     assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    want = core_from_factors(V, W)   # after forced rollbacks too: the core of the RETURNED factors
+    assert np.abs(core - want).max() < 1e-10 * np.abs(want).max(), fail_every
     _, r1 = O.read_csv(c_ref)
     _, r2 = O.read_csv(c_got)
     assert len(r1) == len(r2)
@@ -626,7 +641,7 @@ def test_order3_multi_sweep_schedule(pp, lens, ranks, dtype, monkeypatch):
         c2 = pp.Context(0)
         t = pp.Tensor(c2, lens, dtype).upload(V)
         s = pp.Tucker(c2, t, ranks)
-        for sweeps in (1, 2, 3, 4):
+        for sweeps in (1, 2, 3, 4, 5):
             s.set_factors(W0)
             s.set_core(c0)
             c2.profile_enable(1)
@@ -641,11 +656,15 @@ def test_order3_multi_sweep_schedule(pp, lens, ranks, dtype, monkeypatch):
                 assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
                 assert relerr(proj(a), proj(b)) < (1e-7 if dtype == 1 else 2e-4), (sched, sweeps)
             assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < (1e-9 if dtype == 1 else 1e-5) * np.linalg.norm(core_ref)
+            # the lazily computed core (TuckerEngine::ensure_core) entry by entry, from the returned factors
+            want = core_from_factors(V, W)
+            assert core.shape == want.shape
+            assert np.abs(core - want).max() < (1e-10 if dtype == 1 else 2e-6) * np.abs(want).max(), (sched, sweeps)
         s.close()
         t.close()
         c2.close()
     big = min(lens) >= 16  # (the leading-mode product of the back end wants 16 rows: else the per-sweep tree)
-    for sweeps in (1, 2, 3, 4):
+    for sweeps in (1, 2, 3, 4, 5):
         assert scans[("tree", sweeps)] == 2 * sweeps, scans
         assert scans[("ms", sweeps)] == ((3 * sweeps + 1) // 2 if big else 2 * sweeps), scans
 
