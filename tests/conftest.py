@@ -29,3 +29,15 @@ def pytest_sessionstart(session):
         ppals.preload_eigensolver()
     except Exception as e:  # no product library / no ROCm: the gpu tests will say so themselves
         print(f"[conftest] eigensolver preload skipped: {e}")
+
+
+def bar_log(test, **kw):
+    """PPALS_BAR_LOG=file: one JSON line per asserted fp32 bar with what was measured (how DESIGN.md §5's
+    table of measured bars per input class is made: tools/runs/r05_c.sh)"""
+    path = os.environ.get("PPALS_BAR_LOG")
+    if not path:
+        return
+    import json
+    with open(path, "a") as f:
+        f.write(json.dumps(dict(test=test, **{k: (float(v) if hasattr(v, "__float__") else v)
+                                              for k, v in kw.items()})) + "\n")

@@ -15,6 +15,13 @@ KTOL = {0: 2e-6, 1: 1e-10}   # per-kernel relative Frobenius tolerance by dtype 
 FTOL = {0: 1e-5, 1: 1e-8}    # factor matrices after several sweeps
 
 
+def FTOL_R2_F32(kappa):
+    """fp32 storage on the non-low-rank `r2` input, oracle on the same fp32-rounded tensor: 1e-5 plus
+    the fp32 chain rounding (measured ~1e-7 on M at these sizes) amplified by kappa = cond(S). The
+    coefficient is 3 x what the GPU run measured (profiles/r05_fp32_bars.jsonl); DESIGN.md §5."""
+    return 1e-5 + 3e-8 * kappa
+
+
 @pytest.fixture(scope="module")
 def pp():
     import ppals
@@ -173,6 +180,11 @@ def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule):
     1e-5 relative Frobenius for fp32 storage), for both sweep schedules: the multi-sweep tree
     (default: one tensor scan per N-1 mode updates) and the reference's two-node tree"""
     V, W = problem(lens, R, 3, kind)
+    if dtype == 0 and kind == "r2":
+        # the non-low-rank stream: the oracle runs on the tensor AS THE ENGINE HOLDS IT (fp32-rounded
+        # values, as the cfg2-r2 / cfg5-r2 full-size tests do), so that the comparison sees arithmetic,
+        # not storage: 2e-6 of input rounding times cond(S) would otherwise drown it
+        V = np.asfortranarray(V.astype(np.float32).astype(np.float64))
     G = O.init_factors(lens, R, 99)
     K = 5
     _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=K - 1, resprint=1000)
@@ -183,12 +195,18 @@ def test_dt_sweeps_match_oracle(pp, ctx, lens, R, kind, dtype, schedule):
     s.set_factors(W, G)
     s.sweeps_dt(K)
     W_got, G_got = s.get_factors(with_grad=True)
-    # `r` (exact rank) is the BASELINE problem class and carries the 1e-5 bar; a uniform random
-    # tensor fitted with R=4 is an ill-conditioned ALS problem (nearly collinear factors) where
-    # the fp32 storage of V is amplified by cond(S): looser bar there.
-    ftol = FTOL[dtype] if (kind == "r" or dtype == 1) else 1e-3
+    # `r` (exact rank) is the BASELINE problem class and carries the 1e-5 bar. A uniform random
+    # tensor fitted with R = 4 is an ill-conditioned ALS problem (nearly collinear factors): what
+    # the <= 64-term fp32 chains (and the fp32 first-level intermediate of the multi-sweep schedule)
+    # leave in M is amplified by cond(S) = kappa, measured here and in the bar.
+    kappa = max(np.linalg.cond(O.gram_hadamard(W_ref, i)) for i in range(len(lens)))
+    ftol = FTOL[dtype] if (kind == "r" or dtype == 1) else FTOL_R2_F32(kappa)
+    worst = max(relerr(a, b) for a, b in zip(W_got, W_ref))
+    from conftest import bar_log
+    bar_log("test_dt_sweeps_match_oracle", lens=str(lens), R=R, kind=kind, dtype=dtype, schedule=schedule,
+            kappa=kappa, measured=worst, bar=ftol)
     for a, b in zip(W_got, W_ref):
-        assert relerr(a, b) < ftol, relerr(a, b)
+        assert relerr(a, b) < ftol, (relerr(a, b), ftol, kappa)
     gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
     assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
     # grad_W[i] = -M + W_i S (als_CP.cxx:296) element by element, against the scale that formed

@@ -59,6 +59,9 @@ def test_cfg2_full_size(pp, ctx, dtype, schedule):
     W_ref, G_ref = RS.als_cp_dt(A, W, G, K)
     W_got, G_got = s.get_factors(with_grad=True)
     ftol = 1e-5 if dtype == 0 else 1e-9
+    from conftest import bar_log
+    bar_log("test_cfg2_full_size", kind="r", dtype=dtype, sweeps=K,
+            measured=max(relerr(a, b) for a, b in zip(W_got, W_ref)), bar=ftol)
     for a, b in zip(W_got, W_ref):
         assert relerr(a, b) < ftol, relerr(a, b)
     gn = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
@@ -141,6 +144,9 @@ def test_cfg2_long_run_fp32_factor_parity(pp, ctx):
         W_ref, G_ref = RS.als_cp_dt(A, W_ref, G_ref, upto - done)
         s.sweeps_dt(upto - done)
         done = upto
+        from conftest import bar_log
+        bar_log("test_cfg2_long_run_fp32_factor_parity", kind="r", dtype=0, sweeps=upto,
+                measured=max(relerr(a, b) for a, b in zip(s.get_factors(), W_ref)), bar=1e-5)
         for a, b in zip(s.get_factors(), W_ref):
             assert relerr(a, b) < 1e-5, (upto, relerr(a, b))
     assert s.residual() < 1e-6 * RS.norm(A)
@@ -450,6 +456,9 @@ def test_cfg2_r2_full_size(pp, ctx, cfg2_r2, dtype):
         s.set_factors(c["W"], c["G"])
         s.sweeps_dt(2)
         W_got, G_got = s.get_factors(with_grad=True)
+        from conftest import bar_log
+        bar_log("test_cfg2_r2_full_size", kind="r2", dtype=dtype, schedule=schedule, kappa=kappa,
+                measured=max(relerr(a, b) for a, b in zip(W_got, c["W2"])), bar=ftol)
         for i, (a, b) in enumerate(zip(W_got, c["W2"])):
             assert relerr(a, b) < ftol, (schedule, i, relerr(a, b), ftol)
         gn = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in c["G2"]))
