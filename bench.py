@@ -32,6 +32,13 @@ WORKLOADS = {
     "cp4_s400_r10": ([400, 400, 400, 400], 10),
     "cp4_s200_r20": ([200, 200, 200, 200], 20),
 }
+# the reference's real-data runs (test_ALS.cxx:287-326,366-379; script/script_real.py:42-56): the
+# EXTENTS of coil-100 / time-lapse with synthetic values (`--workload coil100|timelapse`; not a
+# BASELINE config, never the driver's line): name -> (lens, CP rank, Tucker core ranks)
+REAL_SHAPES = {
+    "coil100": ([3, 128, 128, 7200], 10, [3, 10, 10, 70]),
+    "timelapse": ([33, 1344, 1024, 9], 10, [10, 100, 100, 5]),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
@@ -600,12 +607,153 @@ def sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure
     return out
 
 
+def real_shape_main(args):
+    """`--workload coil100|timelapse`: the reference's real-data EXTENTS (3 x 128 x 128 x 7200 and
+    33 x 1344 x 1024 x 9) filled with synthetic U(0.5, 1) values, one GPU: CP R = 10 `-pp 0` (sweeps/s,
+    tensor-scan roofline, which scans the schedule ran), `-pp 1 -pp_res_tol 0.05` against `-pp 0` over
+    the scripts' 250 iterations, Tucker with the ranks of test_ALS.cxx:366-379 (HOSVD + HOOI sweeps).
+    One JSON line; per-root scan times come from a kernel trace of this command (tools/runs/r05_real.sh)."""
+    import tempfile
+    import torch  # noqa: F401  (first: libppals.so then shares torch's HIP runtime)
+    import ppals
+    lens, R, tranks = REAL_SHAPES[args.workload]
+    ppals.preload_eigensolver()
+    ctx = ppals.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    dtype = ppals.F32 if args.dtype == "f32" else ppals.F64
+    esz = 4 if args.dtype == "f32" else 8
+    V = ppals.Tensor(ctx, lens, dtype).fill_uniform(7)
+    vnorm = V.norm()
+    W0, G0 = ppals.init_factors(lens, R, 2000), ppals.init_factors(lens, R, 3000)
+    out = {"metric": f"ALS sweeps/sec (exact sweep, CP order-4 {'x'.join(map(str, lens))} R={R})",
+           "unit": "sweeps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic (U(0.5,1) values in the reference's real-data extents)",
+           "config": {"workload": f"{args.workload}: extents of test_ALS.cxx:287-326 ({lens}), CP R={R} -pp 0 exact "
+                                  "sweeps incl. Normalize; not a BASELINE config", "lens": lens, "rank": R}}
+    sub = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        trace = os.path.join(tmp, "steps.txt")
+        os.environ["PPALS_TRACE_STEPS"] = trace
+        cp = ppals.CP(ctx, V, R)
+        if args.schedule:
+            cp.set_schedule(args.schedule)
+        cp.set_factors(W0, G0)
+        cp.sweeps_dt(args.warmup)
+        ctx.sync()
+        open(trace, "w").close()
+        ctx.profile_reset()
+        ctx.profile_enable(1)
+        t0 = time.perf_counter()
+        cp.sweeps_dt(args.steps)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        ctx.profile_enable(0)
+        del os.environ["PPALS_TRACE_STEPS"]
+        launches, scan_ms, scan_bytes = ctx.profile_read(0)
+        out["value"] = args.steps / el
+        out["ms_per_step"] = 1e3 * el / args.steps
+        out["schedule"] = cp.schedule
+        # which first-level scans the schedule ran in the timed sweeps (root set, layout, shape)
+        scans = {}
+        for ln in open(trace).read().splitlines():
+            kv = dict(t.split("=") for t in ln.split() if "=" in t)
+            key = (kv["root"], kv["k"], kv["layout"], kv["L"], kv["J"], kv["T"])
+            scans[key] = scans.get(key, 0) + 1
+        out["scans"] = [{"root": int(k[0]), "modes_contracted": int(k[1]), "layout": k[2], "L": int(k[3]),
+                         "J": int(k[4]), "T": int(k[5]), "launches_in_timed_region": n,
+                         "algorithmic_bytes": int(k[3]) * int(k[4]) * int(k[5]) * esz
+                                              + int(k[3]) * int(k[5]) * R * esz}
+                        for k, n in sorted(scans.items())]
+        if launches > 0 and scan_ms > 0:
+            ach = scan_bytes / (scan_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                               "avg_launch_ms": scan_ms / launches,
+                               "algorithmic_bytes_per_launch": scan_bytes / launches,
+                               "scan_ms_per_step": scan_ms / args.steps,
+                               "note": "all first-level tensor scans of the timed sweeps together (HIP events on the "
+                                       "engine's stream); per root: the kernel trace of this command"}
+        out["final_gradnorm"] = cp.gradnorm()
+        # per root: the online placement choice times every root's own scans (PPALS_PLACE_MIN_MB lowers its
+        # size threshold below these 1.4 / 1.6 GB tensors) — run until it has, then price each root
+        try:
+            for _ in range(15):
+                rep = cp.placement_report()
+                if rep.get("mode") != "online" or not rep["roots"] or all(r["settled"] for r in rep["roots"]):
+                    break
+                cp.sweeps_dt(8)
+            ctx.sync()
+            rep = cp.placement_report()
+            out["placement"] = rep
+            for sc in out["scans"]:
+                for r in rep.get("roots", []):
+                    if r["root"] == sc["root"] and r["best_ms"] > 0:
+                        sc["best_ms"], sc["worst_ms"] = r["best_ms"], r["worst_ms"]
+                        sc["frac_of_hbm_peak"] = sc["algorithmic_bytes"] / (r["best_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        except Exception as e:
+            out["placement"] = {"error": str(e)}
+        # -pp 1 against -pp 0 over the scripts' 250 iterations (script/script_real.py:42-47)
+        try:
+            kw = dict(tol=1e-10 * vnorm, maxiter=250, resprint=10)
+            dt_csv, pp_csv = os.path.join(tmp, "dt.csv"), os.path.join(tmp, "pp.csv")
+            cp.set_factors(W0, G0)
+            cp.run_dt(csv=dt_csv, **kw)
+            cp.set_factors(W0, G0)
+            cp.run_pp(csv=pp_csv, tol_init=0.05, **kw)
+            dt, pp = _csv_rows(dt_csv), _csv_rows(pp_csv)
+            sub["cp_pp1_vs_pp0"] = {
+                "config": "-model CP -pp 0 / -pp 1 -pp_res_tol 0.05 -rank 10 -maxiter 250 -resprint 10",
+                "dt_total_dtime_s": dt[-1][6], "pp_total_dtime_s": pp[-1][6],
+                "dt_iters": int(dt[-1][1]), "pp_iters": int(pp[-1][1]),
+                "pp_rows_flagged_pp_update": sum(1 for r in pp if r[4] == 1), "rows": len(pp),
+                "final_diffV": {"dt": dt[-1][5], "pp": pp[-1][5]}, "vnorm": vnorm}
+        except Exception as e:
+            sub["cp_pp1_vs_pp0"] = {"error": str(e)}
+        cp.close()
+        # Tucker with the reference's ranks for this data set
+        try:
+            tk = ppals.Tucker(ctx, V, tranks)
+            ctx.sync()
+            t0 = time.perf_counter()
+            tk.hosvd()
+            ctx.sync()
+            hosvd_ms = 1e3 * (time.perf_counter() - t0)
+            csv = os.path.join(tmp, "tucker.csv")
+            tk.run_dt(tol=0.0, maxiter=20, resprint=5, csv=csv)
+            rows = _csv_rows(csv)
+            r5 = [r for r in rows if r[1] == 5][0]
+            ctx.profile_reset()
+            ctx.profile_enable(2)
+            tk.sweeps_dt(5)
+            ctx.sync()
+            ctx.profile_enable(0)
+            ls, sms, sby = ctx.profile_read(0)
+            rec = {"config": f"-model Tucker -tensor o? extents {lens}, core {tranks} (test_ALS.cxx:366-379), "
+                             "hosvd + alsTucker_DT 20 sweeps",
+                   "hosvd_ms": hosvd_ms,
+                   "ms_per_hooi_sweep": 1e3 * (rows[-1][6] - r5[6]) / (rows[-1][1] - r5[1]),
+                   "scan_launches_per_sweep": ls / 5.0, "scan_ms_per_sweep": sms / 5.0,
+                   "final_diffV": rows[-1][5]}
+            if ls > 0 and sms > 0:
+                rec["roofline"] = {"bound": "hbm", "achieved": sby / (sms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": sby / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "launches": ls, "avg_launch_ms": sms / ls}
+            sub["tucker"] = rec
+            tk.close()
+        except Exception as e:
+            sub["tucker"] = {"error": str(e)}
+    out["sub_records"] = sub
+    print(json.dumps(out), flush=True)
+    V.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cp4_s200_r10", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cp4_s200_r10", choices=sorted(WORKLOADS) + sorted(REAL_SHAPES))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="storage type of the tensor in HBM (all factor math is fp64)")
     ap.add_argument("--schedule", default=None, choices=["dt", "msdt"],
@@ -619,6 +767,9 @@ def main():
                     help="do not count HBM bytes with rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
 
+    if args.workload in REAL_SHAPES:
+        real_shape_main(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -291,7 +291,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
   const bool place = schedule_ == 1 && N_ >= 3 && ms_tune_enabled_ && ms_X_slack() > 0;
   if (place) {
     for (int r = 0; r < N_; r++) {
-      if (dist_ && ((0 - r + N_) % N_) < ms_k_) continue;  // never a root set when sharded
+      if (ms_set_excluded(r, ms_k_, ms_excl_)) continue;  // never a root set
       xmax = std::max(xmax, ms_X_bytes(r, ms_k_));
     }
     const size_t avail = ops_.mem_available();
@@ -703,6 +703,16 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
     const int64_t blk = block_rows(s, P_);
     const int64_t nr = std::max<int64_t>(0, std::min(blk, s - blk * rank_));
     double *mine = gatherbuf_ + (size_t)rank_ * blk * R_;
+    if (blk * P_ == s && ldm == blk && nr == blk) {
+      // equal blocks: the local leaf IS this rank's block as the all-gather wants it (no pack launch),
+      // and the fused update reads the gathered blocks as they lie (no unpack launch)
+      comm_.allgather(M, gatherbuf_, blk * R_);
+      ops_.cp_mode_update_blocked(G_, N_, i, R_, lambda, gatherbuf_, blk, P_, sendbuf_, W_[i], s, gradW_[i],
+                                  s, s, gradsq_ + i, pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s,
+                                  ratio, S_, Sinv_);
+      grad_replicated_[i] = true;
+      return;
+    }
     ops_.pack_blocks(M, nr, ldm, R_, blk, 1, mine);
     comm_.allgather(mine, gatherbuf_, blk * R_);
     ops_.unpack_blocks(gatherbuf_, s, s, R_, blk, P_, sendbuf_);
@@ -805,33 +815,89 @@ void CpEngine::ms_reserve(RTensor &t, size_t bytes) {
   }
 }
 
-// How many modes one first-level contraction removes (the "root set" of a step). With k roots a
-// sweep needs N/(N-k) tensor scans and each step writes once / reads twice an intermediate of
-// R / prod(root extents) of the tensor's size; a written byte costs ~2.5 read bytes on this part
-// (profiles/README.md). k = 1 wins at order 4 (cfg2: 1.33 x 1.23 vs 2.0), k = 2 at order 6 with
-// s = 50, R = 6 (1.2 x 1.54 vs 1.5 x 1.01). PPALS_MSDT_ROOTS overrides.
-int CpEngine::ms_choose_roots() const {
-  // sharded: the root set is slid back past the partitioned mode 0 (ms_mode_update); it still has
-  // to end before the mode about to be updated, which needs 2k < N
-  const int kcap = dist_ ? std::max(1, (N_ - 1) / 2) : N_;
-  if (const char *e = std::getenv("PPALS_MSDT_ROOTS")) {
-    const int k = std::atoi(e);
-    if (k >= 1 && k <= N_ - 2) return std::min(k, kcap);
-  }
-  // (sharded: mode 0 is never in a root set, see ms_mode_update)
-  double gm = 1;
-  const int m_lo = (dist_ && N_ > 2) ? 1 : 0;
-  for (int m = m_lo; m < N_; m++) gm *= std::pow((double)V_.glens[m], 1.0 / (N_ - m_lo));
-  int best = 1;
-  double best_cost = 1e300;
-  for (int k = 1; k <= std::max(1, N_ / 2) && k <= N_ - 2 && k <= kcap; k++) {
-    const double xfrac = R_ / std::pow(gm, k);
-    const double cost = (double)N_ / (N_ - k) * (1.0 + 4.5 * xfrac);
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = k;
+// ---- which root sets the multi-sweep schedule uses ----
+bool CpEngine::ms_set_excluded(int first, int k, unsigned excl) const {
+  for (int q = 0; q < k; q++)
+    if ((excl >> ((first + q) % N_)) & 1u) return true;
+  return false;
+}
+
+// The root set that serves the update of mode i when the running step cannot: the k modes updated
+// last, slid back past excluded modes. A slid-back set is older but still current (none of its modes
+// has been updated since); the step is then entered in the middle of its mode list and serves fewer
+// updates (order 4, k = 1, mode 0 excluded: runs 3,3,2 -> 3 scans per 2 sweeps instead of 8/3).
+int CpEngine::ms_next_root(int i, int k, unsigned excl) const {
+  int first = (i - k + N_) % N_, guard = 0;
+  while (ms_set_excluded(first, k, excl) && guard++ < N_) first = (first - 1 + N_) % N_;
+  if (ms_set_excluded(first, k, excl) || ((i - first + N_) % N_) < k) return -1;
+  return first;
+}
+
+// What a sweep costs under (k, excl), in reads of the tensor: the schedule is walked for a few sweeps
+// (the transient of the root rotation dropped), every first-level scan costs 1 + 4.5 x (size of its
+// X relative to the tensor): X is written once — a written byte costs ~2.5 read bytes on this part,
+// profiles/README.md — and read twice by the step's tree.
+double CpEngine::ms_schedule_cost(int k, unsigned excl) const {
+  int root = -1;
+  double cost = 0;
+  const int sweeps = 2 * N_;
+  for (int u = 0; u < (sweeps + 2) * N_; u++) {
+    const int i = u % N_;
+    if (root < 0 || ((i - root + N_) % N_) < k) {
+      root = ms_next_root(i, k, excl);
+      if (root < 0) return 1e300;
+      if (u >= 2 * N_) {
+        double J = 1;
+        for (int q = 0; q < k; q++) J *= (double)ext((root + q) % N_);
+        cost += 1.0 + 4.5 * (double)R_ / J;
+      }
     }
   }
+  return cost / sweeps;
+}
+
+// How many modes one first-level contraction removes (the "root set" of a step) and which modes are
+// never roots. k = 1 with no exclusion wins at order 4 with equal extents (cfg2: 1.33 x 1.23 vs 2.0),
+// k = 2 at order 6 with s = 50, R = 6 (1.2 x 1.54 vs 1.5 x 1.01); a mode of extent 3 at R = 10
+// (coil-100: 3 x 128 x 128 x 7200) is excluded: 1.5 scans of the tensor per sweep instead of 1.33
+// scans plus an X of 3.3 x the tensor written once and read twice every third step.
+// PPALS_MSDT_ROOTS=k fixes k (the exclusion is still chosen by cost).
+int CpEngine::ms_choose_roots() {
+  const unsigned mandatory = (dist_ && N_ > 2) ? 1u : 0u;  // sharded: mode 0 is never in a root set
+  // sharded: the root set is slid back past mode 0; it still has to end before the mode about to be
+  // updated, which needs 2k < N
+  const int kcap = dist_ ? std::max(1, (N_ - 1) / 2) : N_;
+  int kfix = 0;
+  if (const char *e = std::getenv("PPALS_MSDT_ROOTS")) {
+    const int k = std::atoi(e);
+    if (k >= 1 && k <= N_ - 2) kfix = std::min(k, kcap);
+  }
+  // candidates for exclusion: modes whose X would be at least 5 % of the tensor
+  unsigned small = 0;
+  for (int m = 0; m < N_; m++)
+    if ((double)R_ >= 0.05 * (double)ext(m)) small |= 1u << m;
+  int best = 1;
+  unsigned best_excl = mandatory;
+  double best_cost = 1e300;
+  for (int k = 1; k <= std::max(1, N_ / 2) && k <= N_ - 2 && k <= kcap; k++) {
+    if (kfix && k != kfix) continue;
+    for (unsigned sub = small;; sub = (sub - 1) & small) {  // every subset of the short modes
+      const unsigned excl = sub | mandatory;
+      const double cost = ms_schedule_cost(k, excl);
+      // (ties: fewer excluded modes, then smaller k)
+      if (cost < best_cost * (1.0 - 1e-9)) {
+        best_cost = cost;
+        best = k;
+        best_excl = excl;
+      }
+      if (sub == 0) break;
+    }
+  }
+  if (best_cost >= 1e299) {  // nothing schedulable with the requested k: single roots, mandatory exclusion only
+    best = 1;
+    best_excl = mandatory;
+  }
+  ms_excl_ = best_excl;
   return best;
 }
 
@@ -999,7 +1065,11 @@ void CpEngine::ms_start_step(int first) {
     // it (allocation failed / PPALS_TRANSPOSED_COPY=0) fall back to single-mode roots for good
     if (k == 1) throw std::runtime_error("ppals: internal error (single root not adjacent)");
     ms_set_roots(1);
-    ms_start_step((first + k - 1) % N_);  // the mode just before the one about to be updated
+    // the mode just before the one about to be updated, slid back past modes that are never roots
+    // (an older root is still current: none of the skipped modes' successors has been updated since)
+    int r = (first + k - 1) % N_, guard = 0;
+    while (((ms_excl_ >> r) & 1u) && guard++ < N_) r = (r - 1 + N_) % N_;
+    ms_start_step(r);
     return;
   }
   const void *src = pl.lay->ptr;
@@ -1084,20 +1154,12 @@ void CpEngine::ms_start_step(int first) {
 void CpEngine::ms_mode_update(int i, double lambda) {
   check_tensor_generation();
   if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) {
-    int first = (i - ms_k_ + N_) % N_;  // the k modes updated last: serves the next N - k updates
-    if (dist_) {
-      // Sharded: a root set that contains the partitioned mode 0 would make X a PARTIAL sum of
-      // full global size (s^(N-1) R per rank whatever P is: written once and read twice per step,
-      // 5.1 GB against a 12.8 GB shard at cfg4 / P = 8). Slide the root set back until it excludes
-      // mode 0: the step is then entered in the middle of its mode list and serves fewer updates
-      // (order 4, k = 1: runs 3,3,2 -> 3 scans per 2 sweeps instead of 8/3), every X keeps the
-      // local extent of mode 0 and scales with 1/P.
-      auto has0 = [&](int f) { return ((0 - f + N_) % N_) < ms_k_; };
-      int guard = 0;
-      while (has0(first) && guard++ < N_) first = (first - 1 + N_) % N_;
-      if (has0(first) || ((i - first + N_) % N_) < ms_k_)
-        throw std::runtime_error("ppals: no root set without the sharded mode");
-    }
+    // the k modes updated last serve the next N - k updates — unless one of them is never a root
+    // (ms_excl_: the partitioned mode of a sharded session, whose X would be a PARTIAL sum of full
+    // global size — s^(N-1) R per rank whatever P is: 5.1 GB against a 12.8 GB shard at cfg4 / P = 8 —,
+    // or a mode too short for X to be smaller than the tensor): then the set is slid back past it
+    const int first = ms_next_root(i, ms_k_, ms_excl_);
+    if (first < 0) throw std::runtime_error("ppals: no root set without the excluded modes");
     ms_start_step(first);
   }
   int pos = -1;

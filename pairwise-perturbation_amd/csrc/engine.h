@@ -169,7 +169,15 @@ class CpEngine {
   int schedule_ = 1;  // 1: multi-sweep dimension tree (default), 0: the reference's two-node tree
   int ms_root_ = -1;  // first mode of the running step's root set (-1: no step)
   int ms_k_ = 1;      // modes contracted by one first-level scan (ms_choose_roots)
-  int ms_choose_roots() const;
+  // modes that are never part of a root set: the partitioned mode 0 of a sharded session (its X would
+  // be a partial sum of global size) and modes so short that X = V x_m W_m is no smaller than the tensor
+  // (extent 3 at R = 10: X is 3.3 x the tensor — the reference's coil-100 / time-lapse shapes). The root
+  // set is slid back past them (ms_next_root); the cost model prices both (ms_schedule_cost).
+  unsigned ms_excl_ = 0;
+  bool ms_set_excluded(int first, int k, unsigned excl) const;
+  int ms_next_root(int i, int k, unsigned excl) const;  // first mode of the root set that serves update i, -1: none
+  double ms_schedule_cost(int k, unsigned excl) const;  // tensor-scan equivalents per sweep, 1e300: not schedulable
+  int ms_choose_roots();
   void ms_set_roots(int k);
   void ms_mode_update(int i, double lambda);
   RTensor ms_X_;

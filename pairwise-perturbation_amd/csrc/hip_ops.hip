@@ -964,6 +964,26 @@ class HipOps : public Ops {
                        Sinv, force_jacobi_);
     HIP_CHECK(hipGetLastError());
   }
+  void cp_mode_update_blocked(double *Gall, int N, int mode, int R, double lambda, const double *Mblk,
+                              int64_t blk, int P, double *scratch, double *W, int64_t ldw, double *grad,
+                              int64_t ldg, int64_t rows, double *gradsq, const double *Winit, int64_t ldi,
+                              double *dW, int64_t ldd, double ratio, double *S, double *Sinv) override {
+    // the staged fused launch reads the gathered blocks as they lie (one launch less per update of the
+    // partitioned mode); anything else re-assembles them first
+    const size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) + sizeof(int) * 64;
+    const size_t stage = 2 * sizeof(double) * (size_t)rows * R;
+    if (R > 64 || force_jacobi_ || norm_armed_ || lds + stage > 150 * 1024 || blk * P != rows ||
+        blk > 0x7fffffff) {
+      Ops::cp_mode_update_blocked(Gall, N, mode, R, lambda, Mblk, blk, P, scratch, W, ldw, grad, ldg, rows,
+                                  gradsq, Winit, ldi, dW, ldd, ratio, S, Sinv);
+      return;
+    }
+    update_mblk_ = (int)blk;
+    cp_mode_update(Gall, N, mode, R, lambda, Mblk, rows, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
+                   ldd, ratio, S, Sinv, nullptr);
+    update_mblk_ = 0;
+  }
+  int update_mblk_ = 0;
   void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
                       int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
                       double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,
@@ -999,8 +1019,9 @@ class HipOps : public Ops {
     if (lds + stage <= 150 * 1024) {
       hipLaunchKernelGGL((k_cp_mode_update<true, true>), dim3(1), dim3(1024), lds + stage, st_, Gall, N, mode,
                          R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio, S,
-                         Sinv, dwsq, presolved, nrm);
+                         Sinv, dwsq, presolved, nrm, update_mblk_);
     } else {
+      if (update_mblk_) throw std::logic_error("ppals: blocked mode update needs the staged launch");
       hipLaunchKernelGGL((k_cp_mode_update<false, false>), dim3(1), dim3(1024), lds, st_, Gall, N, mode,
                          R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW, ldd, ratio,
                          S, Sinv, dwsq, presolved);

@@ -1283,7 +1283,10 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     double *__restrict__ gradsq, const double *__restrict__ Winit, int64_t ldi,
     double *__restrict__ dW, int64_t ldd, double ratio, double *__restrict__ S_out,
     double *__restrict__ Sinv_out, double *__restrict__ dwsq, int presolved = 0,
-    NormArgs nrm = NormArgs()) {
+    NormArgs nrm = NormArgs(), int mblk = 0) {
+  // mblk > 0 (STAGE only): M is handed over in ROW BLOCKS of mblk rows, block p at p * mblk * R with
+  // leading dimension mblk — the receive buffer of an all-gather of the ranks' row blocks, read as
+  // it arrives (no unpack launch in front of the update)
   extern __shared__ double lds[];
   const int ldA = R + 1;
   double *red = lds;
@@ -1309,7 +1312,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     if (STAGE)
       for (int e = tid; e < total_i; e += (int)blockDim.x) {
         const int i = e % rows_i, j = e / rows_i;
-        sM[e] = M[i + ldm * j];
+        sM[e] = mblk ? M[(int64_t)(i / mblk) * mblk * R + (i % mblk) + (int64_t)mblk * j] : M[i + ldm * j];
         sW[e] = W[i + ldw * j];
       }
     __syncthreads();
@@ -1331,7 +1334,7 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
     } else if (STAGE) {
       for (int e = tid - 64; e < total_i; e += (int)blockDim.x - 64) {
         const int i = e % rows_i, j = e / rows_i;
-        sM[e] = M[i + ldm * j];
+        sM[e] = mblk ? M[(int64_t)(i / mblk) * mblk * R + (i % mblk) + (int64_t)mblk * j] : M[i + ldm * j];
         sW[e] = W[i + ldw * j];
       }
     }

@@ -242,6 +242,19 @@ class Ops {
     gram(W, rows, ldw, R, Gall + (size_t)mode * R * R);
     if (dwsq && Winit) sumsq(dW, rows * R, dwsq);
   }
+  // The same with M handed over in ROW BLOCKS (the receive buffer of an all-gather of the ranks' row
+  // blocks: block p = rows [p*blk, (p+1)*blk) stored at Mblk + p*blk*R with leading dimension blk,
+  // blk * P == rows). A back end may read the blocks as they are; the default re-assembles them in
+  // `scratch` (rows x R) first.
+  virtual void cp_mode_update_blocked(double *Gall, int N, int mode, int R, double lambda,
+                                      const double *Mblk, int64_t blk, int P, double *scratch,
+                                      double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
+                                      double *gradsq, const double *Winit, int64_t ldi, double *dW,
+                                      int64_t ldd, double ratio, double *S, double *Sinv) {
+    unpack_blocks(Mblk, rows, rows, R, blk, P, scratch);
+    cp_mode_update(Gall, N, mode, R, lambda, scratch, rows, W, ldw, grad, ldg, rows, gradsq, Winit, ldi,
+                   dW, ldd, ratio, S, Sinv);
+  }
   // Hint: the next cp_mode_update will be for `mode` with these arguments, and the Grams of the
   // other modes are final NOW — a back end may prepare S / S^-1 on the side of the contraction that
   // is launched next (mttv / pp_correct) instead of at the head of the update launch. Optional.
