@@ -692,6 +692,12 @@ def real_shape_main(args):
                         sc["frac_of_hbm_peak"] = sc["algorithmic_bytes"] / (r["best_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception as e:
             out["placement"] = {"error": str(e)}
+        if args.no_config_records:    # (the exact sweeps only: what a kernel trace of this command should show)
+            cp.close()
+            print(json.dumps(out), flush=True)
+            V.close()
+            ctx.close()
+            return
         # -pp 1 against -pp 0 over the scripts' 250 iterations (script/script_real.py:42-47)
         try:
             kw = dict(tol=1e-10 * vnorm, maxiter=250, resprint=10)

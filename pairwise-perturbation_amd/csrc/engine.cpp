@@ -754,23 +754,31 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
   ops_.gram(W_[i], s, s, R_, Gi);
 }
 
+// cached MSDT tensors were built from the un-normalised factors of their contracted modes: a
+// Normalize multiplies every live tensor's pending scalar by prod_{m contracted} f_m (same launch).
+// Returns the set of live slots, marks them pending; skip_node: a leaf about to be consumed.
+unsigned CpEngine::ms_collect_scales(unsigned *masks, unsigned *fresh, int skip_node) {
+  unsigned active = 0;
+  *fresh = 0;
+  if (!(schedule_ == 1 && ms_root_ >= 0)) return 0;
+  auto visit = [&](RTensor &t) {
+    if (!t.valid) return;
+    masks[t.slot] = t.contracted;
+    active |= 1u << t.slot;
+    if (!t.pending) *fresh |= 1u << t.slot;
+    t.pending = true;
+  };
+  visit(ms_X_);
+  for (size_t q = 0; q < ms_nodes_.size(); q++)
+    if ((int)q != skip_node) visit(ms_nodes_[q].t);
+  return active;
+}
+
 void CpEngine::normalize() {
   int64_t rows[MAX_ORDER];
   for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
-  unsigned masks[32] = {0}, active = 0, fresh = 0;
-  if (schedule_ == 1 && ms_root_ >= 0) {
-    // cached MSDT tensors were built from the un-normalised factors of their contracted modes:
-    // every live tensor's pending scalar is multiplied by prod_{m contracted} f_m (same launch)
-    auto visit = [&](RTensor &t) {
-      if (!t.valid) return;
-      masks[t.slot] = t.contracted;
-      active |= 1u << t.slot;
-      if (!t.pending) fresh |= 1u << t.slot;
-      t.pending = true;
-    };
-    visit(ms_X_);
-    for (auto &n : ms_nodes_) visit(n.t);
-  }
+  unsigned masks[32] = {0}, fresh = 0;
+  const unsigned active = ms_collect_scales(masks, &fresh, -1);
   ops_.normalize_ms(W_.data(), rows, N_, R_, G_, ms_scales_, masks, active, fresh,
                     pp_norms_live_ ? pp_norms_ + 1 : nullptr);
 }
@@ -1151,7 +1159,7 @@ void CpEngine::ms_start_step(int first) {
 
 // one mode update of the multi-sweep schedule: starts a new step when mode i belongs to the root
 // set of the running one (its factor was frozen into X), i.e. after N - k updates
-void CpEngine::ms_mode_update(int i, double lambda) {
+void CpEngine::ms_mode_update(int i, double lambda, bool last_of_sweep) {
   check_tensor_generation();
   if (ms_root_ < 0 || ((i - ms_root_ + N_) % N_) < ms_k_) {
     // the k modes updated last serve the next N - k updates — unless one of them is never a root
@@ -1170,6 +1178,20 @@ void CpEngine::ms_mode_update(int i, double lambda) {
   // next may prepare them on the side)
   ops_.arm_gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
   ms_compute(leaf);
+  ms_norm_fused_ = false;
+  // the sweep's Normalize at the tail of its last update launch, with the pending scales of the cached
+  // tensors that outlive the update (everything valid now but the leaf it consumes) — where the update
+  // is the fused launch: one rank, or the one-all-reduce plan of a sharded session (never mode 0's)
+  if (last_of_sweep && (!dist_ || (i != 0 && (int64_t)sizeof(double) * V_.glens[i] * R_ <= small_msg_bytes_))) {
+    int64_t rows[MAX_ORDER];
+    for (int q = 0; q < N_; q++) rows[q] = V_.glens[q];
+    // (asked first with no cached tensors — a back end that cannot fold it must not see them marked)
+    if (ops_.arm_normalize(W_.data(), rows, N_, R_, G_, i, nullptr)) {
+      unsigned masks[32] = {0}, fresh = 0;
+      const unsigned active = ms_collect_scales(masks, &fresh, leaf);
+      ms_norm_fused_ = ops_.arm_normalize(W_.data(), rows, N_, R_, G_, i, nullptr, ms_scales_, masks, active, fresh);
+    }
+  }
   mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
   ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update
 }
@@ -1227,8 +1249,9 @@ void CpEngine::ms_compute(int idx) {
 }
 
 void CpEngine::sweep_msdt(double lambda) {
-  for (int i = 0; i < N_; i++) ms_mode_update(i, lambda);
-  normalize();
+  for (int i = 0; i < N_; i++) ms_mode_update(i, lambda, i == N_ - 1);
+  if (!ms_norm_fused_) normalize();
+  ms_norm_fused_ = false;
   grad_from_sweep_ = true;
 }
 
@@ -1787,11 +1810,29 @@ void CpEngine::gram_system(int mode, double lambda, double *S_host, double *Sinv
 // ---------------------------------------------------------------------------- PP operators
 // Build_mttkrp_map (als_CP.cxx:352-409): key = contracted modes in ascending order; built by
 // dropping the last contracted mode. Level 1 scans V (K8), deeper levels contract the cache.
+// Build_mttkrp_map (als_CP.cxx:385-390) derives the operator with the contracted modes `seq` from the
+// one without seq's LAST mode, so every chain starts by contracting its lowest mode. Here the mode
+// removed last is the SHORTEST of seq — the chain's level-1 tensor then contracts its longest mode and
+// is the smallest possible (coil-100, 3 x 128 x 128 x 7200, R = 10: V x_a W_a is 3.3 x the tensor,
+// 4.7 GB written once and read three times per build; V x_d W_d is 2 MB). Same operators, another
+// association order; ties keep the reference's order, so equal extents change nothing.
+int CpEngine::pp_last_mode(const std::string &seq) const {
+  int best = seq.back() - 'a';
+  for (int q = (int)seq.size() - 2; q >= 0; q--)
+    if (ext(seq[q] - 'a') < ext(best)) best = seq[q] - 'a';
+  return best;
+}
+std::string CpEngine::pp_parent(const std::string &seq) const {
+  std::string p = seq;
+  p.erase(p.find((char)('a' + pp_last_mode(seq))), 1);
+  return p;
+}
+
 const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
   check_tensor_generation();
   auto it = pp_.find(seq);
   if (it != pp_.end()) return it->second;
-  const int mode = seq.back() - 'a';
+  const int mode = pp_last_mode(seq);
   PPOp op;
   FactorRef f = fref(mode, W_.data());
   int64_t L = 1, T = 1;
@@ -1830,7 +1871,7 @@ const CpEngine::PPOp &CpEngine::pp_get(const std::string &seq) {
                          op.elems, pl.pad);
     }
   } else {
-    const PPOp &par = pp_get(seq.substr(0, seq.size() - 1));
+    const PPOp &par = pp_get(pp_parent(seq));
     bool before = true;
     for (int m : par.modes) {
       if (m == mode) {
@@ -1914,8 +1955,24 @@ void CpEngine::pp_build_all() {
     }
   } timer(*this);
   pp_clear();
+  // the pair operators in an order in which all users of a scaffold are consecutive (pp_buffer keeps
+  // ONE buffer per scaffold level): sorted by their chain of ancestors, level 1 first
+  std::vector<std::pair<std::string, std::string>> pairs;  // (chain, key)
   for (int ii = 0; ii < N_; ii++)
-    for (int jj = ii + 1; jj < N_; jj++) pp_get(all_but(N_, ii, jj));
+    for (int jj = ii + 1; jj < N_; jj++) {
+      const std::string key = all_but(N_, ii, jj);
+      std::string chain = key;
+      for (std::string k = key; k.size() > 1;) {
+        k = pp_parent(k);
+        chain = k + "|" + chain;
+      }
+      pairs.emplace_back(chain, key);
+    }
+  std::stable_sort(pairs.begin(), pairs.end(),
+                   [](const std::pair<std::string, std::string> &a, const std::pair<std::string, std::string> &b) {
+                     return a.first < b.first;
+                   });
+  for (const auto &pk : pairs) pp_get(pk.second);
   for (int ii = 0; ii < N_; ii++) pp_get(all_but(N_, ii));
   // the approximate sweeps read the pair operators (N-2 modes contracted) and the full MTTKRPs
   // only; everything above them in the recursion was scaffolding — at order 6 that is 45 GB of

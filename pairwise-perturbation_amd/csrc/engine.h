@@ -179,7 +179,9 @@ class CpEngine {
   double ms_schedule_cost(int k, unsigned excl) const;  // tensor-scan equivalents per sweep, 1e300: not schedulable
   int ms_choose_roots();
   void ms_set_roots(int k);
-  void ms_mode_update(int i, double lambda);
+  void ms_mode_update(int i, double lambda, bool last_of_sweep = false);
+  bool ms_norm_fused_ = false;  // the sweep's Normalize went into its last update launch (Ops::arm_normalize)
+  unsigned ms_collect_scales(unsigned *masks, unsigned *fresh, int skip_node);
   RTensor ms_X_;
   // Placement of the first-level intermediate: the scan reads the tensor and writes X at the same
   // time, and how the two streams fall onto the HBM channels depends on where X lies relative to
@@ -261,6 +263,8 @@ class CpEngine {
   void mode_update(int i, const double *M, int64_t ldm, double lambda, bool pp, double ratio);
   void normalize();
   const PPOp &pp_get(const std::string &seq);
+  int pp_last_mode(const std::string &seq) const;      // the contracted mode of `seq` that is removed last
+  std::string pp_parent(const std::string &seq) const;  // `seq` without it
   // out (+)= T contracted over `cmode` with f; T is a pair operator (two modes, any storage order)
   void pp_contract_pair(const PPOp &T, int cmode, const FactorRef &f, double *out, int64_t out_rows);
   bool pp_fast_ = true;  // both resident layouts + typed level-1 operators (pp_operator() switches it off for its fp64 hand-out)

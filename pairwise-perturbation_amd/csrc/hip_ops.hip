@@ -984,6 +984,7 @@ class HipOps : public Ops {
     update_mblk_ = 0;
   }
   int update_mblk_ = 0;
+  static constexpr int64_t kUpdateRowParallelFrom = 16384;  // rows x R from which a mode update is row-parallel
   void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
                       int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
                       double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,
@@ -1003,6 +1004,14 @@ class HipOps : public Ops {
     size_t lds = sizeof(double) * (32 + 2 * (size_t)R * R + 2 * (size_t)R * (R + 1) + 64) +
                  sizeof(int) * 64;
     const size_t stage = 2 * sizeof(double) * (size_t)rows * R;
+    // A long mode (7200 rows at R = 10: coil-100's last mode) does not fit the staged launch, and ONE
+    // workgroup walking rows x R entries out of global memory takes 333 us there: the row-parallel
+    // unfused route (S / S^-1, rows over many workgroups, Gram) takes a few short launches instead
+    if (lds + stage > 150 * 1024 && (int64_t)rows * R > kUpdateRowParallelFrom && !norm_armed_ && !update_mblk_) {
+      Ops::cp_mode_update(Gall, N, mode, R, lambda, M, ldm, W, ldw, grad, ldg, rows, gradsq, Winit, ldi, dW,
+                          ldd, ratio, S, Sinv, dwsq);
+      return;
+    }
     // S / S^-1 prepared by the contraction launched before (arm_gram_system + pp_correct)?
     const int presolved = (sys_ready_ && sys_.Gall == Gall && sys_.mode == mode && sys_.S == S &&
                            sys_.Sinv == Sinv && S && sys_.lambda == lambda) ? 1 : 0;
@@ -1029,7 +1038,8 @@ class HipOps : public Ops {
     HIP_CHECK(hipGetLastError());
   }
   bool arm_normalize(double *const *W, const int64_t *rows, int N, int R, double *Gall, int mode,
-                     double *wsq) override {
+                     double *wsq, double *ms_dst, const unsigned *masks, unsigned active,
+                     unsigned fresh) override {
     norm_armed_ = false;
     if (R > 64 || force_jacobi_ || N > MAX_ORDER) return false;
     int64_t tot = 0;
@@ -1044,6 +1054,12 @@ class HipOps : public Ops {
       norm_.w.n[i] = rows[i] * R;
     }
     norm_.wsq = wsq;
+    if (active && ms_dst && masks) {
+      norm_.ms_dst = ms_dst;
+      for (int k = 0; k < 32; k++) norm_.masks.m[k] = masks[k];
+      norm_.active = active;
+      norm_.fresh = fresh;
+    }
     norm_mode_ = mode;
     norm_G_ = Gall;
     (void)small(MAX_ORDER);  // (allocated now: no workspace growth inside the armed launch)
@@ -1116,7 +1132,7 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       return;
     }
-    if (R > 64) {
+    if (R > 64 || (int64_t)rows * R > kUpdateRowParallelFrom) {
       // several blocks update the rows: W_old is read from a scratch copy so that Wnew may alias it
       const int nb = (int)((rows + 63) / 64);
       double *wcopy = (double *)ensure(ws_big2_, ws_big2_sz_,

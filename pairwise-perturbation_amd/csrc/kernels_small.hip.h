@@ -1259,6 +1259,11 @@ struct NormArgs {
   PtrsN w;             // the N factors (p, n)
   double *scales = nullptr;
   double *wsq = nullptr;
+  // the pending-scale update of the cached multi-sweep tensors (as k_normalize_fused): ms_dst[k] for
+  // every k with (active >> k) & 1, starting from 1.0 where (fresh >> k) & 1
+  double *ms_dst = nullptr;
+  ScaleMasks masks;
+  unsigned active = 0, fresh = 0;
 };
 // MF (with STAGE): the two row products — grad = W_old S - M and W = M S^-1, (rows x R)(R x R) —
 // run on the matrix cores out of LDS. As VALU loops they are LDS-bandwidth bound (2 reads per FMA:
@@ -1571,6 +1576,12 @@ __global__ __launch_bounds__(1024) void k_cp_mode_update(
         } else {
           for (int64_t e = tid; e < nrm.w.n[i]; e += blockDim.x) pw[e] = f * pw[e];
         }
+      }
+      if (nrm.ms_dst && tid < 32 && ((nrm.active >> tid) & 1u)) {
+        double v = ((nrm.fresh >> tid) & 1u) ? 1.0 : nrm.ms_dst[tid];
+        for (int m = 0; m < MAX_ORDER; m++)
+          if (nrm.masks.m[tid] & (1u << m)) v *= nr[MAX_ORDER + m];
+        nrm.ms_dst[tid] = v;
       }
     }
   }

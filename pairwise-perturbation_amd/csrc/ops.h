@@ -261,10 +261,13 @@ class Ops {
   virtual void arm_gram_system(const double * /*Gall*/, int /*N*/, int /*mode*/, int /*R*/,
                                double /*lambda*/, double * /*S*/, double * /*Sinv*/) {}
   // Hint: the next cp_mode_update is the last of a sweep and a Normalize of these N full factors
-  // (no cached multi-sweep tensors alive) follows it immediately — a back end may fold it into that
-  // launch. Returns true when it WILL (the caller then skips its normalize call).
+  // follows it immediately — a back end may fold it into that launch, together with the pending-scale
+  // update of the cached multi-sweep tensors (ms_dst / masks / active / fresh as in normalize_ms;
+  // active == 0: none alive). Returns true when it WILL (the caller then skips its normalize call).
   virtual bool arm_normalize(double *const * /*W*/, const int64_t * /*rows*/, int /*N*/, int /*R*/,
-                             double * /*Gall*/, int /*mode*/, double * /*wsq*/) {
+                             double * /*Gall*/, int /*mode*/, double * /*wsq*/,
+                             double * /*ms_dst*/ = nullptr, const unsigned * /*masks*/ = nullptr,
+                             unsigned /*active*/ = 0, unsigned /*fresh*/ = 0) {
     return false;
   }
   // Normalize (common.cxx:680-688) on N full factors using ||W_i||^2 = trace(G_i); rescales the

@@ -31,7 +31,7 @@ test_tensor_refill_while_session_alive = G.test_tensor_refill_while_session_aliv
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R,roots", [([6, 5, 7, 6], 3, 1), ([5, 6, 4, 5, 3, 4], 2, 2),
-                                          ([50, 50, 6, 5], 4, 1), ([9, 40, 33, 7, 5], 17, 2)])
+                                          ([50, 50, 40, 36], 4, 1), ([9, 40, 33, 7, 5], 17, 2)])
 def test_padded_layouts_are_read(pp, ctx, lens, R, roots, dtype, tmp_path, monkeypatch):
     """the trace of a few sweeps shows scans on padded layouts (both of them when the order allows
     it), and the iterates are those of the oracle's alsCP_DT"""

@@ -59,7 +59,20 @@ def test_bench_live_pmc_traffic_units(tmp_path, monkeypatch):
     bench = importlib.import_module("bench")
     calls = []
 
-    def fake_run(cmd, cwd=None, env=None, stdout=None, stderr=None, timeout=None):
+    class FakeChild:
+        """what live_pmc_traffic starts with subprocess.Popen(..., start_new_session=True): the child runs in
+        a process group of its own, so that a timeout can kill the profiled grandchild with it"""
+        returncode = 0
+        pid = 0
+
+        def __init__(self, cmd, cwd=None, env=None, stdout=None, stderr=None, start_new_session=False):
+            assert start_new_session
+            fake_run(cmd)
+
+        def communicate(self, timeout=None):
+            return b"", None
+
+    def fake_run(cmd):
         calls.append(cmd)
         counter = cmd[cmd.index("--pmc") + 1]
         out = cmd[cmd.index("-d") + 1]
@@ -71,12 +84,11 @@ def test_bench_live_pmc_traffic_units(tmp_path, monkeypatch):
                 f'"void ppals::k_mttv_vec<float>(float const*)",{counter},999999.0']
         with open(os.path.join(out, "host", "123", "pmc_counter_collection.csv"), "w") as f:
             f.write("\n".join(rows) + "\n")
-        return argparse.Namespace(returncode=0, stdout=b"")
 
     import shutil
     import subprocess as sp
     monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
-    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.setattr(sp, "Popen", FakeChild)
     args = argparse.Namespace(workload="cp4_s200_r10", dtype="f32", schedule=None)
     traffic, src = bench.live_pmc_traffic(args)
     assert len(calls) == 2
@@ -86,6 +98,7 @@ def test_bench_live_pmc_traffic_units(tmp_path, monkeypatch):
         # the program itself follows `--`: the interpreter, then this script, never a shell or `env`
         tail = cmd[cmd.index("--") + 1:]
         assert tail[0] == sys.executable and tail[1].endswith("bench.py") and "--no-pmc" in tail
+        assert "--pmc-child" in tail   # the counted pass runs the workload's sweeps and nothing else
     want = (3155001.0 * 1024.0 * 2.0) + (312501.0 * 1024.0)
     assert abs(traffic - want) < 1.0, (traffic, want)
     assert "FETCH_SIZE KiB x 2" in src and "2 / 2 launches" in src
