@@ -984,7 +984,10 @@ class HipOps : public Ops {
     update_mblk_ = 0;
   }
   int update_mblk_ = 0;
-  static constexpr int64_t kUpdateRowParallelFrom = 16384;  // rows x R from which a mode update is row-parallel
+  // rows x R from which a mode update that does not fit the staged launch is row-parallel: the unstaged
+  // one-workgroup launch costs 4 us + 4.5 us per 1000 entries (53 us at 1344 x 10, 333 us at 7200 x 10),
+  // the row-parallel route five short launches (~30 us)
+  static constexpr int64_t kUpdateRowParallelFrom = 6144;
   void cp_mode_update(double *Gall, int N, int mode, int R, double lambda, const double *M,
                       int64_t ldm, double *W, int64_t ldw, double *grad, int64_t ldg, int64_t rows,
                       double *gradsq, const double *Winit, int64_t ldi, double *dW, int64_t ldd,

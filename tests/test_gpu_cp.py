@@ -366,7 +366,7 @@ def test_driver_pp_matches_oracle(pp, ctx, dtype, lens, R, tmp_path):
                                     ([7, 1700, 13, 4], 10)])     # time-lapse's: a long mode between short ones
 def test_long_and_short_modes_exact_and_pp(pp, ctx, dtype, lens, R, tmp_path):
     """The reference's real-data extents in miniature (test_ALS.cxx:287-326): a mode of 1700-1800 rows
-    at R = 10 is beyond the one-workgroup fused update (rows x R > 16384: the row-parallel route of
+    at R = 10 is beyond the staged one-workgroup fused update (the row-parallel route of
     HipOps::cp_mode_update), and the PP operator chains contract their LONGEST mode first
     (CpEngine::pp_last_mode) instead of the reference's lowest (als_CP.cxx:385-390) — same operators,
     same iterates: exact sweeps under both schedules and the alsCP_PP driver against the oracle."""

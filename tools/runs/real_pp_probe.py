@@ -18,7 +18,10 @@ SHAPES = {"coil100": [3, 128, 128, 7200], "timelapse": [33, 1344, 1024, 9]}
 def main():
     lens, R = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "coil100"], 10
     ctx = ppals.Context(0)
-    V = ppals.Tensor(ctx, lens, ppals.F32).fill_uniform(7)
+    import numpy as np
+    Wt = ppals.init_factors(lens, 100, 1000)   # image-like: a rank-100 model with decaying weights
+    decay = (0.93 ** np.arange(100)) ** (1.0 / len(lens))
+    V = ppals.Tensor(ctx, lens, ppals.F32).fill_cp([np.asfortranarray(w * decay[None, :]) for w in Wt])
     vn = V.norm()
     W0, G0 = ppals.init_factors(lens, R, 2000), ppals.init_factors(lens, R, 3000)
     cp = ppals.CP(ctx, V, R)

@@ -19,7 +19,10 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     ppals.preload_eigensolver()
     ctx = ppals.Context(0)
-    V = ppals.Tensor(ctx, lens, ppals.F32).fill_uniform(7)
+    import numpy as np
+    Wt = ppals.init_factors(lens, 100, 1000)   # image-like: a rank-100 model with decaying weights
+    decay = (0.93 ** np.arange(100)) ** (1.0 / len(lens))
+    V = ppals.Tensor(ctx, lens, ppals.F32).fill_cp([np.asfortranarray(w * decay[None, :]) for w in Wt])
     tk = ppals.Tucker(ctx, V, ranks)
     ctx.sync()
     t0 = time.perf_counter()
