@@ -124,6 +124,7 @@ class HipOps : public Ops {
       hipEventDestroy(t.a);
       hipEventDestroy(t.b);
     }
+    if (ws_mttv_) hipFree(ws_mttv_);
     if (ws_pack_) hipFree(ws_pack_);
     if (ws_slab_) hipFree(ws_slab_);
     if (ws_krp_) hipFree(ws_krp_);
@@ -859,15 +860,37 @@ class HipOps : public Ops {
       int g = (int)std::min<int64_t>(nb, 1 << 20);
       hipLaunchKernelGGL(k_mttv_vec<TX>, dim3(g + extra), dim3(64), lds, st_, X, L, J, T, R, B, ldb, out,
                          rs, accumulate, scale, sys);
+    } else if (L < 64 && L * J <= 2048 && T * R >= 2048) {
+      // a short plane per (t, r) and many of them: one wave each, no workgroup barrier (k_mttv_s)
+      const int64_t nwaves = T * R;
+      int g = (int)std::min<int64_t>((nwaves + 3) / 4, 16384);
+      hipLaunchKernelGGL(k_mttv_s<TX>, dim3(g + extra), dim3(256), lds, st_, X, (int)L, J, T, R, B, ldb, out,
+                         rs, accumulate, scale, sys);
     } else {
       int64_t nb = ((L + 63) / 64) * T * R;
-      int g = (int)std::min<int64_t>(nb, 32768);
-      if (nb * 4 < 1024)  // few blocks: split the j loop 16 ways instead of 4
-        hipLaunchKernelGGL((k_mttv_l<TX, 16>), dim3(g + extra), dim3(1024), lds, st_, X, L, J, T, R, B,
-                           ldb, out, rs, accumulate, scale, sys);
-      else
+      // a long reduction over few row tiles (128 x 7200 x R: 20 workgroups): the j range is cut into
+      // pieces, one workgroup each, and a second launch adds the partial sums in a fixed order
+      int jsplit = 1;
+      if (nb < 512 && J >= 1024) jsplit = (int)std::min<int64_t>((1024 + nb - 1) / nb, J / 64);
+      if (jsplit > 1) {
+        const int64_t jchunk = (J + jsplit - 1) / jsplit;
+        jsplit = (int)((J + jchunk - 1) / jchunk);
+        double *partial = (double *)ensure(ws_mttv_, ws_mttv_sz_, sizeof(double) * (size_t)jsplit * L * T * R);
+        const int64_t nbs = nb * jsplit;
+        int g = (int)std::min<int64_t>(nbs, 32768);
         hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g + extra), dim3(256), lds, st_, X, L, J, T, R, B, ldb,
-                           out, rs, accumulate, scale, sys);
+                           out, rs, accumulate, scale, sys, jsplit, jchunk, partial);
+        hipLaunchKernelGGL(k_mttv_combine, dim3(grid_for(L * T * R, 256, 1024)), dim3(256), 0, st_, partial,
+                           jsplit, L * T, R, out, rs, accumulate, scale);
+      } else {
+        int g = (int)std::min<int64_t>(nb, 32768);
+        if (nb * 4 < 1024)  // few blocks: split the j loop 16 ways instead of 4
+          hipLaunchKernelGGL((k_mttv_l<TX, 16>), dim3(g + extra), dim3(1024), lds, st_, X, L, J, T, R, B,
+                             ldb, out, rs, accumulate, scale, sys);
+        else
+          hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g + extra), dim3(256), lds, st_, X, L, J, T, R, B, ldb,
+                             out, rs, accumulate, scale, sys);
+      }
     }
     if (extra) {
       sys_ready_ = true;
@@ -2848,6 +2871,8 @@ class HipOps : public Ops {
   size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;
   hipStream_t st_ = nullptr;
   hipStream_t st2_ = nullptr;  // the Jacobi of a lazy eigen-step (created on first use)
+  void *ws_mttv_ = nullptr;  // partial sums of a j-split k_mttv_l
+  size_t ws_mttv_sz_ = 0;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;
   size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0,

@@ -405,20 +405,29 @@ __global__ __launch_bounds__(64) void k_mttv_vec(const TX *__restrict__ X, int64
 // variant L: block = 64 consecutive l for one (t,r); the NW waves split the j range and combine
 // through LDS in a fixed order, so even a 200 x 200 x R leaf contraction spreads over hundreds of
 // waves (NW = 16 for the small fp64 nodes, where the j loop is the whole latency of the launch).
+// jsplit > 1: a LONG reduction over few row tiles (128 x 7200 x R: 20 workgroups) is cut into jsplit
+// ranges of jchunk indices, one workgroup each; the raw partial sums go to `partial`
+// [split][l + L*(t + T*r)] and k_mttv_combine adds them in a fixed order (no atomics).
 template <typename TX, int NW>
 __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, int64_t L, int64_t J,
                                                     int64_t T, int R, const double *__restrict__ B,
                                                     int64_t ldb, double *__restrict__ out,
                                                     int64_t rs, int accumulate,
                                                     const double *__restrict__ scale,
-                                                    SysArgs sys = SysArgs()) {
+                                                    SysArgs sys = SysArgs(), int jsplit = 1,
+                                                    int64_t jchunk = 0,
+                                                    double *__restrict__ partial = nullptr) {
   PPALS_SYS_BLOCK(sys, R, nblk)
   __shared__ double part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ltiles = (L + 63) / 64;
-  const int64_t total = ltiles * T * R;
+  const int64_t total = ltiles * T * R * jsplit;
   const double sc = mttv_scale(scale);
-  for (int64_t blk = blockIdx.x; blk < total; blk += nblk) {
+  for (int64_t blk0 = blockIdx.x; blk0 < total; blk0 += nblk) {
+    const int split = (int)(blk0 % jsplit);
+    const int64_t blk = blk0 / jsplit;
+    const int64_t jbeg = jsplit > 1 ? split * jchunk : 0;
+    const int64_t jend = jsplit > 1 ? min(J, jbeg + jchunk) : J;
     const int64_t lt = blk % ltiles;
     const int64_t t = (blk / ltiles) % T;
     const int r = (int)(blk / (ltiles * T));
@@ -433,14 +442,14 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (l < L && lp < P) {
       const int64_t st = (int64_t)NW * P;
-      int64_t j = (int64_t)wave * P + lp;
-      for (; j + 3 * st < J; j += 4 * st) {
+      int64_t j = jbeg + (int64_t)wave * P + lp;
+      for (; j + 3 * st < jend; j += 4 * st) {
         s0 += (double)x[L * j] * b[j];
         s1 += (double)x[L * (j + st)] * b[j + st];
         s2 += (double)x[L * (j + 2 * st)] * b[j + 2 * st];
         s3 += (double)x[L * (j + 3 * st)] * b[j + 3 * st];
       }
-      for (; j < J; j += st) s0 += (double)x[L * j] * b[j];
+      for (; j < jend; j += st) s0 += (double)x[L * j] * b[j];
     }
     part[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -449,11 +458,78 @@ __global__ __launch_bounds__(64 * NW) void k_mttv_l(const TX *__restrict__ X, in
 #pragma unroll
       for (int w = 0; w < NW; w++)
         for (int q = 0; q < P; q++) s += part[w][lane + (int)L * q];
-      s *= sc;
-      double *o = out + l + L * t + rs * r;
-      *o = accumulate ? (*o + s) : s;
+      if (jsplit > 1) {
+        partial[(int64_t)split * (L * T * R) + l + L * (t + T * (int64_t)r)] = s;
+      } else {
+        s *= sc;
+        double *o = out + l + L * t + rs * r;
+        *o = accumulate ? (*o + s) : s;
+      }
     }
     __syncthreads();
+  }
+}
+// out[lt + rs*r] (+)= scale * sum_s partial[s][lt + LT*r]   (the second pass of a j-split k_mttv_l)
+__global__ __launch_bounds__(256) void k_mttv_combine(const double *__restrict__ partial, int jsplit,
+                                                      int64_t LT, int R, double *__restrict__ out,
+                                                      int64_t rs, int accumulate,
+                                                      const double *__restrict__ scale) {
+  const int64_t n = LT * R;
+  const double sc = mttv_scale(scale);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int q = 0; q < jsplit; q++) s += partial[(int64_t)q * n + e];
+    s *= sc;
+    double *o = out + (e % LT) + rs * (e / LT);
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+// variant S (a short leading extent and a short reduction: L < 64, L*J a few hundred elements, T*R
+// large — X_c of the coil-100 extents, [3, 128 | 7200 x R]): ONE WAVE per (t, r), no workgroup barrier.
+// The wave walks the contiguous L*J plane P = 64 / L reduction indices at a time (lanes (l, p) read L*P
+// contiguous elements), every lane keeps the sum of its own (l, p-class), and the P classes of a row
+// meet by shuffles. k_mttv_l's per-workgroup LDS combine (NW x P serial adds by L lanes, two barriers)
+// was the whole cost of such a launch: 79 us for 110 MB.
+template <typename TX>
+__global__ __launch_bounds__(256) void k_mttv_s(const TX *__restrict__ X, int L, int64_t J, int64_t T,
+                                                int R, const double *__restrict__ B, int64_t ldb,
+                                                double *__restrict__ out, int64_t rs, int accumulate,
+                                                const double *__restrict__ scale,
+                                                SysArgs sys = SysArgs()) {
+  PPALS_SYS_BLOCK(sys, R, nblk)
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)nblk * blockDim.x) >> 6;
+  const int P = 64 / L;
+  const int l = lane % L, p = lane / L;
+  const bool on = p < P;
+  const double sc = mttv_scale(scale);
+  const int64_t plane = (int64_t)L * J;
+  for (int64_t w = wid; w < T * R; w += nw) {
+    const int64_t t = w % T;
+    const int r = (int)(w / T);
+    const TX *x = X + plane * (t + T * (int64_t)r) + l;
+    const double *b = B + ldb * r;
+    double s0 = 0, s1 = 0;
+    if (on) {
+      int64_t j = p;
+      for (; j + P < J; j += 2 * P) {
+        s0 += (double)x[(int64_t)L * j] * b[j];
+        s1 += (double)x[(int64_t)L * (j + P)] * b[j + P];
+      }
+      if (j < J) s0 += (double)x[(int64_t)L * j] * b[j];
+    }
+    double s = on ? s0 + s1 : 0.0;
+    // classes p, p + h, ... of one row: halving tree over p (lane distance h * L)
+    for (int h = (P + 1) / 2, cnt = P; cnt > 1; cnt = h, h = (h + 1) / 2) {
+      const double o = __shfl_down(s, h * L, 64);
+      if (p + h < cnt && on) s += o;
+    }
+    if (p == 0) {
+      double *o = out + l + (int64_t)L * t + rs * r;
+      const double v = sc * s;
+      *o = accumulate ? (*o + v) : v;
+    }
   }
 }
 // variant 1 (L == 1): one wave per 4 consecutive t of one r, lanes stride the contiguous j (four
@@ -628,9 +704,18 @@ __global__ void k_gram(const double *__restrict__ W, int64_t rows, int64_t ld, i
     }
     const int q = p + rem;
     const double *a = W + ld * p, *b = W + ld * q;
-    double s = 0;
-    for (int64_t i = lane; i < rows; i += 64) s += a[i] * b[i];
-    s = wave_sum(s);
+    // four independent chains per lane: a long mode (7200 rows: 112 dependent loads per lane in one
+    // chain, 34 us) is latency, not bandwidth
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t i = lane;
+    for (; i + 192 < rows; i += 256) {
+      s0 += a[i] * b[i];
+      s1 += a[i + 64] * b[i + 64];
+      s2 += a[i + 128] * b[i + 128];
+      s3 += a[i + 192] * b[i + 192];
+    }
+    for (; i < rows; i += 64) s0 += a[i] * b[i];
+    const double s = wave_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) {
       G[p + R * q] = s;
       G[q + R * p] = s;
