@@ -708,6 +708,25 @@ class HipOps : public Ops {
           } else {
             LAUNCH_SUFFIX_BUF(4)
           }
+        } else if (al && M >= VEC && T == 1 && nsplit == 1 && NT <= 2 && k_ld == 0 && !nt_store &&
+                   scan_tail_split<TV>(NT, n_mtiles) >= 0) {
+          // a round and a bit of resident workgroups (cfg5's 625 tiles on 512 slots: 0.49 of the HBM
+          // peak): the tiles of the last, partial round as four quarter-length work items each
+          // (kernels_scan.hip.h, TAIL MODE)
+          const int tail_from = scan_tail_split<TV>(NT, n_mtiles);
+          const int64_t strips = ((M + 16 * VEC - 1) / (16 * VEC)) - (int64_t)tail_from * 4;
+          dim3 grid_t((unsigned)(tail_from + strips));
+          const size_t lds_t = sizeof(double) * 3 * (size_t)(VEC * NT * 4) * 64;
+#define LAUNCH_SUFFIX_TAIL(NTv)                                                                            \
+  hipLaunchKernelGGL((k_scan_suffix_fast<TV, NTv, 9>), grid_t, dim3(256), lds_t, st_, V, M, K, M * K, P,   \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, (int64_t)0,   \
+                     (int64_t)0, tail_from)
+          if (NT == 1) {
+            LAUNCH_SUFFIX_TAIL(1);
+          } else {
+            LAUNCH_SUFFIX_TAIL(2);
+          }
+#undef LAUNCH_SUFFIX_TAIL
         } else if (al && M >= VEC) {
           if (NT == 1) {
             LAUNCH_SUFFIX_FAST(1)
@@ -745,6 +764,34 @@ class HipOps : public Ops {
       }
     }
   }
+  // Where the tail mode of k_scan_suffix_fast starts (first tile of the last, partial round of resident
+  // workgroups), or -1: the launch fits one round, has many rounds (the tail is a small share), or its
+  // last round is nearly full anyway. Resident workgroups per CU from the runtime's occupancy query
+  // of the tail-mode instantiation (its LDS included).
+  template <typename TV>
+  int scan_tail_split(int NT, int n_mtiles) {
+    constexpr int VEC = ScanTraits<TV>::VEC;
+    int &per_cu = scan_tail_occ_[(sizeof(TV) == 8 ? 2 : 0) + (NT - 1)];
+    if (per_cu == 0) {
+      const size_t lds_t = sizeof(double) * 3 * (size_t)(VEC * NT * 4) * 64;
+      int nb = 0;
+      hipError_t e = NT == 1
+          ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_suffix_fast<TV, 1, 9>, 256, lds_t)
+          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_suffix_fast<TV, 2, 9>, 256, lds_t);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+      }
+      per_cu = nb > 0 ? nb : -1;
+    }
+    if (per_cu < 0) return -1;
+    const int slots = ncu_ * per_cu;
+    if (n_mtiles <= slots || n_mtiles > 4 * slots) return -1;
+    const int rem = n_mtiles % slots;
+    if (rem == 0 || rem * 4 > slots * 3) return -1;   // (a last round that is 3/4 full is left alone)
+    return n_mtiles - rem;
+  }
+  int scan_tail_occ_[4] = {0, 0, 0, 0};
   using Ops::scan_contract;
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
                      int nf, int R, void *out, int out_dt, int64_t out_tstride,

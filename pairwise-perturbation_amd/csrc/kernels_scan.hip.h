@@ -338,7 +338,14 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
     const TV *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
     double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
-    int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0) {
+    int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0,
+    int tail_from = -1) {
+  // TAIL MODE (OPT bit 3; one batch, no k-split, dynamic LDS): a launch of a little more than a whole
+  // number of rounds of resident workgroups (cfg5: 625 tiles on 512 slots) leaves its last tiles to a
+  // quarter-empty chip. Tiles from `tail_from` on are therefore handed out as FOUR workgroups each:
+  // a workgroup takes ONE 16*VEC-row strip and its four waves split the k range, the partial sums
+  // meet in LDS in a fixed order. The same bytes are read once, nothing extra is written, no second
+  // launch — the tail simply has four times as many, four times shorter work items.
   typedef ScanTraits<TV> TR;
   typedef typename TR::vec vec;
   typedef typename TR::acc acc_t;
@@ -349,6 +356,8 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j16 = lane & 15;
   int64_t bid = blockIdx.x;
+  bool tail = false;
+  if constexpr ((OPT & 8) != 0) tail = tail_from >= 0 && bid >= tail_from;
   if constexpr (OPT & 2) {
     // blocks are dealt round-robin over the 8 XCDs (speed only): give each XCD a contiguous
     // eighth of the (mtile-fastest) id space so that it works on few k-splits at a time
@@ -358,15 +367,23 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   }
   const int mtile = (int)(bid % n_mtiles);
   bid /= n_mtiles;
-  const int split = (int)(bid % nsplit);
-  const int64_t batch = bid / nsplit;
+  const int split = tail ? 0 : (int)(bid % nsplit);       // (tail mode: one batch, no k-split)
+  const int64_t batch = tail ? 0 : bid / nsplit;
 
-  const int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
-  if (m0 >= M) return;  // wave-uniform
+  int64_t m0 = ((int64_t)mtile * 4 + wave) * (16 * VEC);
+  int kb0 = split * kb_per_split;
+  int kb1 = min(nkb, kb0 + kb_per_split);
+  if constexpr ((OPT & 8) != 0) {
+    if (tail) {  // (workgroup-uniform: all four waves share the strip)
+      m0 = ((int64_t)tail_from * 4 + (blockIdx.x - tail_from)) * (16 * VEC);
+      const int per = (nkb + 3) / 4;
+      kb0 = min(nkb, wave * per);
+      kb1 = min(nkb, kb0 + per);
+    }
+  }
+  if (m0 >= M) return;  // wave-uniform (tail mode: workgroup-uniform)
   const int64_t m = m0 + (int64_t)VEC * j16;
   const int64_t m_ld = min(m, M - VEC);  // clamped: lanes past the edge re-read the last rows
-  const int kb0 = split * kb_per_split;
-  const int kb1 = min(nkb, kb0 + kb_per_split);
   const TV *__restrict__ vp = V + batch * batch_stride + m_ld;
   const TV *__restrict__ pp = P + ((int64_t)g * 16 + j16) * VEC;
 
@@ -443,6 +460,44 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
   }
 #undef PPALS_LOAD_BLOCK
 
+  if constexpr ((OPT & 8) != 0) {
+    if (tail) {
+      // waves 1..3 hand their sums to wave 0 through LDS: [wave - 1][slot][lane], fixed order
+      extern __shared__ double tail_lds[];
+      constexpr int NS = VEC * NT * 4;
+      if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < VEC; a++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              double v;
+              if constexpr (TR::NEEDS_FLUSH)
+                v = acc64[a][nt][r];
+              else
+                v = (double)acc[a][nt][r];
+              tail_lds[((wave - 1) * NS + (a * NT + nt) * 4 + r) * 64 + lane] = v;
+            }
+      }
+      __syncthreads();
+      if (wave > 0) return;
+#pragma unroll
+      for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int a = 0; a < VEC; a++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const double v = tail_lds[(w * NS + (a * NT + nt) * 4 + r) * 64 + lane];
+              if constexpr (TR::NEEDS_FLUSH)
+                acc64[a][nt][r] += v;
+              else
+                acc[a][nt][r] += v;
+            }
+    }
+  }
   // epilogue: a lane owns VEC consecutive rows of 4 output columns -> one vector store per column
   // (16 lanes x VEC rows = 16*VEC contiguous elements); scalar stores only for unaligned strides
   const int64_t obase = split * out_split_stride + batch * out_batch_stride;

@@ -106,6 +106,27 @@ def test_tree_nodes_and_mttkrp(pp, ctx, lens, R, dtype, vt, monkeypatch):
         assert relerr(got, want) < KTOL[dtype], (mode, relerr(got, want))
 
 
+@pytest.mark.parametrize("lens,R", [([600, 250, 12], 20), ([300, 500, 40], 20), ([520, 260, 150], 17)])
+def test_scan_with_a_partial_last_round(pp, ctx, lens, R):
+    """A first-level scan of a little more than one round of resident workgroups (two n-tiles, fp32:
+    586 / 586 / 529 tiles of 256 rows on 512 slots) runs its last tiles in TAIL MODE
+    (k_scan_suffix_fast, OPT bit 3: four workgroups per tile, the four waves of each split the k range —
+    1, 3 and 10 blocks of 16 here: waves with an empty range, ragged last strip — and meet in LDS):
+    node `ab` = V x_c W_c and every mode's MTTKRP against the oracle at kernel accuracy."""
+    V, W = problem(lens, R, 8)
+    t = pp.Tensor(ctx, lens, 0).upload(V)
+    s = pp.CP(ctx, t, R)
+    s.set_schedule("dt")
+    s.set_factors(W)
+    got = s.tree_node("ab")
+    want = O.tree_node(V, W, "ab").ravel(order="F")
+    assert relerr(got, want) < KTOL[0], relerr(got, want)
+    for mode in range(3):
+        assert relerr(s.mttkrp(mode), O.mttkrp(V, W, mode, 0)) < KTOL[0], mode
+    s.close()
+    t.close()
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("lens,R", [([8, 8, 8, 8], 3), ([5, 6, 7, 4], 3), ([12, 10, 9, 11], 10),
                                     ([9, 8, 7], 4), ([5, 4, 3, 4, 3], 2)])
