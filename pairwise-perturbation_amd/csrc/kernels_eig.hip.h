@@ -21,6 +21,14 @@
 
 namespace ppals {
 
+// Ranking key of an eigenvalue: a NaN (a Rayleigh-Ritz matrix built from a block that lost rank — an
+// exactly low-rank tensor, whose Gram has fewer non-zero eigenvalues than the block has columns —
+// reaches the Jacobi before the host has read the factorisation's status) compares false with
+// everything, so several columns would take rank 0 and the other entries of the permutation stay
+// unwritten: an index out of nowhere, a memory fault in the gather behind it. NaNs rank last, ties by index.
+__device__ inline double eig_rank_key(double v) { return v == v ? v : -1.0e308; }
+
+
 // Layout of the block a projector step leaves for its one read-back (device workspace, the slot's
 // pinned copy): check words | eigenvalues (rank + wide columns) | status | deflated eigenvalues |
 // per-workgroup residual shares.
@@ -1564,10 +1572,10 @@ __global__ __launch_bounds__(1024) void k_rr_apply(const double *__restrict__ Bm
   double *A, *Q;
   jacobi_eig_block(A0, A1, Q0, Q1, cols, rc, rs, partner, red, &A, &Q);
   if (tid < cols) {
-    const double wk = A[tid * ldA + tid];
+    const double wk = eig_rank_key(A[tid * ldA + tid]);
     int pos = 0;
     for (int j = 0; j < cols; j++) {
-      const double wj = A[j * ldA + j];
+      const double wj = eig_rank_key(A[j * ldA + j]);
       if (wj > wk || (wj == wk && j < tid)) pos++;
     }
     ord[pos] = tid;
@@ -1729,10 +1737,10 @@ __global__ __launch_bounds__(1024) void k_rr_small(const double *__restrict__ H,
   double *A, *Q;
   jacobi_eig_block(A0, A1, Q0, Q1, cols, rc, rs, partner, red, &A, &Q);
   if (tid < cols) {
-    const double wk = A[tid * ldA + tid];
+    const double wk = eig_rank_key(A[tid * ldA + tid]);
     int pos = 0;
     for (int j = 0; j < cols; j++) {
-      const double wj = A[j * ldA + j];
+      const double wj = eig_rank_key(A[j * ldA + j]);
       if (wj > wk || (wj == wk && j < tid)) pos++;
     }
     ord[pos] = tid;
@@ -1846,10 +1854,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_onesided(const double *__restri
   }
   __syncthreads();
   if (tid < n) {
-    const double wk = nrm[tid];
+    const double wk = eig_rank_key(nrm[tid]);
     int pos = 0;
     for (int j = 0; j < n; j++) {
-      const double wj = nrm[j];
+      const double wj = eig_rank_key(nrm[j]);
       if (wj > wk || (wj == wk && j < tid)) pos++;
     }
     ord[pos] = tid;

@@ -669,6 +669,48 @@ def test_order3_multi_sweep_schedule(pp, lens, ranks, dtype, monkeypatch):
         assert scans[("ms", sweeps)] == ((3 * sweeps + 1) // 2 if big else 2 * sweeps), scans
 
 
+@pytest.mark.parametrize("lens,inner,ranks", [([96, 80, 72], [10, 9, 8], [8, 7, 6]),
+                                              ([130, 120, 12], [75, 75, 12], [70, 70, 10])])
+def test_exactly_low_rank_tensor_block_loses_rank(pp, lens, inner, ranks):
+    """A tensor of EXACT multilinear rank `inner` (no noise): the Gram of an unfolding has fewer non-zero
+    eigenvalues than the cold start's block has columns (rank + 16), the block loses rank, its
+    factorisation leaves NaNs and the Rayleigh-Ritz Jacobi sees them before the host has read the
+    status — it once ranked the NaN eigenvalues all at position 0 and gathered through an unwritten
+    permutation (a memory fault on the time-lapse extents with an image-like rank-100 tensor, round 5).
+    The step must be rejected and the fallback deliver the oracle's subspaces, for a block of <= 64
+    columns (in-LDS Jacobi) and of 86 (k_jacobi_onesided)."""
+    rng = np.random.default_rng(3)
+    U = [np.linalg.qr(rng.standard_normal((s, r)))[0] for s, r in zip(lens, inner)]
+    core = rng.standard_normal(inner)
+    for m, r in enumerate(inner):
+        shape = [1] * len(inner)
+        shape[m] = r
+        core = core * (0.95 ** np.arange(r)).reshape(shape)
+    V = core
+    for m, u in enumerate(U):
+        V = np.moveaxis(np.tensordot(u, V, axes=(1, m)), 0, m)
+    V = np.asfortranarray(V)
+    W_ref, core_ref = O.hosvd(V, ranks)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    s.hosvd()
+    W, core_got = s.get_factors()
+    for a, b, r in zip(W, W_ref, ranks):
+        assert np.isfinite(a).all()
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-7, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core_got) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    s.sweeps_dt(3)
+    W3, core3 = s.get_factors()
+    _, _, W3_ref, core3_ref = O.als_tucker_dt(V, W_ref, core_ref, tol=0.0, maxiter=2, resprint=10 ** 9)
+    for a, b in zip(W3, W3_ref):
+        assert np.isfinite(a).all() and relerr(proj(a), proj(b)) < 1e-6, relerr(proj(a), proj(b))
+    s.close()
+    t.close()
+    c2.close()
+
+
 def test_eigen_step_wide_tail(pp, tmp_path, monkeypatch, capfd):
     """a shift that has slipped below a few more eigenvalues than wanted (forced here:
     PPALS_EIG_SIGMA_SCALE puts it at 0.4 x the next eigenvalue, under the two that follow in this
