@@ -103,6 +103,7 @@ class HipOps : public Ops {
       handover_ok_ = eig_defer_ok_ != 2;  // (2: deferred, the second stream handed over by events)
     }
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
+    if (const char *v = getenv("PPALS_SCAN_TAIL")) scan_tail_on_ = atoi(v) != 0;
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rmult_chol,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_jacobi_onesided,
@@ -772,6 +773,7 @@ class HipOps : public Ops {
   int scan_tail_split(int NT, int n_mtiles) {
     constexpr int VEC = ScanTraits<TV>::VEC;
     int &per_cu = scan_tail_occ_[(sizeof(TV) == 8 ? 2 : 0) + (NT - 1)];
+    if (!scan_tail_on_) return -1;
     if (per_cu == 0) {
       const size_t lds_t = sizeof(double) * 3 * (size_t)(VEC * NT * 4) * 64;
       int nb = 0;
@@ -792,6 +794,7 @@ class HipOps : public Ops {
     return n_mtiles - rem;
   }
   int scan_tail_occ_[4] = {0, 0, 0, 0};
+  bool scan_tail_on_ = true;  // PPALS_SCAN_TAIL=0: no tail mode (A/B)
   using Ops::scan_contract;
   void scan_contract(const void *V, int dt, int64_t L, int64_t J, int64_t T, const FactorRef *f,
                      int nf, int R, void *out, int out_dt, int64_t out_tstride,
