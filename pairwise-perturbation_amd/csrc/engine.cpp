@@ -266,6 +266,7 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
     ops_.zero(gatherbuf_, n);
   }
   if (const char *e = std::getenv("PPALS_COMM_SMALL_BYTES")) small_msg_bytes_ = std::atoll(e);
+  if (const char *e = std::getenv("PPALS_TEST_BLOCKED_UPDATE")) test_blocks_ = std::atoi(e);
   if (N_ < 3) schedule_ = 0;
   if (const char *e = std::getenv("PPALS_PLACE_TUNE")) ms_tune_enabled_ = std::atoi(e) != 0;
   if (N_ >= 3) {  // multi-sweep structures exist for every session so the schedule can be switched
@@ -344,6 +345,7 @@ CpEngine::~CpEngine() {
   ops_.free(sendbuf_);
   ops_.free(recvbuf_);
   ops_.free(gatherbuf_);
+  ops_.free(test_blkbuf_);
   ops_.free(Mbuf_);
   ops_.free(Qbuf_);
   ops_.free(Pbuf_);
@@ -682,6 +684,21 @@ void CpEngine::mode_update(int i, const double *M, int64_t ldm, double lambda, b
   const int64_t s = V_.glens[i];
   double *Gi = G_ + (size_t)i * R_ * R_;
   if (!dist_) {
+    if (test_blocks_ > 1 && s % test_blocks_ == 0 && !pp) {
+      // test hook (PPALS_TEST_BLOCKED_UPDATE=P, one rank): the update reads its M in P row blocks, as the
+      // sharded mode's update reads the all-gather's receive buffer on P ranks — the blocked
+      // addressing of the fused launch with more than one block, on one GPU
+      const int64_t blk = s / test_blocks_;
+      const size_t bytes = sizeof(double) * (size_t)s * R_;
+      if (!test_blkbuf_) {
+        test_blkbuf_ = (double *)ops_.alloc(2 * sizeof(double) * (size_t)maxs_ * R_);
+      }
+      ops_.pack_blocks(M, s, ldm, R_, blk, test_blocks_, test_blkbuf_);
+      ops_.cp_mode_update_blocked(G_, N_, i, R_, lambda, test_blkbuf_, blk, test_blocks_,
+                                  test_blkbuf_ + bytes / sizeof(double), W_[i], s, gradW_[i], s, s,
+                                  gradsq_ + i, nullptr, s, nullptr, s, ratio, S_, Sinv_);
+      return;
+    }
     ops_.cp_mode_update(G_, N_, i, R_, lambda, M, ldm, W_[i], s, gradW_[i], s, s, gradsq_ + i,
                         pp ? Winit_[i] : nullptr, s, pp ? dW_[i] : nullptr, s, ratio, S_, Sinv_,
                         (pp && pp_norms_) ? pp_norms_ + 2 * i : nullptr);

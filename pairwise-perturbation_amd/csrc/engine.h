@@ -173,6 +173,8 @@ class CpEngine {
   // be a partial sum of global size) and modes so short that X = V x_m W_m is no smaller than the tensor
   // (extent 3 at R = 10: X is 3.3 x the tensor — the reference's coil-100 / time-lapse shapes). The root
   // set is slid back past them (ms_next_root); the cost model prices both (ms_schedule_cost).
+  int test_blocks_ = 0;            // PPALS_TEST_BLOCKED_UPDATE (test hook, see mode_update)
+  double *test_blkbuf_ = nullptr;
   unsigned ms_excl_ = 0;
   bool ms_set_excluded(int first, int k, unsigned excl) const;
   int ms_next_root(int i, int k, unsigned excl) const;  // first mode of the root set that serves update i, -1: none

@@ -39,6 +39,7 @@ test_normalize_and_owed_scale = G.test_normalize_and_owed_scale
 test_pp_operator_after_msdt_sweeps = G.test_pp_operator_after_msdt_sweeps
 test_short_modes_are_never_roots = G.test_short_modes_are_never_roots
 test_long_and_short_modes_exact_and_pp = G.test_long_and_short_modes_exact_and_pp
+test_update_reads_gathered_row_blocks = G.test_update_reads_gathered_row_blocks
 test_driver_dt_csv_matches_oracle = G.test_driver_dt_csv_matches_oracle
 test_driver_pp_matches_oracle = G.test_driver_pp_matches_oracle
 test_driver_pp_partupdate_matches_oracle = G.test_driver_pp_partupdate_matches_oracle

@@ -106,6 +106,35 @@ def test_tree_nodes_and_mttkrp(pp, ctx, lens, R, dtype, vt, monkeypatch):
         assert relerr(got, want) < KTOL[dtype], (mode, relerr(got, want))
 
 
+@pytest.mark.parametrize("blocks", [2, 4, 8])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_update_reads_gathered_row_blocks(pp, blocks, dtype, monkeypatch):
+    """The sharded mode's update on P ranks reads the all-gather's receive buffer as it lies: P row blocks
+    of s / P rows, block p at p * blk * R with leading dimension blk (k_cp_mode_update's `mblk`;
+    Ops::cp_mode_update_blocked). On one GPU the test hook PPALS_TEST_BLOCKED_UPDATE=P routes every
+    mode update whose extent P divides through that addressing: same sweeps as the oracle."""
+    monkeypatch.setenv("PPALS_TEST_BLOCKED_UPDATE", str(blocks))
+    lens, R = [16, 24, 8, 32], 6
+    V, W = problem(lens, R, 4, "r")
+    G = O.init_factors(lens, R, 99)
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=3, resprint=1000)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, dtype).upload(V)
+    for schedule in ("msdt", "dt"):
+        s = pp.CP(c2, t, R)
+        s.set_schedule(schedule)
+        s.set_factors(W, G)
+        s.sweeps_dt(4)
+        W_got, G_got = s.get_factors(with_grad=True)
+        for a, b in zip(W_got, W_ref):
+            assert relerr(a, b) < FTOL[dtype], (schedule, relerr(a, b))
+        gn_ref = np.sqrt(sum(np.linalg.norm(g) ** 2 for g in G_ref))
+        assert abs(s.gradnorm() - gn_ref) < 1e-3 * gn_ref + 1e-9
+        s.close()
+    t.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("lens,R", [([600, 250, 12], 20), ([300, 500, 40], 20), ([520, 260, 150], 17)])
 def test_scan_with_a_partial_last_round(pp, ctx, lens, R):
     """A first-level scan of a little more than one round of resident workgroups (two n-tiles, fp32:
