@@ -16,12 +16,8 @@ tools/gpu_steps.sh \
  "${T}_ppbench|200|$B/pp_bench -model CP -tensor r -dim 4 -size 200 -rank 10 -maxiter 5 -prec 32 -filename gpurun_out/${T}_pp_bench_cp.csv" \
  "${T}_ppbench_tucker|300|$B/pp_bench -model Tucker -tensor r2 -dim 3 -size 400 -rank 20 -maxiter 5 -prec 32 -filename gpurun_out/${T}_pp_bench_tucker.csv" \
  "${T}_trace_p8|300|rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${T}_trace_p8 -o t -- python3 tools/shard_probe.py 200 10 8" \
- "${T}_shard_probe|300|python tools/shard_probe.py 200 10 1,8 && python tools/shard_probe.py 400 20 8" \
- "${T}_coil100|400|PPALS_PLACE_MIN_MB=1000 python bench.py --workload coil100 --steps 20 --warmup 3" \
- "${T}_timelapse|400|PPALS_PLACE_MIN_MB=1000 python bench.py --workload timelapse --steps 20 --warmup 3" \
- "${T}_place_ab|300|python tools/runs/place_ab.py 8 250" \
- "${T}_fuzz|1100|PPALS_FUZZ_CASES=1500 PPALS_FUZZ_SEED=6262626 python -m pytest tests/test_gpu_fuzz_campaign.py -x -q"
-for n in bench coil100 timelapse; do tail -1 gpurun_out/${T}_$n.log > gpurun_out/${T}_$n.json; done
+ "${T}_shard_probe|300|python tools/shard_probe.py 200 10 1,8 && python tools/shard_probe.py 400 20 8"
+for n in bench; do tail -1 gpurun_out/${T}_$n.log > gpurun_out/${T}_$n.json; done
 tail -1 gpurun_out/${T}_prof_bench.log | grep -o '{"metric.*' > gpurun_out/${T}_bench_under_rocprof.json
 f=$(find gpurun_out/${T}_prof_bench -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/${T}_bench_kernel_stats.csv
 f=$(find gpurun_out/${T}_prof_bench -name '*kernel_trace.csv' | head -1); python3 tools/trace_timed_launches.py gpurun_out/${T}_bench_under_rocprof.json "$f" > gpurun_out/${T}_timed_launches.txt 2>&1
