@@ -18,7 +18,7 @@ tools/gpu_steps.sh \
  "${T}_trace_p8|300|rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${T}_trace_p8 -o t -- python3 tools/shard_probe.py 200 10 8" \
  "${T}_shard_probe|300|python tools/shard_probe.py 200 10 1,8 && python tools/shard_probe.py 400 20 8"
 for n in bench; do tail -1 gpurun_out/${T}_$n.log > gpurun_out/${T}_$n.json; done
-tail -1 gpurun_out/${T}_prof_bench.log | grep -o '{"metric.*' > gpurun_out/${T}_bench_under_rocprof.json
+grep -a -o '{"metric.*' gpurun_out/${T}_prof_bench.log | tail -1 > gpurun_out/${T}_bench_under_rocprof.json
 f=$(find gpurun_out/${T}_prof_bench -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/${T}_bench_kernel_stats.csv
 f=$(find gpurun_out/${T}_prof_bench -name '*kernel_trace.csv' | head -1); python3 tools/trace_timed_launches.py gpurun_out/${T}_bench_under_rocprof.json "$f" > gpurun_out/${T}_timed_launches.txt 2>&1
 f=$(find gpurun_out/${T}_prof_cfg5 -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/${T}_cfg5_kernel_stats.csv
