@@ -1066,7 +1066,7 @@ void CpEngine::ms_start_step(int first) {
   ms_order_.clear();
   for (int q = k; q < N_; q++) ms_order_.push_back((first + q) % N_);
   for (auto &n : ms_nodes_) n.t.valid = false;
-  // X at this root's offset inside the over-allocated block (see engine.h, ms_X_off_); sized
+  // X at this root's offset inside the over-allocated block (see engine.h, PlaceExplore); sized
   // before the scan is planned (big_alloc may give a resident layout back)
   const size_t xbytes = ms_X_bytes(first, k);
   const size_t slack = ms_tune_enabled_ ? ms_X_slack() : 0;

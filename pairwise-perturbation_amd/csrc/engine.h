@@ -73,8 +73,8 @@ class CpEngine {
   void set_factors(const double *Wflat, const double *gradWflat);
   void set_schedule(int schedule);
   int schedule() const { return schedule_; }
-  // one JSON object: what the set-up's placement measurement chose for every root of the
-  // multi-sweep schedule (block, offset, store kind, fastest / slowest candidate), and its cost
+  // one JSON object: where the online placement choice put every root's first-level intermediate
+  // (block, offset, store kind, fastest / slowest sample, settled or still exploring)
   std::string placement_report() const;
   // operator builds of the PP phases (Build_mttkrp_map, als_CP.cxx:678-694): how many, and — while
   // timing is on (a stream synchronisation on both sides of a build) — how long they took

@@ -670,7 +670,7 @@ class HipOps : public Ops {
         // against 1.19-1.20 ms per launch for the same source and result buffers), and what reads
         // the result next streams it from HBM either way. Not on every pair of buffers, though: in one
         // process (r03q_place6_nt_same_process.txt) 1.21 -> 1.06 ms for some, +1 % for others — so
-        // the engine's placement tuner measures both kinds for the first-level intermediate
+        // the engine's online placement choice tries both kinds for the first-level intermediate
         // (scan_store_mode); this rule is for every other large result.
         constexpr double nt_min_bytes = 192.0 * 1048576.0;
         const bool nt_store =
