@@ -28,6 +28,7 @@ WORKLOADS = {
     "cp4_s400_r20": ([400, 400, 400, 400], 20),
     "cp4_s64_r10": ([64, 64, 64, 64], 10),  # smoke-sized
     "cp4_s12_r3": ([12, 12, 12, 12], 3),    # the CPU rehearsal of the N > 1 path (tests/test_bench_hostsim.py)
+    "cp4_s16_r3": ([16, 12, 12, 12], 3),    # the same for 8 ranks (2 rows of the leading mode each)
     # diagnostics (not BASELINE configs): which of size and rank costs cfg4 its 8 % against cfg2
     "cp4_s400_r10": ([400, 400, 400, 400], 10),
     "cp4_s200_r20": ([200, 200, 200, 200], 20),
@@ -530,7 +531,7 @@ def sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure
         return max_over_ranks(dt)
 
     # ---- configs[3]
-    lens4, R4 = ([12, 12, 12, 12], 3) if hostsim else WORKLOADS["cp4_s400_r20"]
+    lens4, R4 = ([16, 12, 12, 12], 3) if hostsim else WORKLOADS["cp4_s400_r20"]
     f32 = ppals.F64 if hostsim else ppals.F32
     try:
         V4 = ppals.Tensor(ctx, lens4, f32).fill_cp(ppals.init_factors(lens4, R4, 1000))
@@ -571,7 +572,7 @@ def sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure
         out["cfg4_sharded"] = {"error": str(e)}
 
     # ---- configs[4], N-GPU leg
-    lens5, ranks5, nsw = ([14, 12, 10], [3, 3, 3], 4) if hostsim else ([400, 400, 400], [20, 20, 20], 20)
+    lens5, ranks5, nsw = ([16, 12, 10], [3, 3, 3], 4) if hostsim else ([400, 400, 400], [20, 20, 20], 20)
     try:
         V5 = ppals.Tensor(ctx, lens5, f32).fill_uniform(7)
         tk = ppals.Tucker(ctx, V5, ranks5)

@@ -22,19 +22,20 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_multi_rank_path_on_the_host_stand_in(world):
     import hostsim_util
     hostsim_util.load()  # build once, before the ranks race for it
     port = free_port()
     procs = []
+    workload = "cp4_s12_r3" if world < 8 else "cp4_s16_r3"   # (8 ranks: 2 rows of the leading mode each)
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2" if world < 8 else "1",
                    PPALS_BENCH_BACKEND="hostsim")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
-             "--warmup", "1", "--workload", "cp4_s12_r3", "--dtype", "f64", "--no-cpu-baseline"],
+             "--warmup", "1", "--workload", workload, "--dtype", "f64", "--no-cpu-baseline"],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -71,7 +72,7 @@ def test_bench_multi_rank_path_on_the_host_stand_in(world):
     env = dict(os.environ, PPALS_BENCH_BACKEND="hostsim", OMP_NUM_THREADS="2")
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
-                          "--warmup", "1", "--workload", "cp4_s12_r3", "--dtype", "f64",
+                          "--warmup", "1", "--workload", workload, "--dtype", "f64",
                           "--no-cpu-baseline", "--no-config-records"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-3000:]
