@@ -104,6 +104,7 @@ class HipOps : public Ops {
     }
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
     if (const char *v = getenv("PPALS_SCAN_TAIL")) scan_tail_on_ = atoi(v) != 0;
+    if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));  // (probe: tools/runs/r05_m.sh)
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rmult_chol,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_jacobi_onesided,
@@ -659,7 +660,12 @@ class HipOps : public Ops {
     LAUNCH_SUFFIX_FAST_O(NTv, 1); \
   }
         // persistent launch: ncu*40 workgroups (measured best of 3..40 per CU), each walks over its tiles
-        dim3 grid_p((unsigned)std::min<int64_t>(nblocks, (int64_t)ncu_ * persist_mult_));
+        // (fewer tiles than that: every workgroup would take exactly ONE tile and the launch loses what the
+        // persistent form is for — the P = 8 shard of cfg2, 3906 tiles: 6 workgroups per CU walking 2.5
+        // tiles each scan it in 156.3 us instead of 159.6-161.0, profiles/r05m_persist_mult_shard.txt)
+        const int64_t pgrid = nblocks < (int64_t)ncu_ * persist_mult_ ? (int64_t)ncu_ * std::min(persist_mult_, 6)
+                                                                       : (int64_t)ncu_ * persist_mult_;
+        dim3 grid_p((unsigned)std::min<int64_t>(nblocks, pgrid));
 #define LAUNCH_SUFFIX_BUF_O(NTv, OPTv)                                                                \
   hipLaunchKernelGGL((k_scan_suffix_buf<TV, NTv, OPTv>), grid_p, dim3(256), 0, st_, V, M, K, M * K, P, \
                      n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, nblocks,  \
