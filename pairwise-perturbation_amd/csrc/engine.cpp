@@ -315,7 +315,6 @@ CpEngine::CpEngine(Ops &ops, Comm &comm, const TensorDesc &V, int R)
 // 0 = the reference's two-first-level-node tree (alsCP_DT), 1 = multi-sweep tree (default)
 void CpEngine::set_schedule(int schedule) {
   if (schedule != 0 && schedule != 1) throw std::runtime_error("ppals: unknown sweep schedule");
-  ms_prefetch_drop();
   schedule_ = (N_ < 3) ? 0 : schedule;
   for (auto &n : nodes_) n.valid = false;
   ms_invalidate();
@@ -323,7 +322,6 @@ void CpEngine::set_schedule(int schedule) {
 
 CpEngine::~CpEngine() {
   try {
-    ms_prefetch_drop();
     ops_.sync();
   } catch (...) {
   }
@@ -631,7 +629,6 @@ void CpEngine::refresh_grams() {
 }
 
 void CpEngine::set_factors(const double *Wflat, const double *gradWflat) {
-  ms_prefetch_drop();
   const double *w = Wflat, *g = gradWflat;
   double gs = 0, gsi[MAX_ORDER] = {0};
   for (int i = 0; i < N_; i++) {
@@ -795,7 +792,6 @@ unsigned CpEngine::ms_collect_scales(unsigned *masks, unsigned *fresh, int skip_
 }
 
 void CpEngine::normalize() {
-  ms_prefetch_drop();  // (the side lane reads a factor and X's pending scale: both change here)
   int64_t rows[MAX_ORDER];
   for (int i = 0; i < N_; i++) rows[i] = V_.glens[i];
   unsigned masks[32] = {0}, fresh = 0;
@@ -1065,7 +1061,6 @@ void *CpEngine::big_alloc(size_t bytes) {
 // tensor scan on whichever resident layout stores them next to each other and behind at least one
 // other mode; X is kept in the tensor's own precision
 void CpEngine::ms_start_step(int first) {
-  ms_prefetch_drop();
   const int k = ms_k_;
   ms_root_ = first;
   ms_order_.clear();
@@ -1196,9 +1191,6 @@ void CpEngine::ms_mode_update(int i, double lambda, bool last_of_sweep) {
   for (size_t q = 0; q < ms_order_.size(); q++)
     if (ms_order_[q] == i) pos = (int)q;
   const int leaf = ms_leaf_[pos];
-  // the next leaf's first contraction of X may start now, beside this update — unless the sweep's
-  // Normalize follows it (the side lane reads a factor and X's pending scale)
-  if (!last_of_sweep && i != N_ - 1) ms_prefetch_next(pos, i);
   // (S and S^-1 of this update depend on the other modes' Grams only: the contraction launched
   // next may prepare them on the side)
   ops_.arm_gram_system(G_, N_, i, R_, lambda, S_, Sinv_);
@@ -1219,54 +1211,6 @@ void CpEngine::ms_mode_update(int i, double lambda, bool last_of_sweep) {
   }
   mode_update(i, (const double *)ms_nodes_[leaf].t.buf, ext(i), lambda, false, 1.0);
   ms_nodes_[leaf].t.valid = false;  // a leaf is consumed by its own update
-}
-
-// While mode i (position `pos` of the step) is updated: the leaf of position pos + 1, when it hangs
-// directly under X and contracts at least two modes, needs X contracted with a mode OTHER than i first —
-// a factor that is final already. That contraction goes to the side lane now.
-void CpEngine::ms_prefetch_next(int pos, int i) {
-  if (!ops_.lanes() || ms_pre_.node >= 0 || !ms_X_.valid) return;
-  const int q = pos + 1;
-  if (q >= (int)ms_order_.size()) return;
-  const int idx = ms_leaf_[q];
-  MsNode &n = ms_nodes_[idx];
-  if (n.t.valid || n.parent >= 0) return;
-  std::vector<int> sib;
-  for (int p = n.slo; p <= n.shi; p++) sib.push_back(ms_order_[p]);
-  if (sib.size() < 2) return;
-  auto storage_pos = [&](int mode) {
-    for (size_t k = 0; k < ms_X_.modes.size(); k++)
-      if (ms_X_.modes[k] == mode) return (int)k;
-    return -1;
-  };
-  std::sort(sib.begin(), sib.end(), [&](int a, int b) { return storage_pos(a) > storage_pos(b); });
-  int m = -1;
-  for (int c : sib)
-    if (c != i) {
-      m = c;
-      break;
-    }
-  if (m < 0) return;
-  if (n.tmp.size() + 1 < sib.size()) n.tmp.resize(sib.size() - 1);
-  // (the buffer is sized on the main lane: a first-time allocation synchronises)
-  {
-    int64_t cnt = 1;
-    for (int mm : ms_X_.modes)
-      if (mm != m) cnt *= ext(mm);
-    ms_reserve(n.tmp[0], sizeof(double) * (size_t)cnt * R_);
-  }
-  ops_.lane_fork();
-  ms_contract(ms_X_, m, n.tmp[0], ms_scale_of(ms_X_));
-  ops_.lane_main();
-  ms_pre_.node = idx;
-  ms_pre_.mode = m;
-  ms_pre_.joined = false;
-}
-
-void CpEngine::ms_prefetch_drop() {
-  if (ms_pre_.node < 0) return;
-  if (!ms_pre_.joined) ops_.lane_join();
-  ms_pre_ = MsPrefetch();
 }
 
 // dst = src contracted with `mode` (rank index shared), fp64 result; in_scale = pending factor of
@@ -1311,19 +1255,7 @@ void CpEngine::ms_compute(int idx) {
   std::sort(sib.begin(), sib.end(), [&](int a, int b) { return storage_pos(a) > storage_pos(b); });
   if (n.tmp.size() + 1 < sib.size()) n.tmp.resize(sib.size() - 1);
   const RTensor *cur = src;
-  size_t k0 = 0;
-  if (ms_pre_.node == idx && n.parent < 0 && sib.size() >= 2) {
-    // tmp[0] = X contracted with ms_pre_.mode came from the side lane: that mode goes first, the main
-    // lane waits for it and goes on from there
-    if (!ms_pre_.joined) ops_.lane_join();
-    const auto it = std::find(sib.begin(), sib.end(), ms_pre_.mode);
-    if (it == sib.end()) throw std::runtime_error("ppals: internal error (prefetched mode not in the sibling set)");
-    std::rotate(sib.begin(), it, it + 1);
-    cur = &n.tmp[0];
-    k0 = 1;
-    ms_pre_ = MsPrefetch();
-  }
-  for (size_t k = k0; k < sib.size(); k++) {
+  for (size_t k = 0; k < sib.size(); k++) {
     RTensor &dst = (k + 1 == sib.size()) ? n.t : n.tmp[k];
     ms_contract(*cur, sib[k], dst, k == 0 ? ms_scale_of(*src) : nullptr);
     cur = &dst;

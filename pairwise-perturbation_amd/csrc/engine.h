@@ -182,16 +182,6 @@ class CpEngine {
   int ms_choose_roots();
   void ms_set_roots(int k);
   void ms_mode_update(int i, double lambda, bool last_of_sweep = false);
-  // The one independent piece of a step: while mode i is updated, the NEXT leaf's first
-  // contraction of X — with a mode other than i — runs on the back end's side lane (Ops::lane_*).
-  struct MsPrefetch {
-    int node = -1;   // ms_nodes_ index whose tmp[0] holds X contracted with `mode`
-    int mode = -1;
-    bool joined = false;
-  };
-  MsPrefetch ms_pre_;
-  void ms_prefetch_next(int pos, int i);
-  void ms_prefetch_drop();  // wait for a prefetch in flight and forget it
   bool ms_norm_fused_ = false;  // the sweep's Normalize went into its last update launch (Ops::arm_normalize)
   unsigned ms_collect_scales(unsigned *masks, unsigned *fresh, int skip_node);
   RTensor ms_X_;

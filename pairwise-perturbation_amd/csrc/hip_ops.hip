@@ -69,25 +69,7 @@ class HipOps : public Ops {
       throw std::runtime_error("ppals: device index out of range");
     dev_ = device;
     HIP_CHECK(hipSetDevice(dev_));
-    // PPALS_LANES=0: no side lane; PPALS_LANE_CUS=n (A/B): the side lane on the first n CU-mask bits (bit i =
-    // CU i / 8 of XCC i mod 8: n / 8 CUs of every XCD), the main lane on the complement
-    if (const char *v = getenv("PPALS_LANES")) lanes_on_ = atoi(v) != 0;
-    if (const char *v = getenv("PPALS_LANE_CUS")) lane_cus_ = std::max(0, std::min(atoi(v), ncu_ / 2));
-    if (lanes_on_ && lane_cus_ > 0) {
-      const int words = (ncu_ + 31) / 32;
-      std::vector<uint32_t> mside(words, 0), mmain(words, 0);
-      for (int b = 0; b < ncu_; b++) (b < lane_cus_ ? mside : mmain)[b / 32] |= 1u << (b % 32);
-      if (hipExtStreamCreateWithCUMask(&st_, words, mmain.data()) != hipSuccess ||
-          hipExtStreamCreateWithCUMask(&st_side_, words, mside.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        if (st_) hipStreamDestroy(st_);
-        if (st_side_) hipStreamDestroy(st_side_);
-        st_ = st_side_ = nullptr;
-        lane_cus_ = 0;
-      }
-    }
-    if (!st_) HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-    st_main_ = st_;
+    HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, dev_));
     ncu_ = prop.multiProcessorCount;
@@ -134,7 +116,6 @@ class HipOps : public Ops {
   }
   ~HipOps() override {
     hipSetDevice(dev_);
-    st_ = st_main_;
     hipStreamSynchronize(st_);
     if (st2_) hipStreamSynchronize(st2_);  // (checks of deferred steps still read the slots' buffers)
     for (auto &ev : events_) {
@@ -145,11 +126,7 @@ class HipOps : public Ops {
       hipEventDestroy(t.a);
       hipEventDestroy(t.b);
     }
-    if (st_side_) hipStreamSynchronize(st_side_);
-    if (ws_mttv_[0]) hipFree(ws_mttv_[0]);
-    if (ws_mttv_[1]) hipFree(ws_mttv_[1]);
-    if (ev_fork_) hipEventDestroy(ev_fork_);
-    if (ev_join_) hipEventDestroy(ev_join_);
+    if (ws_mttv_) hipFree(ws_mttv_);
     if (ws_pack_) hipFree(ws_pack_);
     if (ws_slab_) hipFree(ws_slab_);
     if (ws_krp_) hipFree(ws_krp_);
@@ -173,8 +150,7 @@ class HipOps : public Ops {
       if (kv.second.Q) hipFree(kv.second.Q);
     if (st2_) hipStreamDestroy(st2_);
     if (handover_) hipFree(handover_);
-    if (st_side_) hipStreamDestroy(st_side_);
-    hipStreamDestroy(st_main_);
+    hipStreamDestroy(st_);
   }
 
   void *alloc(size_t bytes) override {
@@ -185,8 +161,7 @@ class HipOps : public Ops {
   }
   void free(void *p) override {
     if (p) {
-      hipStreamSynchronize(st_main_);
-      if (st_side_) hipStreamSynchronize(st_side_);
+      hipStreamSynchronize(st_);
       hipFree(p);
     }
   }
@@ -202,34 +177,8 @@ class HipOps : public Ops {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st_));
   }
   void zero(void *p, size_t bytes) override { HIP_CHECK(hipMemsetAsync(p, 0, bytes, st_)); }
-  void sync() override {
-    HIP_CHECK(hipStreamSynchronize(st_main_));
-    if (st_side_) HIP_CHECK(hipStreamSynchronize(st_side_));
-  }
+  void sync() override { HIP_CHECK(hipStreamSynchronize(st_)); }
   void *stream() override { return (void *)st_; }
-  // ---- lanes (ops.h): the side lane is a second stream; events order it against the main one
-  bool lanes() override { return lanes_on_; }
-  void lane_fork() override {
-    if (!lanes_on_) return;
-    if (!st_side_) HIP_CHECK(hipStreamCreateWithFlags(&st_side_, hipStreamNonBlocking));
-    if (!ev_fork_) {
-      HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
-    HIP_CHECK(hipEventRecord(ev_fork_, st_main_));
-    HIP_CHECK(hipStreamWaitEvent(st_side_, ev_fork_, 0));
-    st_ = st_side_;
-    lane_ = 1;
-  }
-  void lane_main() override {
-    st_ = st_main_;
-    lane_ = 0;
-  }
-  void lane_join() override {
-    if (!lanes_on_ || !st_side_) return;
-    HIP_CHECK(hipEventRecord(ev_join_, st_side_));
-    HIP_CHECK(hipStreamWaitEvent(st_main_, ev_join_, 0));
-  }
   void bind() override { HIP_CHECK(hipSetDevice(dev_)); }
 
   // ------------------------------------------------------------------ generation / norms
@@ -982,7 +931,7 @@ class HipOps : public Ops {
       if (jsplit > 1) {
         const int64_t jchunk = (J + jsplit - 1) / jsplit;
         jsplit = (int)((J + jchunk - 1) / jchunk);
-        double *partial = (double *)ensure(ws_mttv_[lane_], ws_mttv_sz_[lane_], sizeof(double) * (size_t)jsplit * L * T * R);
+        double *partial = (double *)ensure(ws_mttv_, ws_mttv_sz_, sizeof(double) * (size_t)jsplit * L * T * R);
         const int64_t nbs = nb * jsplit;
         int g = (int)std::min<int64_t>(nbs, 32768);
         hipLaunchKernelGGL((k_mttv_l<TX, 4>), dim3(g + extra), dim3(256), lds, st_, X, L, J, T, R, B, ldb,
@@ -2978,12 +2927,8 @@ class HipOps : public Ops {
   size_t ws_eig_sz_ = 0, ws_orth_sz_ = 0, ws_pow_sz_ = 0, ws_part2_sz_ = 0;
   hipStream_t st_ = nullptr;
   hipStream_t st2_ = nullptr;  // the Jacobi of a lazy eigen-step (created on first use)
-  void *ws_mttv_[2] = {nullptr, nullptr};  // partial sums of a j-split k_mttv_l, one per lane
-  size_t ws_mttv_sz_[2] = {0, 0};
-  bool lanes_on_ = true;
-  int lane_ = 0, lane_cus_ = 0;
-  hipStream_t st_main_ = nullptr, st_side_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  void *ws_mttv_ = nullptr;  // partial sums of a j-split k_mttv_l
+  size_t ws_mttv_sz_ = 0;
   void *ws_pack_ = nullptr, *ws_slab_ = nullptr, *ws_krp_ = nullptr, *ws_part_ = nullptr,
        *ws_small_ = nullptr, *ws_big_ = nullptr, *ws_big2_ = nullptr;
   size_t ws_pack_sz_ = 0, ws_slab_sz_ = 0, ws_krp_sz_ = 0, ws_part_sz_ = 0, ws_small_sz_ = 0,

@@ -348,17 +348,6 @@ class Ops {
   virtual void sign_align(double *W, const double *Wref, int64_t rows, int r) = 0;
 
 
-  // ---- a second lane (the one piece of a multi-sweep step that is independent of the mode update in
-  // flight: the next leaf's first contraction of X) ----
-  // lanes(): the back end has one. lane_fork(): everything issued from now on goes to the SIDE lane,
-  // which first waits for all that has been issued on the main lane so far. lane_main(): back to the
-  // main lane (no synchronisation). lane_join(): the main lane waits for all that has been issued on
-  // the side lane. A back end without lanes runs everything in issue order (a valid schedule).
-  virtual bool lanes() { return false; }
-  virtual void lane_fork() {}
-  virtual void lane_main() {}
-  virtual void lane_join() {}
-
   // A stopwatch on the launch stream (the online placement choice of the multi-sweep schedule):
   // timer_begin() marks the stream and returns a handle (-1: no stopwatch to be had), timer_end(h)
   // marks it again, timer_read(h) returns the seconds between the two marks once both have been

@@ -83,13 +83,7 @@ class HostOps : public Ops {
   HostOps() {
     if (const char *e = std::getenv("PPALS_HOSTSIM_DEFER")) sim_defer_ = std::atoi(e);
     if (const char *e = std::getenv("PPALS_HOSTSIM_DEFER_FAIL")) sim_fail_every_ = std::atoi(e);
-    if (const char *e = std::getenv("PPALS_LANES")) sim_lanes_ = std::atoi(e) != 0;
   }
-  // the side lane of the multi-sweep step: here everything runs in issue order (a valid schedule), the
-  // engine's bookkeeping — which contraction is issued early, in which order a leaf's modes go — is
-  // the same as on the device
-  bool lanes() override { return sim_lanes_; }
-  bool sim_lanes_ = true;
   void *alloc(size_t bytes) override { return std::calloc(1, bytes ? bytes : 8); }
   void free(void *p) override { std::free(p); }
   void h2d(void *d, const void *s, size_t n) override { std::memcpy(d, s, n); }
