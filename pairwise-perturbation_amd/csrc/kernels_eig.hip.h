@@ -564,10 +564,19 @@ __global__ __launch_bounds__(256) void k_unfold_syrk_f32(const float *__restrict
   const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
   const bool p_fast = (L == 1);
   f64x4 acc[2][2];
+  // which of the wave's four 16 x 16 sub-tiles are worth the matrix cores (wave-uniform): not those
+  // past the edge (J = 400: the seventh tile of 64 holds 16 rows) and, in a tile on the diagonal, not
+  // those strictly below it — they are the mirror images of the ones above, written from there. At
+  // J = 400: 325 sub-tiles instead of 448 (the other waves of a SIMD get the pipe meanwhile).
+  bool use[2][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 2; b++) {
+      acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+      const int64_t r0 = p0 + wi + 16 * a, c0 = q0 + wj + 16 * b;
+      use[a][b] = r0 < J && c0 < J && (!diag || c0 >= r0);
+    }
   // per-thread slice of a 64 x 32 panel: p-fast: rows pq..pq+3 of columns cc, cc + 16;
   // c-fast: row pp, columns cq..cq+7
   const int pq = (tid & 15) * 4, cc = tid >> 4;
@@ -628,10 +637,10 @@ __global__ __launch_bounds__(256) void k_unfold_syrk_f32(const float *__restrict
     for (int ks = 0; ks < KC / 4; ks++) {
       const double a0 = As[4 * ks + g][wi + l16], a1 = As[4 * ks + g][wi + 16 + l16];
       const double b0 = Bp[4 * ks + g][wj + l16], b1 = Bp[4 * ks + g][wj + 16 + l16];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      if (use[0][0]) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      if (use[0][1]) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      if (use[1][0]) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      if (use[1][1]) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
   double *gs = slab + (int64_t)blockIdx.z * J * J;
@@ -640,13 +649,15 @@ __global__ __launch_bounds__(256) void k_unfold_syrk_f32(const float *__restrict
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       const int64_t q = q0 + wj + 16 * b + l16;  // D: lane holds column l16, rows g + 4 r
-      if (q < J) {
+      // (a sub-tile ON the diagonal holds both of its triangles; every other one is mirrored)
+      const bool mirror = !diag || (q0 + wj + 16 * b) > (p0 + wi + 16 * a);
+      if (use[a][b] && q < J) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int64_t pr = p0 + wi + 16 * a + g + 4 * r;
           if (pr < J) {
             gs[pr + J * q] = acc[a][b][r];
-            if (!diag) gs[q + J * pr] = acc[a][b][r];
+            if (mirror) gs[q + J * pr] = acc[a][b][r];
           }
         }
       }
