@@ -71,7 +71,7 @@ def lib(path=None):
         _lib.ppals_version.restype = C.c_char_p
         # the product binding only ever drives the HIP build; the host stand-in of tests/hostsim is
         # reachable solely through tests/hostsim_util.py, which loads this file under another name
-        if __name__ == "ppals" and b"hostsim" in _lib.ppals_version():
+        if __name__ == "ppals" and b"TEST INFRASTRUCTURE" in _lib.ppals_version():
             _lib = None
             raise PpalsError(f"{p} is the test stand-in, not the HIP engine (no CPU fallback)")
     return _lib
