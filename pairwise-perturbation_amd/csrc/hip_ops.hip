@@ -104,6 +104,7 @@ class HipOps : public Ops {
     }
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
     if (const char *v = getenv("PPALS_SCAN_TAIL")) scan_tail_on_ = atoi(v) != 0;
+    if (const char *v = getenv("PPALS_SCAN_WIDE")) wide_enabled_ = atoi(v) != 0;
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));  // (probe: tools/runs/r05_m.sh)
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rmult_chol,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -532,7 +533,19 @@ class HipOps : public Ops {
     if (pad.ld && (L % pad.ld || pad.ld % VEC || pad.valid > pad.ld || pad.valid <= 0 || L == 1))
       throw std::runtime_error("ppals: scan_contract padded rows inconsistent");
     const bool aligned_base = (((uintptr_t)V) & 15) == 0;
-    for (int col0 = 0; col0 < R; col0 += 64) {
+    // 65..128 columns of an fp32 tensor in ONE pass (k_scan_wide: MFMA-bound regime, the tensor tile
+    // staged through LDS); whatever is left after whole passes of 128 goes the narrow way
+    const bool wide_ok = sizeof(TV) == 4 && wide_enabled_ && L > 1 && aligned_base && (L % 4 == 0) &&
+                         L >= 4 && (double)L * J * T >= 1.0e6;
+    int col_step = 64;
+    for (int col0 = 0; col0 < R; col0 += col_step) {
+      if (wide_ok && R - col0 > 64) {
+        col_step = std::min(128, R - col0);
+        if constexpr (sizeof(TV) == 4)
+          scan_wide((const float *)V, L, J, T, a, col0, col_step, out, out_tstride, out_rstride, out32, pad);
+        continue;
+      }
+      col_step = 64;
       const int ncols = std::min(64, R - col0);
       // n-tiles of 16 result columns: 3 for 33..48 columns (ranks such as 40, or the second
       // launch of R = 100 = 64 + 36) instead of padding them to 64 — these scans are MFMA-bound
@@ -771,6 +784,94 @@ class HipOps : public Ops {
       }
     }
   }
+  // One pass of the wide kernel over columns [col0, col0 + ncols), 64 < ncols <= 128 (fp32 tensor,
+  // suffix / batched form): pack, launch, combine the k-splits.
+  void scan_wide(const float *V, int64_t L, int64_t J, int64_t T, const KrpArgs &a, int col0, int ncols,
+                 double *out, int64_t out_tstride, int64_t out_rstride, int out32, RowPad pad) {
+    const int NT = (ncols + 15) / 16;
+    const int64_t nblk64 = (J + 15) / 16;
+    if (nblk64 > 0x7fffffff) throw std::runtime_error("ppals: contraction extent too large");
+    const int nblk = (int)nblk64;
+    const size_t pack_bytes = (size_t)nblk * NT * 256 * sizeof(float);
+    float *P = (float *)ensure(ws_pack_, ws_pack_sz_, pack_bytes);
+    hipLaunchKernelGGL(k_krp_pack<float>, dim3(grid_for((int64_t)nblk * NT * 256, 256)), dim3(256), 0, st_,
+                       P, nblk, NT, 0, a, J, col0, ncols);
+    HIP_CHECK(hipGetLastError());
+    double *o = out32 ? (double *)((float *)out + (int64_t)col0 * out_rstride)
+                      : out + (int64_t)col0 * out_rstride;
+    const int64_t M = L, K = J;
+    const int64_t n_mtiles64 = (M + 63) / 64;
+    if (n_mtiles64 * T > 0x7fffffff) throw std::runtime_error("ppals: scan grid too large");
+    const int n_mtiles = (int)n_mtiles64;
+    // k-split: the launch is MFMA-bound, so what counts is how evenly its workgroups fill the resident
+    // slots (a partial last round idles the matrix cores): take the split whose number of rounds is
+    // closest below a whole number, a little in favour of fewer splits (slab traffic, the combine)
+    int &occ = wide_occ_[NT - 5];
+    if (occ == 0) {
+      int nb = 0;
+      hipError_t e = hipErrorUnknown;
+      switch (NT) {
+        case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_wide<5, 1>, 512, 0); break;
+        case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_wide<6, 1>, 512, 0); break;
+        case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_wide<7, 1>, 512, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_scan_wide<8, 1>, 512, 0); break;
+      }
+      if (e != hipSuccess) (void)hipGetLastError();
+      occ = (e == hipSuccess && nb > 0) ? nb : 2;
+    }
+    const double slots = (double)ncu_ * occ;
+    const int64_t tiles = n_mtiles64 * T;
+    int nsplit = 1;
+    if ((double)tiles < 8.0 * slots) {
+      double best = -1.0;
+      const int ns_max = (int)std::min<int64_t>(24, std::max(1, nblk / 16));
+      for (int ns = 1; ns <= ns_max; ns++) {
+        const double rounds = (double)tiles * ns / slots;
+        const double score = rounds / std::ceil(rounds) - 0.004 * ns;
+        if (score > best) {
+          best = score;
+          nsplit = ns;
+        }
+      }
+    }
+    const int per = (nblk + nsplit - 1) / nsplit;
+    nsplit = (nblk + per - 1) / per;
+    double *dst = o;
+    int dst32 = out32;
+    int64_t dst_ns = out_rstride, dst_ss = 0, dst_bs = out_tstride;
+    if (nsplit > 1) {
+      dst32 = 0;
+      dst = (double *)ensure(ws_slab_, ws_slab_sz_, sizeof(double) * nsplit * ncols * M * T);
+      dst_ns = M;
+      dst_ss = (int64_t)ncols * M * T;
+      dst_bs = (int64_t)ncols * M;
+    }
+    const int64_t nblocks = (int64_t)n_mtiles * nsplit * T;
+    if (nblocks > 0x7fffffff) throw std::runtime_error("ppals: scan grid too large");
+    const int64_t k_ld = nsplit > 1 ? 0 : pad.ld, k_valid = nsplit > 1 ? 0 : pad.valid;
+    const double bytes = (double)L * (double)J * (double)T * 4.0 + (double)L * (double)T * ncols * (out32 ? 4.0 : 8.0);
+    prof_begin(0, bytes);
+#define LAUNCH_WIDE(NTv)                                                                                  \
+  hipLaunchKernelGGL((k_scan_wide<NTv, 1>), dim3((unsigned)nblocks), dim3(512), 0, st_, V, M, K, M * K, P, \
+                     n_mtiles, nsplit, per, nblk, dst, dst_ns, dst_ss, dst_bs, ncols, dst32, k_ld, k_valid)
+    switch (NT) {
+      case 5: LAUNCH_WIDE(5); break;
+      case 6: LAUNCH_WIDE(6); break;
+      case 7: LAUNCH_WIDE(7); break;
+      default: LAUNCH_WIDE(8); break;
+    }
+#undef LAUNCH_WIDE
+    prof_end();
+    HIP_CHECK(hipGetLastError());
+    if (nsplit > 1) {
+      hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(M * ncols, 256), (unsigned)T), dim3(256), 0, st_, dst,
+                         nsplit, dst_ss, M, ncols, o, (int64_t)1, out_rstride, out32, pad.ld, pad.valid,
+                         dst_bs, out_tstride);
+      HIP_CHECK(hipGetLastError());
+    }
+  }
+  bool wide_enabled_ = true;  // PPALS_SCAN_WIDE=0: chunks of 64 columns (A/B, tests)
+  int wide_occ_[4] = {0, 0, 0, 0};  // resident workgroups per CU of k_scan_wide<5..8>
   // Where the tail mode of k_scan_suffix_fast starts (first tile of the last, partial round of resident
   // workgroups), or -1: the launch fits one round, has many rounds (the tail is a small share), or its
   // last round is nearly full anyway. Resident workgroups per CU from the runtime's occupancy query

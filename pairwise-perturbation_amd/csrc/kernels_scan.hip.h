@@ -757,6 +757,193 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
 #undef PPALS_BUF_LOAD
 }
 
+// ---------------------------------------------------------------------------------------------
+// WIDE suffix scan: 65..128 result columns in ONE pass over the tensor (fp32 storage).
+//
+// Above 64 columns the scan is no longer HBM-bound: AI = 2R/4 >= 32 flop/B is past the fp32
+// matrix-core ridge (157 TFLOP/s / 8 TB/s = 20), so the tensor must be read ONCE for all columns —
+// the narrow kernels above would run one launch per 64 columns, each re-reading it — and what
+// bounds the launch is the MFMA pipe. One lane cannot hold 8 n-tiles of accumulators for 4 rows
+// (128 fp32 + 256 fp64 registers), so the rows a wave owns shrink and the tensor tile goes through
+// LDS: a workgroup (8 waves, 2 x 4) owns 64 rows x all NT n-tiles; per 16-column k-block it copies
+// the 64 x 16 tensor tile (16-byte loads, 256 B contiguous per column) and the NT packed Khatri-Rao
+// tiles (the same packing as the narrow kernels: one ds_read_b128 per lane = the A operands of four
+// MFMAs) into LDS, two k-blocks per barrier, double-buffered; wave (wm, wn) multiplies rows
+// [32 wm, 32 wm + 32) by n-tiles 2 wn, 2 wn + 1: four accumulator tiles (16 fp32 + 32 fp64
+// registers), so that FOUR waves share a SIMD: one wave's fp32 -> fp64 flush, barrier or LDS wait is
+// covered by the others' matrix work (measured on the 4-wave form, profiles/r06f: the flush cost 10 %,
+// barrier + staging 11 %, the loads 7 % of a launch whose bare LDS + MFMA loop runs at 0.90 of the
+// fp32 matrix-core peak). Same numerics as the narrow kernels: exact fp32 products on
+// v_mfma_f32_16x16x4_f32, chains of <= 64 terms, fp64 beyond.
+// Preconditions (launcher): M % 4 == 0, M >= 4, V 16-byte aligned, 5 <= NT <= 8.
+template <int NT, int OPT = 0>
+__global__ __launch_bounds__(512) void k_scan_wide(
+    const float *__restrict__ V, int64_t M, int64_t K, int64_t batch_stride,
+    const float *__restrict__ P, int n_mtiles, int nsplit, int kb_per_split, int nkb,
+    double *__restrict__ out, int64_t out_nstride, int64_t out_split_stride,
+    int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0) {
+  constexpr int BM = 64, BK = 16;  // BK: one k-block = 16 columns = four k-quads
+  constexpr int PITCH = BM + 16;   // floats; k rows 4q+g of one quad land in distinct bank groups
+  constexpr int NTA = 2;  // n-tiles per wave
+  // a STAGE = two k-blocks (32 MFMAs per wave between barriers); LDS: two stage buffers
+  constexpr int VSZ = BK * PITCH, PSZ = 512 * 4;  // floats per k-block (512 items: both loader items
+                                                  // of every thread land inside the block's image)
+  __shared__ __attribute__((aligned(16))) float Vs[2][2 * VSZ];
+  __shared__ __attribute__((aligned(16))) float Ps[2][2 * PSZ];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: descriptors and branches below)
+  const int g = lane >> 4, j16 = lane & 15;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int nt0 = 2 * wn, ntc = max(0, min(NTA, NT - nt0));  // (NT = 7: 2, 2, 2, 1 tiles)
+
+  unsigned b = blockIdx.x;
+  const int mtile = (int)(b % (unsigned)n_mtiles);
+  b /= (unsigned)n_mtiles;
+  const int split = (int)(b % (unsigned)nsplit);
+  const int64_t batch = b / (unsigned)nsplit;
+  const int64_t m0 = (int64_t)mtile * BM;
+  const int kb0 = split * kb_per_split;
+  const int kb1 = min(nkb, kb0 + kb_per_split);
+  const int nb = kb1 - kb0;
+  if (nb <= 0) return;  // (workgroup-uniform; the launcher makes no empty split)
+  const int nstages = (nb + 1) >> 1;
+
+  // loader roles, per stage: tensor tile — thread (mq = tid & 15, kk = (tid >> 4) & 15, hv = tid >> 8)
+  // copies rows 4mq..4mq+3 of column kk of k-block hv; Khatri-Rao tiles — float4 item tid of the 512
+  // item slots of each of the two k-blocks (NT * 64 of them are real).
+  // BUFFER loads (wave-uniform descriptor + loop-invariant lane offset + scalar offset, as in
+  // k_scan_suffix_buf): no address temporaries in VGPRs, so nothing aliases a register that a load
+  // still in flight will write, and every load is unconditional, so the compiler's COUNTED vmcnt
+  // waits keep the ring in flight. A block's descriptor ends at the last valid k column (the ragged
+  // tail reads zeros in hardware) and has no records at all past the split's last block.
+  const int mq = tid & 15, kk = (tid >> 4) & 15, hv = wave >> 2;
+  const int64_t m_ld = min(m0 + 4 * mq, M - 4);  // clamped: rows past the edge re-read the last ones
+  const char *__restrict__ vbase = (const char *)(V + batch * batch_stride);
+  const int voffV = (int)(((int64_t)kk * M + m_ld) * 4);
+  const int64_t block_bytes = (int64_t)BK * M * 4, total_bytes = K * M * 4;
+  const int voffP = tid * 16;
+  const int vdst = hv * VSZ + kk * PITCH + 4 * mq;
+  const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)P, 0, (int)((int64_t)nkb * NT * 1024), 0x00020000);
+  constexpr int AUXV = (OPT & 1) ? 2 : 0;  // nt: streamed once
+
+  // register ring: two slot sets of one stage each. Stage j + 2 is requested at the top of stage j
+  // (into the set stage j vacated when it went to LDS) and written to LDS at the end of stage j + 1:
+  // two stages = ~1.7 us of matrix work between a request and its use (HBM latency under load ~2 us).
+  f32x4 gv[2], gp[2][2];
+#define PPALS_WIDE_LOAD(set_, st_)                                                                     \
+  {                                                                                                    \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                 \
+      const int kb_ = kb0 + min(2 * (st_) + h_, nb - 1);                                               \
+      gp[set_][h_] = __builtin_bit_cast(                                                               \
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcP, voffP, kb_ * (NT * 1024), 0));           \
+    }                                                                                                  \
+    const int i_ = 2 * (st_) + hv;             /* block of the split; past its end: no records */      \
+    const int64_t boff_ = (int64_t)(kb0 + min(i_, nb - 1)) * block_bytes;                              \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
+        (void *)(vbase + boff_), 0, i_ < nb ? (int)min(total_bytes - boff_, block_bytes) : 0,          \
+        0x00020000);                                                                                   \
+    gv[set_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, voffV, 0, AUXV));  \
+  }
+#define PPALS_WIDE_STAGE(set_, buf_)                                                         \
+  {                                                                                          \
+    *reinterpret_cast<f32x4 *>(&Vs[buf_][vdst]) = gv[set_];                                  \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++)                                         \
+        *reinterpret_cast<f32x4 *>(&Ps[buf_][h_ * PSZ + 4 * tid]) = gp[set_][h_];            \
+  }
+
+  f32x4 acc[2][NTA];
+  double acc64[2][NTA][4];
+#pragma unroll
+  for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+    for (int i = 0; i < NTA; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        acc[ms][i][r] = 0;
+        acc64[ms][i][r] = 0;
+      }
+
+  PPALS_WIDE_LOAD(0, 0);
+  PPALS_WIDE_LOAD(1, min(1, nstages - 1));
+  PPALS_WIDE_STAGE(0, 0);
+  __syncthreads();
+  // two stages (= 4 k-blocks = chains of 64 terms) per trip: slot sets and LDS buffers are
+  // compile-time constants; fp32 -> fp64 after each trip
+  for (int j0 = 0; j0 < nstages; j0 += 2) {
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++) {
+      const int j = j0 + sp;
+      if (j < nstages) {  // workgroup-uniform
+        // the slot set of stage j went to LDS one stage ago: refill it with stage j + 2 (past the
+        // split's last stage: that stage again, harmless)
+        PPALS_WIDE_LOAD(sp, min(j + 2, nstages - 1));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          // B operands: tensor values of this wave's two 16-row strips, four k-quads
+          float vb[2][4];
+          const float *vs = &Vs[sp][h * VSZ + g * PITCH + 32 * wm + j16];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int ms = 0; ms < 2; ms++) vb[ms][q] = vs[4 * q * PITCH + 16 * ms];
+          // A operands of all this wave's n-tiles first, then k-quad by k-quad over the 2 * ntc
+          // accumulator tiles: consecutive MFMAs never touch the same accumulator
+          f32x4 pa[NTA];
+#pragma unroll
+          for (int t = 0; t < NTA; t++)
+            pa[t] = *reinterpret_cast<const f32x4 *>(
+                &Ps[sp][h * PSZ + (min(nt0 + t, NT - 1) * 64 + lane) * 4]);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < NTA; t++) {
+              if (t >= ntc) break;  // wave-uniform (the last column group of an odd NT)
+#pragma unroll
+              for (int ms = 0; ms < 2; ms++)
+                acc[ms][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][q], vb[ms][q], acc[ms][t], 0, 0, 0);
+            }
+        }
+        // stage j + 1 (requested two stages ago) -> the other LDS buffer
+        PPALS_WIDE_STAGE(sp ^ 1, sp ^ 1);
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+      for (int t = 0; t < NTA; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          acc64[ms][t][r] += (double)acc[ms][t][r];
+          acc[ms][t][r] = 0;
+        }
+  }
+#undef PPALS_WIDE_LOAD
+#undef PPALS_WIDE_STAGE
+
+  // epilogue: lane (j16, g) holds row m of strip ms and columns 16 nt + 4 g + r
+  const int64_t obase = split * out_split_stride + batch * out_batch_stride;
+#pragma unroll
+  for (int ms = 0; ms < 2; ms++) {
+    const int64_t m = m0 + 32 * wm + 16 * ms + j16;
+    const ScanRowMap rm = scan_row_map<1>(m, M, row_ld, row_valid);
+    if (rm.nvalid == 0) continue;
+#pragma unroll
+    for (int i = 0; i < NTA; i++) {
+      if (i >= ntc) break;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = 16 * (nt0 + i) + 4 * g + r;
+        if (n < ncols)
+          scan_store(out, obase + (int64_t)n * out_nstride + rm.mo,
+                     acc64[ms][i][r] + (double)acc[ms][i][r], out32);
+      }
+    }
+  }
+}
+
 template <typename TV, int NT, int OPT = 0>
 __global__ __launch_bounds__(256) void k_scan_prefix_fast(
     const TV *__restrict__ V, int64_t M, int64_t K, const TV *__restrict__ P, int mb_per_split,

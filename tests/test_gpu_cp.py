@@ -1096,3 +1096,85 @@ def _low_rank_case(pp, ctx, lens, R, dtype, ur, kind, tmp_path, randomsvd):
         s.cpd_als_lr(kind, ur, 2, maxiter=2)
     s.close()
     t.close()
+
+
+WIDE_SHAPES = [([64, 40, 36, 32], 100),   # the reference CLI's default rank regime (-rank s/2)
+               ([68, 36, 30, 28], 65),    # rows not a multiple of the 64-row tile, 5 n-tiles (one column in the 5th)
+               ([72, 44, 40, 24], 70),    # the coil-100 Tucker rank (test_ALS.cxx:366-379) as a CP rank
+               ([64, 48, 32, 36], 128),   # 8 full n-tiles
+               ([60, 40, 36, 32], 130),   # one wide pass + a narrow remainder of 2 columns
+               ([128, 96, 80], 112),      # order 3
+               ([48, 40, 36, 32], 200)]   # two wide passes (128 + 72)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("lens,R", WIDE_SHAPES)
+def test_wide_scan_one_pass(pp, lens, R, dtype, monkeypatch):
+    """More than 64 result columns (common.cxx:56,83 with the reference's default -rank s/2): the
+    fp32 tensor is read ONCE for up to 128 columns (k_scan_wide, tensor tile through LDS). Every
+    first-level tree node (suffix form), every MTTKRP and exact sweeps under both schedules (the
+    batched single-mode form) against the oracle; fp64 storage takes the 64-column chunks."""
+    V, W = problem(lens, R, 3, kind="r")
+    G = O.init_factors(lens, R, 3003)
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, dtype).upload(V)
+    s = pp.CP(c2, t, R)
+    s.set_factors(W, G)
+    N = len(lens)
+    for key, info in O.dimension_tree(N).items():
+        if len(info["parent"]) != N or len(key) == 1:
+            continue
+        e = relerr(s.tree_node(key), O.tree_node(V, W, key).ravel(order="F"))
+        assert e < KTOL[dtype], (key, e)
+    if dtype == 0 and N == 4:
+        # alsCP_DT's sweep: two first-level nodes, ONE tensor pass per 128 columns each
+        s.set_schedule("dt")
+        c2.profile_enable(1)
+        c2.profile_reset()
+        s.sweeps_dt(1)
+        c2.sync()
+        n_first, _, _ = c2.profile_read(0)
+        c2.profile_enable(0)
+        assert n_first == 2 * -(-R // 128), n_first
+        s.set_factors(W, G)
+    for mode in range(N):
+        e = relerr(s.mttkrp(mode), O.mttkrp(V, W, mode, 0))
+        assert e < KTOL[dtype], (mode, e)
+    _, _, W_ref, G_ref = O.als_cp_dt(V, W, G, tol=0.0, maxiter=1, resprint=1000)
+    for schedule in ("msdt", "dt"):
+        s.set_schedule(schedule)
+        s.set_factors(W, G)
+        s.sweeps_dt(2)
+        W_got, G_got = s.get_factors(with_grad=True)
+        cond = max(np.linalg.cond(np.prod([w.T @ w for j, w in enumerate(W_ref) if j != i], axis=0))
+                   for i in range(N))
+        bar = (1e-8 if dtype == 1 else 1e-5) + (1e-15 if dtype == 1 else 3e-8) * cond
+        for a, b in zip(W_got, W_ref):
+            assert relerr(a, b) < bar, (schedule, relerr(a, b), cond)
+    s.close()
+    t.close()
+    c2.close()
+
+
+def test_wide_scan_padded_layout_and_switch(pp, monkeypatch):
+    """the wide scan on a padded resident layout (rows compacted as they are stored) and its A/B
+    switch: PPALS_SCAN_WIDE=0 runs the 64-column chunks — both against the oracle, and against
+    each other at rounding level"""
+    lens, R = [50, 36, 50, 36], 80      # 50 * 4 B is no multiple of 128 B: padded leading blocks
+    V, W = problem(lens, R, 5, kind="r")
+    got = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PPALS_SCAN_WIDE", wide)
+        monkeypatch.setenv("PPALS_PAD_LAYOUT", "1")
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, 0).upload(V)
+        s = pp.CP(c2, t, R)
+        s.set_factors(W)
+        got[wide] = [s.mttkrp(m) for m in range(4)] + [s.tree_node("ab"), s.tree_node("cd")]
+        for m in range(4):
+            assert relerr(got[wide][m], O.mttkrp(V, W, m, 0)) < KTOL[0], (wide, m)
+        s.close()
+        t.close()
+        c2.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert relerr(a, b) < 5e-7

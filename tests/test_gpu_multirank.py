@@ -34,6 +34,15 @@ def hipsim_lib():
     hipsim_util.build()   # once, before the ranks race for it (a no-op when the tree shipped it)
 
 
+def _keep(name, text):
+    """PPALS_MULTIRANK_LOG=dir: the ranks' own output is kept there (evidence for profiles/)"""
+    d = os.environ.get("PPALS_MULTIRANK_LOG")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".log"), "w") as f:
+            f.write(text)
+
+
 def _reap(procs, timeout):
     outs = []
     for p in procs:
@@ -63,6 +72,7 @@ def run_processes(case, world, timeout=900, extra_env=None):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} of {world} ({case}) failed:\n{out[-4000:]}"
         assert f"rank {r}: OK" in out
+    _keep(f"{case}_procs{world}", "\n".join(f"--- rank {r}\n{o}" for r, o in enumerate(outs)))
     return outs
 
 
@@ -75,6 +85,7 @@ def run_threads(case, world, timeout=1100, extra_env=None):
     out = _reap([p], timeout)[0]
     assert p.returncode == 0, f"{case} with {world} thread ranks failed:\n{out[-6000:]}"
     assert f"all {world} ranks: OK" in out
+    _keep(f"{case}_threads{world}", out)
     return out
 
 
