@@ -13,7 +13,7 @@
 // (src/optimizer/cp_msdt_optimizer.cxx:172-207): ONE first-level contraction V x_r W_r is reused
 // for the next N-1 mode updates, so an exact sweep costs N/(N-1) tensor scans instead of 2 — the
 // very same ALS iterates (same update order, same normal equations), 1.5x fewer tensor bytes at
-// N = 4. PPALS_DT_SCHEDULE=dt selects the two-first-level-node tree of alsCP_DT instead.
+// N = 4. ppals_cp_set_schedule(0) selects the two-first-level-node tree of alsCP_DT instead.
 // Multi-GPU: V is block-partitioned along mode 0; factors are replicated; each
 // mode update combines the s x R partial MTTKRP rows over the communicator — one all-reduce plus
 // the redundant fused update for small messages, reduce-scatter / row-block solve / all-gather
@@ -909,8 +909,11 @@ int CpEngine::ms_choose_roots() {
     for (unsigned sub = small;; sub = (sub - 1) & small) {  // every subset of the short modes
       const unsigned excl = sub | mandatory;
       const double cost = ms_schedule_cost(k, excl);
-      // (ties: fewer excluded modes, then smaller k)
-      if (cost < best_cost * (1.0 - 1e-9)) {
+      // (ties: fewer excluded modes, then smaller k — the subsets are walked from the fullest down, so a
+      // tie has to be broken explicitly)
+      const bool tie = cost <= best_cost * (1.0 + 1e-9) && cost >= best_cost * (1.0 - 1e-9);
+      if (cost < best_cost * (1.0 - 1e-9) ||
+          (tie && k == best && __builtin_popcount(excl) < __builtin_popcount(best_excl))) {
         best_cost = cost;
         best = k;
         best_excl = excl;

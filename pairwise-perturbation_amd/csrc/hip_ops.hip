@@ -114,6 +114,9 @@ class HipOps : public Ops {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_lds,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_gram_system_mfma,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    if (const char *v = getenv("PPALS_GJ_SCALAR")) gj_scalar_ = atoi(v);
   }
   ~HipOps() override {
     hipSetDevice(dev_);
@@ -870,6 +873,7 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
     }
   }
+  int gj_scalar_ = 0;  // PPALS_GJ_SCALAR=1: the scalar in-LDS sweeps for 64 < R <= 128 (A/B, tests)
   bool wide_enabled_ = true;  // PPALS_SCAN_WIDE=0: chunks of 64 columns (A/B, tests)
   int wide_occ_[4] = {0, 0, 0, 0};  // resident workgroups per CU of k_scan_wide<5..8>
   // Where the tail mode of k_scan_suffix_fast starts (first tile of the last, partial round of resident
@@ -1112,7 +1116,13 @@ class HipOps : public Ops {
       double *work = (double *)ensure(ws_big_, ws_big_sz_, sizeof(double) * (size_t)R * R + 64);
       int *status = (int *)(work + (size_t)R * R);
       const size_t lds_gj = sizeof(double) * ((size_t)R * R + 2 * (size_t)R);
-      if (lds_gj <= 150 * 1024)
+      const size_t RP = ((size_t)R + 15) & ~(size_t)15;
+      const size_t LDm = RP + ((34 - (RP & 31)) & 31);
+      const size_t lds_mf = sizeof(double) * (LDm * RP + 8 * RP);
+      if (lds_mf <= 150 * 1024 && !gj_scalar_)   // block sweeps, trailing update on the fp64 matrix cores
+        hipLaunchKernelGGL(k_gram_system_mfma, dim3(1), dim3(1024), lds_mf, st_, Gall, N, mode, R,
+                           lambda, S, Sinv, status);
+      else if (lds_gj <= 150 * 1024)
         hipLaunchKernelGGL(k_gram_system_lds, dim3(1), dim3(1024), lds_gj, st_, Gall, N, mode, R,
                            lambda, S, Sinv, status);
       else

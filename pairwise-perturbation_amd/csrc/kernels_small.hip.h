@@ -1230,6 +1230,139 @@ __global__ __launch_bounds__(1024) void k_gram_system_lds(const double *__restri
                   : 0.5 * (A[a + R * b] + A[b + R * a]);  // the two triangles differ by rounding
   }
 }
+// The same inverse by BLOCK Gauss-Jordan sweeps, four pivots per step, with the trailing update on
+// the fp64 matrix cores (64 < R <= 128; round 6). The scalar sweeps above spend 3.3 us per pivot on one
+// CU (330 us at R = 100: four of them were 15 % of an exact sweep at the reference's default rank s/2);
+// here a step inverts the 4 x 4 pivot block in registers (every thread, redundantly: the same scalar
+// pivots as the scalar sweeps, so the same "not positive definite" test), threads 0..RP-1 form the
+// row panel P^-1 A[K,:] and the column panels -A[:,K], -A[:,K] P^-1, and the 16 waves apply
+// A[O,O] -= A[O,K] P^-1 A[K,O] tile by tile as ONE v_mfma_f64_16x16x4_f64 each (K = 4 is the block).
+// The matrix is padded to a multiple of 16 with the identity (its inverse is the identity: the pad
+// never mixes with S). Three barriers per step, R/4 steps.
+// LDS: LD*RP + 8*RP doubles, RP = R rounded up to 16, LD = RP padded to 2 (mod 32) (141 KB at R = 128).
+__global__ __launch_bounds__(1024) void k_gram_system_mfma(const double *__restrict__ Gall, int N,
+                                                           int mode, int R, double lambda,
+                                                           double *__restrict__ S,
+                                                           double *__restrict__ Sinv,
+                                                           int *__restrict__ status) {
+  extern __shared__ double lds[];
+  const int RP = (R + 15) & ~15;
+  // leading dimension == 2 (mod 32) doubles: the 16 columns x 4 rows a wave touches in a tile land in
+  // distinct banks (a column stride of RP = 112 doubles puts eight lanes on one bank)
+  const int LD = RP + ((34 - (RP & 31)) & 31);
+  double *A = lds;             // RP x RP, column-major, leading dimension LD
+  double *Rk = A + LD * RP;    // [4][RP]  P^-1 A[K, :]     (zero in the K columns)
+  double *Cn = Rk + 4 * RP;    // [4][RP]  -A[:, K]         (zero in the K rows)
+  __shared__ int bad_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < RP * RP; e += blockDim.x) {
+    const int i = e % RP, j = e / RP;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < R && j < R) {
+      v = hadamard_entry(Gall, N, mode, R, lambda, i + R * j);
+      S[i + R * j] = v;
+    }
+    A[i + LD * j] = v;
+  }
+  if (tid == 0) bad_s = 0;
+  __syncthreads();
+  const int ntile = RP >> 4;
+  const int t = tid;
+  for (int k0 = 0; k0 < R; k0 += 4) {
+    // threads 0..RP-1 (two waves): the pivot block's inverse in registers (each of them, redundantly:
+    // the same scalar pivots as the scalar sweeps), column t of the row panel, row t of the column panels
+    double P[4][4], rk_new[4], cw[4];
+    const bool inK = t >= k0 && t < k0 + 4;
+    if (t < RP) {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) P[a][b] = A[(k0 + a) + LD * (k0 + b)];
+      int bad = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const double p = P[s][s];
+        if (!(p > 0.0)) bad = 1;
+        const double d = 1.0 / p;
+        double rs[4], cs[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          rs[a] = P[s][a];
+          cs[a] = P[a][s];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            double v;
+            if (a == s)
+              v = (b == s) ? d : rs[b] * d;
+            else if (b == s)
+              v = -cs[a] * d;
+            else
+              v = P[a][b] - cs[a] * (rs[b] * d);
+            P[a][b] = v;
+          }
+      }
+      if (bad && t == 0) bad_s = 1;
+      double x[4], y[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        x[a] = A[(k0 + a) + LD * t];
+        y[a] = A[t + LD * (k0 + a)];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        double r = 0, c = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          r += P[a][b] * x[b];
+          c -= y[b] * P[b][a];
+        }
+        rk_new[a] = r;
+        cw[a] = c;
+        Rk[a * RP + t] = inK ? 0.0 : r;
+        Cn[a * RP + t] = inK ? 0.0 : -y[a];
+      }
+    }
+    __syncthreads();
+    if (bad_s) break;  // (workgroup-uniform: written before the barrier, read after it)
+    // trailing update, one MFMA per 16 x 16 tile (f64 C/D map: column lane & 15, rows (lane >> 4) + 4 r)
+    for (int tile = wave; tile < ntile * ntile; tile += 16) {
+      const int ti = tile % ntile, tj = tile / ntile;
+      double *c0 = A + (16 * ti + (lane >> 4)) + LD * (16 * tj + (lane & 15));
+      f64x4 c = {c0[0], c0[4], c0[8], c0[12]};
+      const double av = Cn[(lane >> 4) * RP + 16 * ti + (lane & 15)];
+      const double bv = Rk[(lane >> 4) * RP + 16 * tj + (lane & 15)];
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+      c0[0] = c[0];
+      c0[4] = c[1];
+      c0[8] = c[2];
+      c0[12] = c[3];
+    }
+    __syncthreads();
+    if (t < RP) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        if (!inK) {
+          A[(k0 + a) + LD * t] = rk_new[a];
+          A[t + LD * (k0 + a)] = cw[a];
+        } else {
+          const int tb = t - k0;  // (a select chain: no dynamically indexed register array)
+          A[(k0 + a) + LD * t] = tb == 0 ? P[a][0] : (tb == 1 ? P[a][1] : (tb == 2 ? P[a][2] : P[a][3]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int bad = bad_s;
+  if (tid == 0) *status = bad;
+  for (int e = tid; e < R * R; e += blockDim.x) {
+    const int a = e % R, b = e / R;
+    Sinv[e] = bad ? __longlong_as_double(0x7ff8000000000000LL)
+                  : 0.5 * (A[a + LD * b] + A[b + LD * a]);  // the two triangles differ by rounding
+  }
+}
 // Sinv = Z diag(1/w) Z^T from the eigen-decomposition S = Z diag(w) Z^T (Z column-major, w any
 // order): for symmetric S this IS the reference's untruncated V diag(1/sigma) U^T
 // (common.cxx:717-722) — the defined answer when S is not positive definite

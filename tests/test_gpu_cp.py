@@ -1178,3 +1178,33 @@ def test_wide_scan_padded_layout_and_switch(pp, monkeypatch):
         c2.close()
     for a, b in zip(got["1"], got["0"]):
         assert relerr(a, b) < 5e-7
+
+
+@pytest.mark.parametrize("R", [65, 80, 100, 112, 128])
+def test_gram_system_above_64(pp, R, monkeypatch):
+    """S and S^-1 (common.cxx:710-725) for 64 < R <= 128: the block Gauss-Jordan sweeps with the
+    trailing update on the fp64 matrix cores (k_gram_system_mfma) and the scalar in-LDS sweeps
+    (PPALS_GJ_SCALAR=1) against the oracle's Hadamard / numpy's inverse, and against each other"""
+    lens = [150, 140, 130, 135]
+    W = O.init_factors(lens, R, 7)
+    got = {}
+    for scalar in ("0", "1"):
+        monkeypatch.setenv("PPALS_GJ_SCALAR", scalar)
+        c2 = pp.Context(0)
+        t2 = pp.Tensor(c2, lens, 0)
+        s = pp.CP(c2, t2, R)
+        s.set_factors(W)
+        for mode in (0, 3):
+            S, Si = s.gram_system(mode, 0.125)
+            want = O.gram_hadamard(W, mode, 0.125)
+            cond = np.linalg.cond(want)
+            assert relerr(S, want) < 1e-13
+            assert relerr(Si @ want, np.eye(R)) < 1e-9 * cond, (scalar, mode, relerr(Si @ want, np.eye(R)), cond)
+            assert relerr(Si, O.svd_solve(np.eye(R), want)) < 1e-9 * cond
+            assert np.array_equal(Si, Si.T)       # symmetric bit for bit (both routes average the triangles)
+            got[(scalar, mode)] = Si
+        s.close()
+        t2.close()
+        c2.close()
+    for mode in (0, 3):
+        assert relerr(got[("0", mode)], got[("1", mode)]) < 1e-10 * cond
