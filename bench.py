@@ -530,81 +530,120 @@ def sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure
         dt = time.perf_counter() - t0
         return max_over_ranks(dt)
 
+    def agree(ok):
+        """every rank learns whether ALL ranks got through the stage just ended (a stage that can fail
+        — an allocation, a session set-up — holds no collective; the sweeps that follow do, so a rank
+        that failed must not leave the others inside them): all ranks skip the rest of a record together"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def guarded(make):
+        """(object, error) of a collective-free construction, agreed over the ranks"""
+        obj, err = None, None
+        try:
+            obj = make()
+        except Exception as e:  # reported, never required
+            err = str(e)
+        if not agree(err is None):
+            if obj is not None:
+                obj.close()
+            return None, err or "another rank failed this stage"
+        return obj, None
+
     # ---- configs[3]
     lens4, R4 = ([16, 12, 12, 12], 3) if hostsim else WORKLOADS["cp4_s400_r20"]
     f32 = ppals.F64 if hostsim else ppals.F32
-    try:
-        V4 = ppals.Tensor(ctx, lens4, f32).fill_cp(ppals.init_factors(lens4, R4, 1000))
-        W4, G4 = ppals.init_factors(lens4, R4, 2000), ppals.init_factors(lens4, R4, 3000)
-        rec = {"config": f"BASELINE configs[3]: CP order-4 s={lens4[0]} R={R4} -tensor r, leading-mode blocks "
-                         f"over {world} ranks, 2 warm-up + 5 timed exact sweeps per collective plan",
-               "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32"}
-        for plan, small in (("allreduce_plan", None), ("reduce_scatter_plan", "0")):
-            old = os.environ.get("PPALS_COMM_SMALL_BYTES")
-            if small is not None:
-                os.environ["PPALS_COMM_SMALL_BYTES"] = small
-            try:
-                cp4 = ppals.CP(ctx, V4, R4)
-                r = measure(cp4, 5, 2, W4, G4)
-                r["sweep_flops"] = sweep_flops(lens4, R4, cp4.schedule)
-                r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
-                r["comm_plan"] = ("one all-reduce of the s x R partials per mode + redundant fused update"
-                                  if small is None else "reduce-scatter + row-block update + all-gather per mode")
-                if "roofline" in r:
-                    rl = r["roofline"]
-                    rl["avg_launch_ms_slowest_rank"] = max_over_ranks(rl["avg_launch_ms"])
-                    rl["avg_launch_ms_fastest_rank"] = max_over_ranks(rl["avg_launch_ms"], dist.ReduceOp.MIN)
-                    rl["frac_slowest_rank"] = (rl["algorithmic_bytes_per_launch"] /
-                                               (rl["avg_launch_ms_slowest_rank"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                    rl["note"] = "rank 0's shard: bytes of ITS scans / ITS average launch; *_slowest_rank over all ranks"
-                r["final_gradnorm"] = cp4.gradnorm()
-                rec[plan] = r
-                cp4.close()
-            finally:
+    V4, err = guarded(lambda: ppals.Tensor(ctx, lens4, f32).fill_cp(ppals.init_factors(lens4, R4, 1000)))
+    if V4 is None:
+        out["cfg4_sharded"] = {"error": err}
+    else:
+        try:
+            W4, G4 = ppals.init_factors(lens4, R4, 2000), ppals.init_factors(lens4, R4, 3000)
+            rec = {"config": f"BASELINE configs[3]: CP order-4 s={lens4[0]} R={R4} -tensor r, leading-mode blocks "
+                             f"over {world} ranks, 2 warm-up + 5 timed exact sweeps per collective plan",
+                   "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32"}
+            for plan, small in (("allreduce_plan", None), ("reduce_scatter_plan", "0")):
+                old = os.environ.get("PPALS_COMM_SMALL_BYTES")
                 if small is not None:
-                    if old is None:
-                        del os.environ["PPALS_COMM_SMALL_BYTES"]
-                    else:
-                        os.environ["PPALS_COMM_SMALL_BYTES"] = old
-        V4.close()
-        out["cfg4_sharded"] = rec
-    except Exception as e:  # reported, never required
-        out["cfg4_sharded"] = {"error": str(e)}
+                    os.environ["PPALS_COMM_SMALL_BYTES"] = small
+                cp4 = None
+                try:
+                    cp4, err = guarded(lambda: ppals.CP(ctx, V4, R4))
+                    if cp4 is None:
+                        rec[plan] = {"error": err}
+                        continue
+                    r = measure(cp4, 5, 2, W4, G4)
+                    r["sweep_flops"] = sweep_flops(lens4, R4, cp4.schedule)
+                    r["mttkrp_tflops"] = r["sweep_flops"] * r["value"] / 1e12
+                    r["comm_plan"] = ("one all-reduce of the s x R partials per mode + redundant fused update"
+                                      if small is None else
+                                      "reduce-scatter + row-block update + all-gather per mode (the plan north_star names)")
+                    if "roofline" in r:
+                        rl = r["roofline"]
+                        rl["avg_launch_ms_slowest_rank"] = max_over_ranks(rl["avg_launch_ms"])
+                        rl["avg_launch_ms_fastest_rank"] = max_over_ranks(rl["avg_launch_ms"], dist.ReduceOp.MIN)
+                        rl["frac_slowest_rank"] = (rl["algorithmic_bytes_per_launch"] /
+                                                   (rl["avg_launch_ms_slowest_rank"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                        rl["note"] = "rank 0's shard: bytes of ITS scans / ITS average launch; *_slowest_rank over all ranks"
+                    r["final_gradnorm"] = cp4.gradnorm()
+                    rec[plan] = r
+                finally:
+                    if cp4 is not None:
+                        cp4.close()
+                    if small is not None:
+                        if old is None:
+                            del os.environ["PPALS_COMM_SMALL_BYTES"]
+                        else:
+                            os.environ["PPALS_COMM_SMALL_BYTES"] = old
+            out["cfg4_sharded"] = rec
+        finally:
+            V4.close()
 
     # ---- configs[4], N-GPU leg
     lens5, ranks5, nsw = ([16, 12, 10], [3, 3, 3], 4) if hostsim else ([400, 400, 400], [20, 20, 20], 20)
-    try:
-        V5 = ppals.Tensor(ctx, lens5, f32).fill_uniform(7)
-        tk = ppals.Tucker(ctx, V5, ranks5)
-        tk.hosvd()                      # warm-up of the one-off paths
-        tk.close()
-        tk = ppals.Tucker(ctx, V5, ranks5)   # a new session: nothing known about the Grams
-        hosvd_s = timed(tk.hosvd)
-        tk.sweeps_dt(2)
-        ctx.profile_reset()
-        ctx.profile_enable(1)
-        sweeps_s = timed(lambda: tk.sweeps_dt(nsw))
-        ctx.profile_enable(0)
-        ls, scan_ms, scan_bytes = ctx.profile_read(0)
-        rec = {"config": f"BASELINE configs[4] on {world} ranks: Tucker order-3 s={lens5[0]} core "
-                         f"{'x'.join(map(str, ranks5))}, -tensor r2, leading-mode blocks; hosvd + 2 warm-up + "
-                         f"{nsw} timed HOOI sweeps (alsTucker_DT)",
-               "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32",
-               "hosvd_ms": 1e3 * hosvd_s, "ms_per_hooi_sweep": 1e3 * sweeps_s / nsw, "sweeps": nsw}
-        if ls > 0 and scan_ms > 0:
-            avg = scan_ms / ls
-            rec["roofline"] = {"bound": "hbm", "achieved": scan_bytes / ls / (avg * 1e-3) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": scan_bytes / ls / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "launches": ls, "avg_launch_ms": avg,
-                               "avg_launch_ms_slowest_rank": max_over_ranks(avg),
-                               "algorithmic_bytes_per_launch": scan_bytes / ls,
-                               "kernel": "tensor scans of the TTMc chain (K11), rank 0's shard"}
-        tk.close()
-        V5.close()
-        out["cfg5_tucker_sharded"] = rec
-    except Exception as e:  # reported, never required
-        out["cfg5_tucker_sharded"] = {"error": str(e)}
+    V5, err = guarded(lambda: ppals.Tensor(ctx, lens5, f32).fill_uniform(7))
+    tk = None
+    if V5 is None:
+        out["cfg5_tucker_sharded"] = {"error": err}
+    else:
+        try:
+            tk, err = guarded(lambda: ppals.Tucker(ctx, V5, ranks5))
+            if tk is None:
+                raise RuntimeError(err)
+            tk.hosvd()                      # warm-up of the one-off paths
+            tk.close()
+            tk, err = guarded(lambda: ppals.Tucker(ctx, V5, ranks5))   # a new session: nothing known about the Grams
+            if tk is None:
+                raise RuntimeError(err)
+            hosvd_s = timed(tk.hosvd)
+            tk.sweeps_dt(2)
+            ctx.profile_reset()
+            ctx.profile_enable(1)
+            sweeps_s = timed(lambda: tk.sweeps_dt(nsw))
+            ctx.profile_enable(0)
+            ls, scan_ms, scan_bytes = ctx.profile_read(0)
+            rec = {"config": f"BASELINE configs[4] on {world} ranks: Tucker order-3 s={lens5[0]} core "
+                             f"{'x'.join(map(str, ranks5))}, -tensor r2, leading-mode blocks; hosvd + 2 warm-up + "
+                             f"{nsw} timed HOOI sweeps (alsTucker_DT)",
+                   "rccl_ranks": ctx.nranks, "dtype": "f64" if hostsim else "f32",
+                   "hosvd_ms": 1e3 * hosvd_s, "ms_per_hooi_sweep": 1e3 * sweeps_s / nsw, "sweeps": nsw}
+            if ls > 0 and scan_ms > 0:
+                avg = scan_ms / ls
+                rec["roofline"] = {"bound": "hbm", "achieved": scan_bytes / ls / (avg * 1e-3) / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": scan_bytes / ls / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "launches": ls, "avg_launch_ms": avg,
+                                   "avg_launch_ms_slowest_rank": max_over_ranks(avg),
+                                   "algorithmic_bytes_per_launch": scan_bytes / ls,
+                                   "kernel": "tensor scans of the TTMc chain (K11), rank 0's shard"}
+            out["cfg5_tucker_sharded"] = rec
+        except Exception as e:  # reported, never required (a failure agreed by all ranks)
+            out["cfg5_tucker_sharded"] = {"error": str(e)}
+        finally:
+            if tk is not None:
+                tk.close()
+            V5.close()
     return out
 
 
@@ -947,8 +986,13 @@ def main():
         V.close()
         ctx.close()
         return
+    # (on real factors: the session's own are still zero, and sweeps on a singular S would time the
+    # solve's fallback path; at most 24 sweeps — the engine's evidence gate ends an exploration that
+    # finds nothing after 8 samples per root, and whatever is still exploring then simply goes on inside
+    # the timed region: an exploring visit IS the sweep's own scan)
+    cp.set_factors(W0, G0)
     t0 = time.perf_counter()
-    while settle_sweeps < 120:
+    while settle_sweeps < 24:
         try:
             rep = cp.placement_report()
             done = (rep.get("mode") != "online" or (rep["roots"] and all(r["settled"] for r in rep["roots"]))
@@ -1073,6 +1117,10 @@ def main():
             os.environ["PPALS_COMM_SMALL_BYTES"] = old
     cp.close()
     if sharded_records:
+        if rank == 0:   # the optional records contain collectives: what is already measured is not lost with them
+            print("[bench] headline before the sharded config records: " +
+                  json.dumps({"value": head["value"], "ms_per_step": head["ms_per_step"], "n_gpus": world}),
+                  file=sys.stderr, flush=True)
         sub.update(sharded_config_records(ppals, ctx, torch, dist, dev, hostsim, world, measure, barrier))
     if config_records:
         import tempfile
@@ -1081,6 +1129,41 @@ def main():
                 sub["cfg3_pp"] = cfg3_pp_record(ppals, ctx, V, R, W0, G0, vnorm, tmpdir)
             except Exception as e:  # reported, never required
                 sub["cfg3_pp"] = {"error": str(e)}
+    if config_records and world == 1 and args.dtype == "f32" and not args.schedule and args.workload == "cp4_s200_r10":
+        # the reference CLI's DEFAULT rank is s/2 (test_ALS.cxx:119-125): past 64 columns the scan is
+        # bound by the fp32 matrix cores, not by HBM — one pass per 128 columns (k_scan_wide)
+        try:
+            R100 = 100
+            cpw = ppals.CP(ctx, V, R100)
+            cpw.set_factors(ppals.init_factors(lens, R100, 2000), ppals.init_factors(lens, R100, 3000))
+            cpw.sweeps_dt(2)
+            ctx.sync()
+            t0w = time.perf_counter()
+            cpw.sweeps_dt(6)
+            ctx.sync()
+            ms_w = 1e3 * (time.perf_counter() - t0w) / 6
+            ctx.profile_reset()
+            ctx.profile_enable(1)
+            cpw.sweeps_dt(4)
+            ctx.sync()
+            ctx.profile_enable(0)
+            lw, scan_ms_w, _ = ctx.profile_read(0)
+            cols = 16 * ((R100 + 15) // 16)
+            rec = {"config": "CP order-4 s=200 R=100 (-rank s/2, the reference CLI's default), -tensor values of "
+                             "the headline tensor, fp32 storage, exact sweeps",
+                   "ms_per_sweep": ms_w, "scan_launches_per_sweep": lw / 4, "schedule": cpw.schedule}
+            if lw > 0 and scan_ms_w > 0:
+                avg = scan_ms_w / lw
+                tf = 2.0 * float(np.prod(lens)) * cols / (avg * 1e-3) / 1e12
+                rec["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": tf / 157.3, "avg_launch_ms": avg, "launches": lw,
+                                   "kernel": "k_scan_wide<7> (one pass for 7 n-tiles of 16 columns; executed flops "
+                                             "= 2 x elements x 112 columns, 100 of them useful)",
+                                   "useful_tflops": 2.0 * float(np.prod(lens)) * R100 / (avg * 1e-3) / 1e12}
+            cpw.close()
+            sub["rank100"] = rec
+        except Exception as e:  # reported, never required
+            sub["rank100"] = {"error": str(e)}
     V.close()
     if world == 1 and args.dtype == "f32" and not args.schedule and args.workload == "cp4_s200_r10":
         V64 = ppals.Tensor(ctx, lens, ppals.F64).fill_cp(Wtrue)

@@ -48,7 +48,10 @@ const char *ppals_version(void);
  * dsyevd). Its libraries register their code objects in milliseconds when they enter the process
  * BEFORE the HIP runtime is initialised, and in minutes afterwards (0.013 s vs 253 s measured).
  * Call this first thing — before ppals_ctx_create and before anything else touches the GPU (e.g.
- * torch.cuda) — in a process that will run such a session. Without it they are loaded on demand. */
+ * torch.cuda) — in a process that will run such a session. Without it they are loaded on demand:
+ * the library then prints one line on stderr (what is about to happen, how long it can take, how to
+ * avoid it) before it stalls, and with PPALS_STRICT_PRELOAD=1 in the environment the call that needed
+ * the solver fails with PPALS_ERR_UNSUPPORTED instead (csrc/preload_policy.h). */
 int ppals_preload_eigensolver(void);
 
 /* ---- context (replaces CTF::World dw, test_ALS.cxx:200) ---- */

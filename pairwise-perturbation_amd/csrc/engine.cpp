@@ -982,6 +982,29 @@ void CpEngine::ms_place_collect(PlaceExplore &ex) {
 // schedule old when it is read here: nothing waits.
 int CpEngine::ms_place_pick(PlaceExplore &ex) {
   ms_place_collect(ex);
+  // Evidence gate (round 6): on the driver's boxes five rounds of headlines showed the choice worth
+  // nothing (tuned 537.6 against untuned 537.8 sweeps/s, fastest and slowest candidate 2.6 % apart),
+  // on others 2 %. After the first 8 samples of a root, a spread below 4 % between its fastest and
+  // slowest candidate ends the exploration: the root keeps the fastest sample IN THE FIRST BLOCK, so
+  // that the second block goes back to the device at once.
+  if (ex.phase == 0) {
+    int n = 0, best0 = -1;
+    double lo = 1e300, hi = 0;
+    for (size_t q = 0; q < ex.cands.size(); q++)
+      if (ex.cands[q].samples > 0) {
+        n++;
+        lo = std::min(lo, ex.cands[q].best);
+        hi = std::max(hi, ex.cands[q].best);
+        if (ex.cands[q].blk == 0 && (best0 < 0 || ex.cands[q].best < ex.cands[best0].best)) best0 = (int)q;
+      }
+    if (n >= kPlaceGateSamples && best0 >= 0 && hi < lo * (1.0 + kPlaceGateSpread)) {
+      ex.chosen = best0;
+      ex.gated = true;
+      ex.phase = 2;
+      ms_place_release_unchosen();
+      return -1;
+    }
+  }
   if (ex.phase == 0 && ex.next >= ex.cands.size()) {
     std::vector<int> idx(ex.cands.size());
     for (size_t q = 0; q < idx.size(); q++) idx[q] = (int)q;
@@ -1048,6 +1071,23 @@ void *CpEngine::big_alloc(size_t bytes) {
   for (;;) {
     void *p = ops_.try_alloc(bytes);
     if (p) return p;
+    // first what is merely optional for SPEED OF CHOICE: the second candidate block of the placement
+    // exploration (unless the intermediate alive right now lies in it) — a resident layout is worth
+    // more to every later sweep than a few more candidates to ~24 visits
+    if (ms_X_alt_ && !(ms_X_.valid && (char *)ms_X_.buf >= (char *)ms_X_alt_ &&
+                       (char *)ms_X_.buf < (char *)ms_X_alt_ + ms_X_cap_)) {
+      ops_.sync();
+      for (auto &ex : ms_place_) {
+        if (ex.timer >= 0) {  // a sample of a candidate in the block that goes away is dropped
+          ops_.timer_read(ex.timer);
+          ex.timer = -1;
+        }
+        for (auto &c : ex.cands) c.blk = 0;  // (its candidates now alias offsets of the first block)
+      }
+      ops_.free(ms_X_alt_);
+      ms_X_alt_ = nullptr;
+      continue;
+    }
     if (lay_.size() > 1 && lay_.back().owned) {
       ops_.sync();
       ops_.free(lay_.back().ptr);
@@ -2017,7 +2057,7 @@ void CpEngine::pp_build_all() {
   }
 }
 std::string CpEngine::placement_report() const {
-  char buf[320];
+  char buf[400];
   std::string out = "{\"mode\": ";
   out += ms_tune_enabled_ && ms_X_slack() > 0 ? "\"online\"" : "\"off\"";
   out += ", \"setup_s\": 0.0, \"candidate_blocks_held\": ";
@@ -2033,11 +2073,11 @@ std::string CpEngine::placement_report() const {
       if (q.samples > 0) best = std::min(best, q.best);
     snprintf(buf, sizeof buf,
              "%s{\"root\": %d, \"layout\": \"%s\", \"settled\": %s, \"visits\": %d, \"block\": %d, \"offset_mb\": %lld, "
-             "\"store\": \"%s\", \"best_ms\": %.4f, \"worst_ms\": %.4f}",
+             "\"store\": \"%s\", \"best_ms\": %.4f, \"worst_ms\": %.4f, \"gated\": %s}",
              firstrow ? "" : ", ", r, ex.layout == 1 ? "second (transposed) copy" : "tensor",
              ex.phase == 2 ? "true" : "false", ex.visits, c ? c->blk : 0, c ? (long long)(c->off >> 20) : 0LL,
              !c || c->nt < 0 ? "by size" : (c->nt == 1 ? "non-temporal" : "ordinary"),
-             best < 1e299 ? best * 1e3 : 0.0, ex.worst * 1e3);
+             best < 1e299 ? best * 1e3 : 0.0, ex.worst * 1e3, ex.gated ? "true" : "false");
     out += buf;
     firstrow = false;
   }

@@ -213,8 +213,11 @@ class CpEngine {
     int layout = 0;        // which resident layout the root's scan reads
     double worst = 0;      // slowest sample seen, seconds
     int visits = 0;
+    bool gated = false;    // settled early: the candidates' spread was inside the gate (ms_place_pick)
     std::vector<PlaceCand> cands;
   };
+  static constexpr int kPlaceGateSamples = 8;       // samples of a root before the gate is consulted
+  static constexpr double kPlaceGateSpread = 0.04;  // fastest / slowest candidate closer than this: stop
   PlaceExplore ms_place_[MAX_ORDER];
   void ms_place_collect(PlaceExplore &ex);
   int ms_place_pick(PlaceExplore &ex);

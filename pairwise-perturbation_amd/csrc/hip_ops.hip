@@ -14,6 +14,7 @@
 
 #include "hip_ops.h"
 #include "roctx_ranges.h"
+#include "preload_policy.h"
 #include "kernels_scan.hip.h"
 #include "kernels_small.hip.h"
 #include "kernels_eig.hip.h"
@@ -44,9 +45,15 @@ static inline int grid_for(int64_t n, int block, int cap = 4096) {
 struct EigLibs {
   void *blas = nullptr, *solver = nullptr;
 };
+static bool g_hip_runtime_up = false;  // set by the first HipOps (this library's own use of the runtime)
 static EigLibs &eig_libs() {
   static EigLibs l;
   if (l.blas && l.solver) return l;
+  switch (late_preload_policy(false, g_hip_runtime_up, getenv("PPALS_STRICT_PRELOAD"))) {
+    case kPreloadRefuse: throw Unsupported(late_preload_message());
+    case kPreloadWarn: fprintf(stderr, "%s\n", late_preload_message()); fflush(stderr); break;
+    default: break;
+  }
   l.blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
   if (!l.blas) l.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
   l.solver = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
@@ -68,6 +75,7 @@ class HipOps : public Ops {
     if (device < 0 || device >= ndev)
       throw std::runtime_error("ppals: device index out of range");
     dev_ = device;
+    g_hip_runtime_up = true;
     HIP_CHECK(hipSetDevice(dev_));
     HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     hipDeviceProp_t prop;
@@ -695,7 +703,7 @@ class HipOps : public Ops {
         // the engine's online placement choice tries both kinds for the first-level intermediate
         // (scan_store_mode); this rule is for every other large result.
         constexpr double nt_min_bytes = 192.0 * 1048576.0;
-        const bool nt_store =
+        bool nt_store =
             nsplit == 1 && (scan_nt_mode_ < 0 ? (double)M * T * ncols * (dst32 ? 4.0 : 8.0) >= nt_min_bytes
                                               : scan_nt_mode_ == 1);
         // (Measured and rejected, tools/runs/r03_u.sh: second-level sums in fp32 for short
@@ -712,6 +720,16 @@ class HipOps : public Ops {
   }
         // buffer-load variant: needs 32-bit byte offsets inside one 16-column block
         const bool buf_ok = (16.0 * (double)M * sizeof(TV) < 2.0e9) && (pack_bytes < 2000000000ull);
+        // Which KERNEL runs must not depend on the store kind: the engine's placement exploration tries
+        // both kinds and keeps what the stopwatch prefers, and the tail-mode kernel (which has no
+        // non-temporal instantiation) sums k in another order than the others — results would then vary
+        // from run to run with timing noise. So the tail mode is decided first, and where it applies
+        // the stores are ordinary whatever was asked for.
+        const bool takes_buf = al && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
+                               !(sizeof(TV) == 8 && nsplit > 1);
+        const bool takes_tail = !takes_buf && al && M >= VEC && T == 1 && nsplit == 1 && NT <= 2 && k_ld == 0 &&
+                                scan_tail_split<TV>(NT, n_mtiles) >= 0;
+        if (takes_tail) nt_store = false;
         // (measured: with NT >= 2 the fp32 build of the buffer variant drops to 2 waves/SIMD and
         // loses to the global-load kernel, so it is used for one n-tile / fp64 storage only)
         // (and: K-split scans of an fp64 tensor — few, long work items of half-size blocks — run
@@ -720,8 +738,7 @@ class HipOps : public Ops {
         // cfg5, 625 tiles, 73 us — is a round and a quarter at 2 waves per SIMD; handing it to the
         // register-lean persistent form with 3 waves, k_scan_suffix_lean<2,4,0,3>, was measured:
         // 40 HOOI sweeps 0.0446 / 0.0443 s against 0.0442 / 0.0441 s. Not kept.)
-        if (al && M >= VEC && buf_ok && (NT == 1 || sizeof(TV) == 8) &&
-            !(sizeof(TV) == 8 && nsplit > 1)) {
+        if (takes_buf) {
           if (NT == 1) {
             LAUNCH_SUFFIX_BUF(1)
           } else if (NT == 2) {
@@ -731,8 +748,7 @@ class HipOps : public Ops {
           } else {
             LAUNCH_SUFFIX_BUF(4)
           }
-        } else if (al && M >= VEC && T == 1 && nsplit == 1 && NT <= 2 && k_ld == 0 && !nt_store &&
-                   scan_tail_split<TV>(NT, n_mtiles) >= 0) {
+        } else if (takes_tail) {
           // a round and a bit of resident workgroups (cfg5's 625 tiles on 512 slots: 0.49 of the HBM
           // peak): the tiles of the last, partial round as four quarter-length work items each
           // (kernels_scan.hip.h, TAIL MODE)

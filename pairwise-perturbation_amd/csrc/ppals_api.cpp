@@ -10,6 +10,7 @@
 
 #include "../../include/ppals.h"
 #include "backend.h"
+#include "preload_policy.h"
 #include "engine.h"
 #include "tucker.h"
 
@@ -46,6 +47,10 @@ struct ppals_tucker {
 
 #define API_BEGIN try {
 #define API_END(code)                     \
+  }                                       \
+  catch (const ppals::Unsupported &e) {   \
+    g_err = e.what();                     \
+    return PPALS_ERR_UNSUPPORTED;         \
   }                                       \
   catch (const std::exception &e) {       \
     g_err = e.what();                     \

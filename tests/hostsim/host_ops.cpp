@@ -98,7 +98,13 @@ class HostOps : public Ops {
   double timer_read(int h) override {
     if (h < 0) return -1.0;
     const uint32_t x = (uint32_t)h * 2654435761u;
-    return 1e-3 * (1.0 + 0.1 * (double)((x >> 16) & 15) / 15.0);
+    // (PPALS_HOSTSIM_TIMER_SPREAD: how far apart the stand-in's "measurements" lie — 0.1 by default;
+    // below the engine's gate of 4 % the exploration must end early, tests/test_engine_hostsim.py)
+    static const double spread = [] {
+      const char *e = std::getenv("PPALS_HOSTSIM_TIMER_SPREAD");
+      return e ? std::atof(e) : 0.1;
+    }();
+    return 1e-3 * (1.0 + spread * (double)((x >> 16) & 15) / 15.0);
   }
   uint64_t timer_calls_ = 0;
 

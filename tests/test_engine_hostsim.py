@@ -2,6 +2,8 @@
 engine + C ABI linked against the host stand-in ops (tests/hostsim). They check the sweep / tree /
 PP-restart / CSV control flow of pairwise-perturbation_amd/csrc/engine.cpp against the oracle on a
 box without a GPU. They say nothing about the HIP kernels — that is what `-m gpu` is for."""
+import os
+
 import pytest
 
 import hostsim_util
@@ -136,6 +138,39 @@ def test_placement_measurement_leaves_results_alone(pp, monkeypatch):
         assert r["settled"] and r["visits"] == 14 + 4 + 6 and r["worst_ms"] >= r["best_ms"] > 0
     # (the stand-in's stopwatch is a hash of the call count: the roots do not all agree)
     assert len({(r["block"], r["offset_mb"], r["store"]) for r in rep["roots"]}) > 1
+
+
+def test_placement_exploration_ends_early_without_evidence():
+    """the evidence gate of the online placement choice (engine.cpp ms_place_pick, round 6): when a
+    root's first 8 samples lie within 4 % of each other the exploration ends there — the root keeps its
+    fastest candidate of the FIRST block and the second candidate block is released — instead of
+    walking all 24 candidates for nothing (what five rounds of driver-box headlines showed). A fresh
+    process: the stand-in reads its stopwatch spread once."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, json
+os.environ["PPALS_HOSTSIM_TIMER_SPREAD"] = "0.01"
+os.environ["PPALS_PLACE_MIN_MB"] = "0"
+sys.path.insert(0, %r)
+import hostsim_util
+pp = hostsim_util.load()
+lens, R = [9, 8, 7, 6], 3
+c = pp.Context(0)
+t = pp.Tensor(c, lens, 1).fill_uniform(11)
+s = pp.CP(c, t, R)
+s.set_factors(pp.init_factors(lens, R, 5))
+s.sweeps_dt(40)
+print("REPORT " + json.dumps(s.placement_report()))
+""" % os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("REPORT ")][0][7:])
+    assert rep["mode"] == "online" and rep["candidate_blocks_held"] == 1 and rep["roots"]
+    for r in rep["roots"]:
+        # one sample is read a visit late: the gate sees 8 samples at the head of the 10th visit
+        assert r["settled"] and r["gated"] and r["visits"] <= 10 and r["block"] == 0, r
 
 
 @pytest.mark.parametrize("sched", ["ms", "tree"])

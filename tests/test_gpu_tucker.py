@@ -765,3 +765,34 @@ def test_hosvd_gram_syrk_f32(pp, lens, ranks, monkeypatch):
     s.close()
     t.close()
     c2.close()
+
+
+def test_strict_preload_refuses_a_late_eigensolver_load():
+    """include/ppals.h: with PPALS_STRICT_PRELOAD=1 a session that needs the vendor eigensolver in a
+    process that did not call ppals_preload_eigensolver() before the HIP runtime came up fails with
+    PPALS_ERR_UNSUPPORTED (-5) at once instead of stalling for minutes in dlopen (fresh child: this
+    process has preloaded the solver already, tests/conftest.py)"""
+    import subprocess
+    import sys
+    import time
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pairwise-perturbation_amd")
+    code = f"""
+import os, sys
+os.environ['PPALS_STRICT_PRELOAD'] = '1'
+os.environ['PPALS_EIG_FAST'] = '0'          # every eigen-step on the full solver
+sys.path.insert(0, {pkg!r})
+import ppals
+ctx = ppals.Context(0)                       # the HIP runtime is up now, the solver is not loaded
+t = ppals.Tensor(ctx, [160, 10, 8], 1).fill_uniform(3)
+tk = ppals.Tucker(ctx, t, [4, 3, 3])
+try:
+    tk.hosvd()
+    print('RAN')
+except ppals.PpalsError as e:
+    print('REFUSED', e)
+"""
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "REFUSED ppals error -5" in out.stdout, out.stdout + out.stderr[-2000:]
+    assert "ppals_preload_eigensolver" in out.stdout
+    assert time.time() - t0 < 120

@@ -106,3 +106,42 @@ def test_bench_live_pmc_traffic_units(tmp_path, monkeypatch):
     monkeypatch.setattr(shutil, "which", lambda name: None)
     traffic, src = bench.live_pmc_traffic(args)
     assert traffic is None and "rocprofv3" in src
+
+
+def test_late_eigensolver_preload_policy(tmp_path):
+    """include/ppals.h, ppals_preload_eigensolver: a process that loads rocBLAS / rocSOLVER after the
+    HIP runtime is up is told so on stderr before it stalls, and refused under PPALS_STRICT_PRELOAD=1
+    (csrc/preload_policy.h — the host logic the library runs at its late dlopen, compiled here on its
+    own; the refusal reaches the C ABI as PPALS_ERR_UNSUPPORTED through ppals::Unsupported)"""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "preload_policy.h"
+using namespace ppals;
+int main() {
+  if (late_preload_policy(true, true, "1") != kPreloadSilent) return 1;    // already loaded
+  if (late_preload_policy(false, false, "1") != kPreloadSilent) return 2;  // runtime not up yet: cheap
+  if (late_preload_policy(false, true, nullptr) != kPreloadWarn) return 3;
+  if (late_preload_policy(false, true, "0") != kPreloadWarn) return 4;
+  if (late_preload_policy(false, true, "1") != kPreloadRefuse) return 5;
+  const char *m = late_preload_message();
+  if (!strstr(m, "ppals_preload_eigensolver") || !strstr(m, "minutes") || !strstr(m, "PPALS_STRICT_PRELOAD"))
+    return 6;
+  try { throw Unsupported(m); } catch (const std::runtime_error &e) { if (strcmp(e.what(), m)) return 7; }
+  puts(m);
+  return 0;
+}
+''')
+    exe = tmp_path / "t"
+    inc = os.path.join(ROOT, "pairwise-perturbation_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.returncode
+    assert "stall" in out.stdout
+    # the product wires it in: the late dlopen consults the policy, the ABI maps the refusal
+    hip = open(os.path.join(inc, "hip_ops.hip")).read()
+    api = open(os.path.join(inc, "ppals_api.cpp")).read()
+    assert "late_preload_policy(false, g_hip_runtime_up" in hip and "PPALS_STRICT_PRELOAD" in hip
+    assert "catch (const ppals::Unsupported" in api and "PPALS_ERR_UNSUPPORTED" in api
