@@ -26,7 +26,7 @@ def full_size():
 test_test_ALS_matches_oracle = D.test_test_ALS_matches_oracle
 test_cli_defaults_and_silent_resets = D.test_cli_defaults_and_silent_resets
 test_pp_bench_lines = D.test_pp_bench_lines
-test_every_tensor_source_and_pp_mode_runs = D.test_every_tensor_source_and_pp_mode_runs
+test_every_tensor_source_and_pp_mode_matches_oracle = D.test_every_tensor_source_and_pp_mode_matches_oracle
 test_run_driver_class_api = D.test_run_driver_class_api
 test_run_driver_low_rank_optimizers = D.test_run_driver_low_rank_optimizers
 test_cfg1_cli_matches_oracle = D.test_cfg1_cli_matches_oracle

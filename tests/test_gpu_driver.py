@@ -108,15 +108,55 @@ def test_pp_bench_lines(BIN, tmp_path):
     ["-model", "Tucker", "-tensor", "r2", "-dim", "3", "-size", "12", "-rank", "3", "-pp", "1",
      "-pp_res_tol", "0.1"],
 ])
-def test_every_tensor_source_and_pp_mode_runs(BIN, tmp_path, args):
-    """the whole -tensor / -pp flag space of test_ALS.cxx:222-326,352-396 is accepted and decreases
-    the residual"""
-    csv = str(tmp_path / "o.csv")
-    run([os.path.join(BIN, "test_ALS"), "-maxiter", "25", "-resprint", "1", "-filename", csv,
-         "-prec", "64"] + args)
-    _, rows = O.read_csv(csv)
-    assert len(rows) >= 5
-    assert rows[-1][5] <= rows[0][5] * (1 + 1e-9)
+def test_every_tensor_source_and_pp_mode_matches_oracle(BIN, tmp_path, args):
+    """the rest of the -tensor / -pp flag space of test_ALS.cxx:222-326,352-396 at the CLI, against the
+    oracle's CSV: -tensor p | p2 | c, CP -pp 2 (alsCP_PP_partupdate) and Tucker -pp 1 (alsTucker_PP).
+    The driver dumps the tensor it built and the factors it started from (-dumpV / -dumpW0); the
+    oracle is driven from those files with the CLI's options; compared row by row: iteration numbers,
+    [pp_update] flags, [gradnorm] and [diffV] to 1e-4 (as test_test_ALS_matches_oracle does for r)."""
+    csv, vdump, w0 = (str(tmp_path / n) for n in ("o.csv", "v.bin", "w0.bin"))
+    maxiter = 25
+    run([os.path.join(BIN, "test_ALS"), "-maxiter", str(maxiter), "-resprint", "1", "-filename", csv,
+         "-prec", "64", "-dumpV", vdump, "-dumpW0", w0] + args)
+    opt = dict(zip(args[0::2], args[1::2]))
+    model, tensor = opt.get("-model", "CP"), opt["-tensor"]
+    dim, s, R, ppmode = int(opt["-dim"]), int(opt["-size"]), int(opt["-rank"]), int(opt.get("-pp", "0"))
+    lens = [s * s] * (dim // 2) if tensor == "p" else [s] * dim
+    V = _read_doubles(vdump).reshape(lens, order="F")
+    Vn = np.linalg.norm(V)
+    ref = str(tmp_path / "ref.csv")
+    kw = dict(tol=1e-10 * Vn, maxiter=maxiter, csv=ref, resprint=1)     # (-tol default 1e-10, x ||V||: test_ALS.cxx:354)
+    if model == "CP":
+        flat = _read_doubles(w0)
+        W0, o = _split_flat(flat, lens, [R] * len(lens))
+        G0, _ = _split_flat(flat[o:], lens, [R] * len(lens))
+        if ppmode == 0:
+            O.als_cp_dt(V, W0, G0, **kw)
+        elif ppmode == 1:
+            O.als_cp_pp(V, W0, G0, tol_init=float(opt["-pp_res_tol"]), **kw)
+        else:
+            O.als_cp_pp_partupdate(V, W0, G0, tol_init=float(opt["-pp_res_tol"]),
+                                   update_percentage=float(opt["-update_percentage_pp"]), **kw)
+    else:
+        W0, _ = _split_flat(_read_doubles(w0), lens, [R] * len(lens))
+        O.als_tucker_pp(V, W0, O.ttmc(V, W0, -1), tol_init=float(opt["-pp_res_tol"]), **kw)
+    h1, r1 = O.read_csv(ref)
+    h2, r2 = O.read_csv(csv)
+    assert h1 == h2
+    n = min(len(r1), len(r2))
+    assert n >= 5
+    compared = 0
+    for a, b in zip(r1[:n], r2[:n]):
+        if model == "CP" and a[5] < 1e-4 * Vn:
+            break        # (converged: what is left of the rows is rounding)
+        assert a[:2] == b[:2] and a[4] == b[4], (a, b)              # [dim], [iter], [pp_update]
+        for col in (2, 5):                                          # [gradnorm] / metric, [diffV]
+            assert abs(a[col] - b[col]) <= 1e-4 * abs(a[col]) + 1e-9 * Vn, (col, a, b)
+        compared += 1
+    assert compared >= 5
+    if ppmode:
+        assert any(r[4] == 1 for r in r2[:n]), "no PP sweep in the run: the case does not test the PP path"
+    assert r2[-1][5] <= r2[0][5] * (1 + 1e-9)
 
 
 @pytest.mark.parametrize("pp,kind", [(0, 1), (1, 2), (4, 0)])
