@@ -113,6 +113,7 @@ class HipOps : public Ops {
     if (const char *v = getenv("PPALS_EIG_DEFER_FAIL")) eig_defer_fail_ = atoi(v);
     if (const char *v = getenv("PPALS_SCAN_TAIL")) scan_tail_on_ = atoi(v) != 0;
     if (const char *v = getenv("PPALS_SCAN_WIDE")) wide_enabled_ = atoi(v) != 0;
+    if (const char *v = getenv("PPALS_COLD_SUBSPACE_FROM")) cold_subspace_from_ = std::max(65, atoi(v));
     if (const char *v = getenv("PPALS_PERSIST_MULT")) persist_mult_ = std::max(1, atoi(v));  // (probe: tools/runs/r05_m.sh)
     HIP_CHECK(hipFuncSetAttribute((const void *)k_rmult_chol,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -150,6 +151,7 @@ class HipOps : public Ops {
     if (ws_orth_) hipFree(ws_orth_);
     if (ws_pow_) hipFree(ws_pow_);
     if (ws_cold_) hipFree(ws_cold_);
+    if (ws_cold2_) hipFree(ws_cold2_);
     if (ws_jac_) hipFree(ws_jac_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
@@ -1815,7 +1817,12 @@ class HipOps : public Ops {
     // projector step — checked against machine precision, not against an estimated gap — delivers
     // the eigenpairs; the full solver remains the fallback of the fallback
     if (eig_cold_) {
-      if (cold_ritz_state(es, G, J, rank, slot) && projector_step(es, G, J, rank, U, slot, true)) return;
+      if (cold_ritz_state(es, G, J, rank, slot)) {
+        // (long modes: thin products instead of ~46 products of J^3; kColdSubspaceFrom: where a J^3
+        // product, 7.4 us at J = 400, stops being cheap against a step of thin products + Rayleigh-Ritz)
+        if (J >= cold_subspace_from_ && cold_subspace(es, G, J, rank, U, slot)) return;
+        if (projector_step(es, G, J, rank, U, slot, true)) return;
+      }
       // a flat spectrum around the cut (the Gram of a noise tensor: the HOSVD initialisation), where
       // Ritz values cannot place the shift: place it by COUNTING eigenvalues with the sign iteration
       if (cold_ok_ && cold_bisect(es, G, J, rank, U, slot)) return;
@@ -2651,6 +2658,89 @@ class HipOps : public Ops {
     return true;
   }
 
+  // Cold start of a LONG mode by block subspace iteration with Rayleigh-Ritz in every step (round 6).
+  // The projector route costs ~46 products of J^3 from cold — 8.9 ms each at J = 7200, the image mode of
+  // coil-100 (test_ALS.cxx:296-299): 408 of the 516 ms of that HOSVD — to deliver `rank` vectors;
+  // a step here costs two THIN products (G times J x (rank + 16)) and a Rayleigh-Ritz on rank + 16
+  // columns. From the Ritz pairs (U, theta) of cold_ritz_state: B = orth(G U theta^-1) — scaled column
+  // by column, so the block stays near orthonormal whatever the spread of the spectrum (a mean
+  // component 1e6 above the rest included) —, Rayleigh-Ritz on B, residual of the leading `rank` pairs;
+  // accepted at the warm steps' bar (residual <= 1e-9 x the Ritz gap below the rank-th value, or the
+  // rounding floor). The iteration converges like (lambda_{rank+17} / lambda_rank)^k: where the residual
+  // shows that this will not get there within the budget, false — the caller goes on to the projector.
+  bool cold_subspace(EigState &es, double *G, int64_t J, int rank, double *U, int slot) {
+    const int b = cold_b_, Ji = (int)J;
+    if (b <= rank || !cold_Uo_) return false;
+    const size_t nJB = (size_t)J * b;
+    double *w = (double *)ensure(ws_cold_, ws_cold_sz_, sizeof(double) * (5 * nJB + 3 * kEE + kEigEvMax + 64));
+    double *Z = w, *Z2 = Z + nJB, *Zt = Z2 + nJB, *GB = Zt + nJB, *Uo = GB + nJB;
+    double *C = Uo + nJB, *H = C + kEE, *Yr = H + kEE, *ev = Yr + kEE;
+    int *status = (int *)(ev + kEigEvMax);
+    if (Uo != cold_Uo_) return false;  // (the workspace moved: nothing to continue from)
+    double *w2 = (double *)ensure(ws_cold2_, ws_cold2_sz_, sizeof(double) * (nJB + 16));
+    double *GU = w2, *res_d = GU + nJB;
+    constexpr int kMaxIt = 24;
+    double th[kEigEvMax], res_prev = 0;
+    for (int it = 0; it < kMaxIt; it++) {
+      gemm_nn(G, J, Uo, J, nullptr, 0, Z, J, Ji, b, Ji, 1.0, 0.0);  // G * (Ritz vectors)
+      hipLaunchKernelGGL(k_scale_cols_inv, dim3(grid_for((int64_t)nJB, 256)), dim3(256), 0, st_, Z, J, b,
+                         (const double *)ev);
+      HIP_CHECK(hipMemsetAsync(status, 0, 4 * sizeof(int), st_));
+      double *B = chol_qr2(Z, Z2, J, b, C, status);
+      rayleigh_ritz(G, B, J, b, Zt, GB, H, Yr, Uo, ev, GU);
+      hipLaunchKernelGGL(k_eig_residual, dim3(1), dim3(1024), 0, st_, GU, Uo, ev, J, rank, res_d);
+      double res2 = 0;
+      int hs[4];
+      HIP_CHECK(hipMemcpyAsync(th, ev, sizeof(double) * b, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(&res2, res_d, sizeof(double), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(hs, status, sizeof(int) * 4, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      HIP_CHECK(hipGetLastError());
+      const double res = std::sqrt(res2);
+      const bool sane = hs[0] != 1 && hs[1] == 0 && std::isfinite(res) && th[rank - 1] > 0 && th[rank] >= 0;
+      const double gap = sane ? th[rank - 1] - th[rank] : 0.0;
+      const double tol = std::max(1e-9 * gap, 1e-13 * th[0]) * std::sqrt((double)rank);
+      if (eig_debug_)
+        fprintf(stderr, "[ppals eig] slot %d J %lld rank %d: cold subspace step %d, Ritz %.4e .. %.4e | %.4e, "
+                        "residual %.3e (bar %.3e)\n", slot, (long long)J, rank, it, th[0], th[rank - 1], th[rank],
+                res, tol);
+      if (!sane) return false;
+      if (gap > 0 && res <= tol) {
+        const int below = std::min(b - 1, rank + 4);
+        if (!es.Q || es.J != J || es.rank != rank) {
+          if (es.Q) hipFree(es.Q);
+          if (es.Qn) hipFree(es.Qn);
+          HIP_CHECK(hipMalloc(&es.Q, sizeof(double) * J * rank));
+          HIP_CHECK(hipMalloc(&es.Qn, sizeof(double) * J * rank));
+        }
+        es.J = J;
+        es.rank = rank;
+        HIP_CHECK(hipMemcpyAsync(es.Q, Uo, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(U, Uo, sizeof(double) * J * rank, hipMemcpyDeviceToDevice, st_));
+        for (int d = 0; d < rank; d++) es.evh[d] = th[d];
+        es.lamR = th[rank - 1];
+        es.lamR1 = th[below];
+        es.rho = th[0];
+        es.rho_frob = 0;
+        es.head = 4.0;
+        es.valid = es.lamR > es.lamR1 * (1 + 1e-9);
+        es.fast++;
+        n_cold_subspace_++;
+        return true;
+      }
+      // the residual of a linearly converging iteration: where will it be when the budget ends?
+      if (it >= 2 && res_prev > 0) {
+        const double f = res / res_prev;
+        if (!(f < 0.97) || res * std::pow(f, kMaxIt - 1 - it) > tol) return false;
+      }
+      res_prev = res;
+    }
+    return false;
+  }
+  int64_t n_cold_subspace_ = 0;
+  void *ws_cold2_ = nullptr;
+  size_t ws_cold2_sz_ = 0;
+
   // Cold start by eigenvalue counting. trace(sign(G - sigma I)) says how many eigenvalues lie above
   // sigma — exactly, whatever the spectrum looks like — so the shift is placed by a few trials of
   // the sign iteration instead of by Ritz values: a bracket [lo, hi] with count(lo) >= rank (the
@@ -2855,6 +2945,7 @@ class HipOps : public Ops {
     return true;
   }
   bool cold_ok_ = false;
+  int64_t cold_subspace_from_ = 2048;  // PPALS_COLD_SUBSPACE_FROM (tests: lower it to exercise the route)
   int cold_b_ = 0;
   const double *cold_Uo_ = nullptr;
   double cold_th_[kEigEvMax] = {0};

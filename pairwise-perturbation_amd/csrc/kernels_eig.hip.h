@@ -765,6 +765,18 @@ __global__ __launch_bounds__(256) void k_deflate_shift(const double *__restrict_
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// Z[:, d] /= ev[d] (ev[d] <= 0: left alone): the block G * (Ritz vectors) brought back to unit scale
+// column by column, so that the Cholesky QR behind it sees a nearly orthonormal block whatever the
+// spread of the Ritz values (cold_subspace)
+__global__ void k_scale_cols_inv(double *__restrict__ Z, int64_t J, int r, const double *__restrict__ ev) {
+  const int64_t total = J * r;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const double v = ev[e / J];
+    if (v > 0) Z[e] /= v;
+  }
+}
+
 // *out = || GU - U diag(ev) ||_F^2  (residual of the returned eigenpairs; one block)
 __global__ __launch_bounds__(1024) void k_eig_residual(const double *__restrict__ GU,
                                                        const double *__restrict__ U,

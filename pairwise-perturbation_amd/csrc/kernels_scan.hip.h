@@ -435,10 +435,6 @@ __global__ __launch_bounds__(256) void k_scan_suffix_fast(
         for (int jj = 0; jj < VEC; jj++)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
-            // OPT bit 4 (tools/scan2_bench only, WRONG results): the matrix work of the first tile
-            // only, everything else as it is — what the second tile's MFMAs cost the launch
-            if constexpr ((OPT & 16) != 0)
-              if (nt > 0) continue;
             acc[jj][nt] = TR::mfma(cb[nt][u], cv[u][jj], acc[jj][nt]);
           }
 #pragma unroll

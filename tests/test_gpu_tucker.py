@@ -796,3 +796,48 @@ except ppals.PpalsError as e:
     assert "REFUSED ppals error -5" in out.stdout, out.stdout + out.stderr[-2000:]
     assert "ppals_preload_eigensolver" in out.stdout
     assert time.time() - t0 < 120
+
+
+def test_long_mode_cold_start_by_subspace_iteration(pp, monkeypatch, capfd):
+    """hosvd on a LONG mode (als_Tucker.cxx:12-23; coil-100's image mode has 7200 rows,
+    test_ALS.cxx:296-299): the cold start runs block subspace iteration with Rayleigh-Ritz on thin
+    blocks (cold_subspace: two products of G with J x (rank + 16) per step) instead of ~46 products of
+    J^3 on the projector route. The step log must show that route accepted and neither a projector
+    step nor the full solver for that mode during hosvd; projectors against numpy's LAPACK reading;
+    the HOOI sweeps that follow start warm from the state it left."""
+    import numpy_ref as NR
+    lens, ranks, inner = [2400, 20, 16], [30, 6, 5], [60, 10, 8]
+    V = _slow_decay_tensor(lens, inner, [0.9, 0.8, 0.8], 5, 1e-5)
+    W0, c0 = NR.tucker_hosvd(V, ranks)
+    monkeypatch.setenv("PPALS_TUCKER_THIN", "0")     # (the long mode keeps its s x s Gram in the sweeps too)
+    monkeypatch.setenv("PPALS_EIG_DEBUG", "1")
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 1).upload(V)
+    s = pp.Tucker(c2, t, ranks)
+    capfd.readouterr()
+    s.hosvd()
+    err = capfd.readouterr().err
+    W_h, core_h = s.get_factors()
+    for a, b, r in zip(W_h, W0, ranks):
+        assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
+        assert relerr(proj(a), proj(b)) < 1e-7, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core_h) - np.linalg.norm(c0)) < 1e-9 * np.linalg.norm(c0)
+    log = [ln for ln in err.splitlines() if "[ppals eig]" in ln and "J 2400" in ln]
+    steps = [ln for ln in log if "cold subspace step" in ln]
+    assert 1 <= len(steps) <= 16, "\n".join(log)
+    assert not any("||X^2-I||" in ln for ln in log), "\n".join(log)    # no projector step from cold
+    assert not any("full solver" in ln for ln in log), "\n".join(log)
+    # warm from there
+    W_ref, core_ref = NR.tucker_hooi(V, W0, 3)
+    s.set_factors(W0)
+    s.set_core(c0)
+    s.sweeps_dt(3)
+    W, core = s.get_factors()
+    err = capfd.readouterr().err
+    for a, b in zip(W, W_ref):
+        assert relerr(proj(a), proj(b)) < 1e-6, relerr(proj(a), proj(b))
+    assert abs(np.linalg.norm(core) - np.linalg.norm(core_ref)) < 1e-9 * np.linalg.norm(core_ref)
+    assert not any("full solver" in ln for ln in err.splitlines() if "[ppals eig]" in ln)
+    s.close()
+    t.close()
+    c2.close()
