@@ -827,7 +827,7 @@ class HipOps : public Ops {
     // k-split: the launch is MFMA-bound, so what counts is how evenly its workgroups fill the resident
     // slots (a partial last round idles the matrix cores): take the split whose number of rounds is
     // closest below a whole number, a little in favour of fewer splits (slab traffic, the combine)
-    int &occ = wide_occ_[NT - 5];
+    int &occ = wide_occ_[NT - 1];
     if (occ == 0) {
       int nb = 0;
       hipError_t e = hipErrorUnknown;
@@ -893,7 +893,7 @@ class HipOps : public Ops {
   }
   int gj_scalar_ = 0;  // PPALS_GJ_SCALAR=1: the scalar in-LDS sweeps for 64 < R <= 128 (A/B, tests)
   bool wide_enabled_ = true;  // PPALS_SCAN_WIDE=0: chunks of 64 columns (A/B, tests)
-  int wide_occ_[4] = {0, 0, 0, 0};  // resident workgroups per CU of k_scan_wide<5..8>
+  int wide_occ_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // resident workgroups per CU of k_scan_wide<1..8>
   // Where the tail mode of k_scan_suffix_fast starts (first tile of the last, partial round of resident
   // workgroups), or -1: the launch fits one round, has many rounds (the tail is a small share), or its
   // last round is nearly full anyway. Resident workgroups per CU from the runtime's occupancy query

@@ -771,6 +771,10 @@ __global__ __launch_bounds__(256) void k_scan_suffix_buf(
 // barrier + staging 11 %, the loads 7 % of a launch whose bare LDS + MFMA loop runs at 0.90 of the
 // fp32 matrix-core peak). Same numerics as the narrow kernels: exact fp32 products on
 // v_mfma_f32_16x16x4_f32, chains of <= 64 terms, fp64 beyond.
+// (At 64 columns and below the same structure LOSES to the register-streaming kernels above — cfg4's
+// two-tile scan 22.4 against 17.6 ms, cfg2's 1.18 against 1.01 ms, R = 40 1.91 against 1.75, R = 64 2.24
+// against 2.07: profiles/r06k_lds_staged_scan_below_64_columns.txt — so it is instantiated for 5..8
+// n-tiles only; the template itself takes 1..8.)
 // Preconditions (launcher): M % 4 == 0, M >= 4, V 16-byte aligned, 5 <= NT <= 8.
 template <int NT, int OPT = 0>
 __global__ __launch_bounds__(512) void k_scan_wide(
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(512) void k_scan_wide(
     int64_t out_batch_stride, int ncols, int out32, int64_t row_ld = 0, int64_t row_valid = 0) {
   constexpr int BM = 64, BK = 16;  // BK: one k-block = 16 columns = four k-quads
   constexpr int PITCH = BM + 16;   // floats; k rows 4q+g of one quad land in distinct bank groups
-  constexpr int NTA = 2;  // n-tiles per wave
+  constexpr int NTA = (NT + 3) / 4;  // n-tiles per wave (the four column groups of waves)
   // a STAGE = two k-blocks (32 MFMAs per wave between barriers); LDS: two stage buffers
   constexpr int VSZ = BK * PITCH, PSZ = 512 * 4;  // floats per k-block (512 items: both loader items
                                                   // of every thread land inside the block's image)
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(512) void k_scan_wide(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: descriptors and branches below)
   const int g = lane >> 4, j16 = lane & 15;
   const int wm = wave & 1, wn = wave >> 1;
-  const int nt0 = 2 * wn, ntc = max(0, min(NTA, NT - nt0));  // (NT = 7: 2, 2, 2, 1 tiles)
+  const int nt0 = NTA * wn, ntc = max(0, min(NTA, NT - nt0));  // (NT = 7: 2, 2, 2, 1 tiles)
 
   unsigned b = blockIdx.x;
   const int mtile = (int)(b % (unsigned)n_mtiles);
@@ -820,8 +824,10 @@ __global__ __launch_bounds__(512) void k_scan_wide(
   const int64_t block_bytes = (int64_t)BK * M * 4, total_bytes = K * M * 4;
   const int voffP = tid * 16;
   const int vdst = hv * VSZ + kk * PITCH + 4 * mq;
+  // (a wave whose 64 item slots lie past the block's NT * 64 items gets a descriptor without records:
+  // its loads return zeros without touching memory — no branch around a load, the waits stay counted)
   const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)P, 0, (int)((int64_t)nkb * NT * 1024), 0x00020000);
+      (void *)P, 0, wave < NT ? (int)((int64_t)nkb * NT * 1024) : 0, 0x00020000);
   constexpr int AUXV = (OPT & 1) ? 2 : 0;  // nt: streamed once
 
   // register ring: two slot sets of one stage each. Stage j + 2 is requested at the top of stage j
