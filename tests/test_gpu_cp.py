@@ -4,6 +4,8 @@
 Tolerances: fp64 tensor storage -> 1e-10 relative (pure rounding-order differences); fp32 tensor
 storage -> kernels 2e-6 relative, factor matrices after sweeps 1e-5 relative Frobenius (the
 tolerance BASELINE.json's north_star states)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1208,3 +1210,49 @@ def test_gram_system_above_64(pp, R, monkeypatch):
         c2.close()
     for mode in (0, 3):
         assert relerr(got[("0", mode)], got[("1", mode)]) < 1e-10 * cond
+
+
+def _wide_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.integers(3, 5))
+        lens = [int(rng.integers(24, 150 if N == 3 else 64)) for _ in range(N)]
+        size = int(np.prod(lens))
+        if size < 1.1e6 or size > 5e6:
+            continue
+        out.append(dict(lens=lens, R=int(rng.integers(65, 161)), sched=str(rng.choice(["dt", "msdt"])),
+                        roots=int(rng.integers(0, 3)), pad=int(rng.integers(0, 2)), seed=int(rng.integers(0, 1000))))
+    return out
+
+
+@pytest.mark.parametrize("c", _wide_cases(int(os.environ.get("PPALS_FUZZ_CASES", "8")),
+                                          int(os.environ.get("PPALS_FUZZ_SEED", "20261005"))),
+                         ids=lambda c: "-".join(map(str, c["lens"])) + f"-R{c['R']}")
+def test_wide_scan_random_shapes(pp, c, monkeypatch):
+    """seeded random shapes in the regime of more than 64 columns (fp32 storage): extents that are no
+    multiples of the 64-row tile or of the 16-column k-block, ranks with a ragged last n-tile, two wide
+    passes above 128, k-splits, padded layouts, forced root counts — every MTTKRP and two exact sweeps
+    against the oracle (a campaign sets PPALS_FUZZ_CASES / PPALS_FUZZ_SEED)"""
+    if c["roots"] > 0 and c["roots"] <= len(c["lens"]) - 2:
+        monkeypatch.setenv("PPALS_MSDT_ROOTS", str(c["roots"]))
+    monkeypatch.setenv("PPALS_PAD_LAYOUT", str(c["pad"]))
+    lens, R = c["lens"], c["R"]
+    V, W = problem(lens, R, c["seed"], kind="r")
+    G0 = O.init_factors(lens, R, 7 + c["seed"])
+    c2 = pp.Context(0)
+    t = pp.Tensor(c2, lens, 0).upload(V)
+    s = pp.CP(c2, t, R)
+    s.set_schedule(c["sched"])
+    s.set_factors(W, G0)
+    for m in range(len(lens)):
+        assert relerr(s.mttkrp(m), O.mttkrp(V, W, m, 0)) < KTOL[0], (c, m)
+    s.sweeps_dt(2)
+    _, _, W_ref, _ = O.als_cp_dt(V, W, G0, tol=0.0, maxiter=1, resprint=1000)
+    cond = max(np.linalg.cond(np.prod([w.T @ w for j, w in enumerate(W_ref) if j != i], axis=0))
+               for i in range(len(lens)))
+    for a, b in zip(s.get_factors(), W_ref):
+        assert relerr(a, b) < 1e-5 + 3e-8 * cond, (c, relerr(a, b), cond)
+    s.close()
+    t.close()
+    c2.close()
