@@ -798,7 +798,11 @@ except ppals.PpalsError as e:
     assert time.time() - t0 < 120
 
 
-def test_long_mode_cold_start_by_subspace_iteration(pp, monkeypatch, capfd):
+@pytest.mark.parametrize("lens,ranks,inner,from_rows", [
+    ([2400, 24, 20], [30, 8, 7], [60, 14, 12], None),     # long enough for the route by default (2048)
+    ([500, 24, 20], [20, 8, 7], [48, 14, 12], "65"),      # PPALS_COLD_SUBSPACE_FROM lowers the threshold
+])
+def test_long_mode_cold_start_by_subspace_iteration(pp, lens, ranks, inner, from_rows, monkeypatch, capfd):
     """hosvd on a LONG mode (als_Tucker.cxx:12-23; coil-100's image mode has 7200 rows,
     test_ALS.cxx:296-299): the cold start runs block subspace iteration with Rayleigh-Ritz on thin
     blocks (cold_subspace: two products of G with J x (rank + 16) per step) instead of ~46 products of
@@ -806,7 +810,9 @@ def test_long_mode_cold_start_by_subspace_iteration(pp, monkeypatch, capfd):
     step nor the full solver for that mode during hosvd; projectors against numpy's LAPACK reading;
     the HOOI sweeps that follow start warm from the state it left."""
     import numpy_ref as NR
-    lens, ranks, inner = [2400, 24, 20], [30, 8, 7], [60, 14, 12]   # (8 x 7 > 30 + 16: the sweeps' Grams keep a full block of directions)
+    # (ranks: 8 x 7 > rank + 16, so that the sweeps' Grams keep a full block of directions)
+    if from_rows:
+        monkeypatch.setenv("PPALS_COLD_SUBSPACE_FROM", from_rows)
     V = _slow_decay_tensor(lens, inner, [0.9, 0.8, 0.8], 5, 1e-5)
     W0, c0 = NR.tucker_hosvd(V, ranks)
     monkeypatch.setenv("PPALS_TUCKER_THIN", "0")     # (the long mode keeps its s x s Gram in the sweeps too)
@@ -822,7 +828,7 @@ def test_long_mode_cold_start_by_subspace_iteration(pp, monkeypatch, capfd):
         assert np.allclose(a.T @ a, np.eye(r), atol=1e-9)
         assert relerr(proj(a), proj(b)) < 1e-7, relerr(proj(a), proj(b))
     assert abs(np.linalg.norm(core_h) - np.linalg.norm(c0)) < 1e-9 * np.linalg.norm(c0)
-    log = [ln for ln in err.splitlines() if "[ppals eig]" in ln and "J 2400" in ln]
+    log = [ln for ln in err.splitlines() if "[ppals eig]" in ln and f"J {lens[0]}" in ln]
     steps = [ln for ln in log if "cold subspace step" in ln]
     assert 1 <= len(steps) <= 16, "\n".join(log)
     assert not any("||X^2-I||" in ln for ln in log), "\n".join(log)    # no projector step from cold
