@@ -152,6 +152,7 @@ class HipOps : public Ops {
     if (ws_pow_) hipFree(ws_pow_);
     if (ws_cold_) hipFree(ws_cold_);
     if (ws_cold2_) hipFree(ws_cold2_);
+    if (ws_cholm_) hipFree(ws_cholm_);
     if (ws_jac_) hipFree(ws_jac_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
@@ -1679,12 +1680,17 @@ class HipOps : public Ops {
       HIP_CHECK(hipStreamSynchronize(st_));
       return cur;
     }
-    const size_t lds_chol = sizeof(double) * 2 * (size_t)r * r;
+    // R^-1 by ONE elimination of [C | I] on a whole workgroup (k_chol_m: two pivots per barrier, all
+    // 2 r^2 elements of a step in parallel) instead of the one-wave Cholesky + column-wise substitution
+    // (k_chol_rinv: 175 us a call at 64 columns, 1.8 ms of a time-lapse HOOI sweep; round 6)
+    const size_t lds_m = sizeof(double) * (4 * (size_t)r * r + r + 8);
+    double *Minv = (double *)ensure(ws_cholm_, ws_cholm_sz_, sizeof(double) * 64 * 64);
     for (int pass = 0; pass < npass; pass++) {
       hipLaunchKernelGGL(k_tn_small, dim3((r * r + 15) / 16), dim3(1024), 0, st_, cur, cur, J, r, C);
-      hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(64), lds_chol, st_, C, r, status + pass);
+      hipLaunchKernelGGL(k_chol_m, dim3(1), dim3(k_chol_threads(r)), lds_m, st_, cur, (const double *)nullptr, J, r, 0,
+                         (const double *)C, Minv, status + pass);
       hipLaunchKernelGGL(k_right_mult, dim3(grid_for(J * r, 256)), dim3(256),
-                         sizeof(double) * r * r, st_, cur, J, r, C, nxt);
+                         sizeof(double) * r * r, st_, cur, J, r, Minv, nxt);
       std::swap(cur, nxt);
     }
     return cur;
@@ -2740,6 +2746,8 @@ class HipOps : public Ops {
   int64_t n_cold_subspace_ = 0;
   void *ws_cold2_ = nullptr;
   size_t ws_cold2_sz_ = 0;
+  void *ws_cholm_ = nullptr;
+  size_t ws_cholm_sz_ = 0;
 
   // Cold start by eigenvalue counting. trace(sign(G - sigma I)) says how many eigenvalues lie above
   // sigma — exactly, whatever the spectrum looks like — so the shift is placed by a few trials of
