@@ -549,8 +549,10 @@ class HipOps : public Ops {
     const bool aligned_base = (((uintptr_t)V) & 15) == 0;
     // 65..128 columns of an fp32 tensor in ONE pass (k_scan_wide: MFMA-bound regime, the tensor tile
     // staged through LDS); whatever is left after whole passes of 128 goes the narrow way
+    // (buffer loads: a k-block of 16 columns and the packed operand must be addressable with 32-bit offsets)
     const bool wide_ok = sizeof(TV) == 4 && wide_enabled_ && L > 1 && aligned_base && (L % 4 == 0) &&
-                         L >= 4 && (double)L * J * T >= 1.0e6;
+                         L >= 4 && (double)L * J * T >= 1.0e6 && 16.0 * (double)L * 4.0 < 2.0e9 &&
+                         ((double)J / 16.0 + 1.0) * 8.0 * 1024.0 < 2.0e9;
     int col_step = 64;
     for (int col0 = 0; col0 < R; col0 += col_step) {
       if (wide_ok && R - col0 > 64) {
