@@ -848,3 +848,42 @@ def test_long_mode_cold_start_by_subspace_iteration(pp, lens, ranks, inner, from
     s.close()
     t.close()
     c2.close()
+
+
+@pytest.mark.parametrize("lens,ranks", [([128, 160, 64], [8, 70, 6]),       # the mode product with 70 columns is a batched wide scan
+                                        ([96, 72, 144, 16], [6, 5, 100, 4])])  # 100 columns (the time-lapse run's rank), order 4
+def test_mode_products_above_64_columns(pp, lens, ranks, monkeypatch):
+    """Tucker mode products with more than 64 core columns (the reference's real-data ranks 70 and 100,
+    test_ALS.cxx:366-379; als_Tucker.cxx:102): on fp32 storage the first-level product is ONE pass of the
+    LDS-staged wide scan in its batched, keep-the-mode-in-place form (k_scan_wide with T > 1 and an fp64
+    result); TTMc for every skipped mode against the oracle, and the same with the wide scan switched
+    off (64-column chunks) to rounding level."""
+    V = O.fill_uniform(int(np.prod(lens)), 3, lo=0.5, hi=1.0).reshape(lens, order="F")
+    W = [np.linalg.qr(O.fill_uniform(s * r, 40 + i, lo=-1, hi=1).reshape((s, r), order="F"))[0]
+         for i, (s, r) in enumerate(zip(lens, ranks))]
+    got = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PPALS_SCAN_WIDE", wide)
+        c2 = pp.Context(0)
+        t = pp.Tensor(c2, lens, 0).upload(V)
+        s = pp.Tucker(c2, t, ranks)
+        s.set_factors(W)
+        c2.profile_enable(1)
+        c2.profile_reset()
+        got[wide] = [s.ttmc(skip) for skip in [-1] + list(range(len(lens)))]
+        n_scans, _, _ = c2.profile_read(0)
+        c2.profile_enable(0)
+        got[wide + "n"] = n_scans
+        for skip, g in zip([-1] + list(range(len(lens))), got[wide]):
+            assert relerr(g, O.ttmc(V, W, skip)) < 2e-6, (wide, skip, relerr(g, O.ttmc(V, W, skip)))
+        s.close()
+        t.close()
+        c2.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert relerr(a, b) < 5e-7
+    # fewer tensor passes with the wide scan wherever a product of more than 64 columns meets the fp32
+    # tensor itself (order 3 here; the order-4 chain contracts a short-rank mode first and its 100-column
+    # product acts on an fp64 intermediate, which keeps the 64-column chunks)
+    assert got["1n"] <= got["0n"], (got["1n"], got["0n"])
+    if len(lens) == 3:
+        assert got["1n"] < got["0n"], (got["1n"], got["0n"])
