@@ -153,6 +153,7 @@ class HipOps : public Ops {
     if (ws_cold_) hipFree(ws_cold_);
     if (ws_cold2_) hipFree(ws_cold2_);
     if (ws_cholm_) hipFree(ws_cholm_);
+    if (ws_gsfb_) hipFree(ws_gsfb_);
     if (ws_jac_) hipFree(ws_jac_);
     if (eig_host_) hipHostFree(eig_host_);
     if (ws_part2_) hipFree(ws_part2_);
@@ -1152,7 +1153,24 @@ class HipOps : public Ops {
       HIP_CHECK(hipGetLastError());
       // a non-positive pivot (S not positive definite: a rank above a mode extent, collinear
       // columns) leaves NaNs in Sinv: take the reference's route instead, the untruncated inverse
-      // through a full eigen-decomposition (vendor solver; this unfused path is not a fast path)
+      // through a full eigen-decomposition.
+      // Up to 128 columns that route is two CONDITIONAL launches on the stream — the one-workgroup
+      // one-sided Jacobi of S and Z diag(1/w) Z^T, both returning at once unless the elimination set
+      // its status word — so a mode update above 64 columns holds no host synchronisation any more
+      // (round 6: four read-backs per sweep were 40 us of idle stream each, and milliseconds each
+      // whenever the host's cores were busy). PPALS_FORCE_EIGINV=2 runs the two launches ungated (tests).
+      if (R <= kJacobiBigMax && force_eiginv_ != 1) {
+        double *fb = (double *)ensure(ws_gsfb_, ws_gsfb_sz_, sizeof(double) * (2 * (size_t)R * R + R));
+        double *Vt = fb, *Yz = Vt + (size_t)R * R, *wv = Yz + (size_t)R * R;
+        const int *gate = force_eiginv_ == 2 ? nullptr : status;
+        const size_t lds_j = sizeof(double) * ((size_t)R * (R + 1) + 256) + sizeof(int) * 256;
+        hipLaunchKernelGGL(k_jacobi_onesided, dim3(1), dim3(1024), lds_j, st_, (const double *)S, R, Vt, Yz, wv,
+                           (double *)nullptr, gate);
+        hipLaunchKernelGGL(k_eig_inverse, dim3(grid_for((int64_t)R * R, 256)), dim3(256), 0, st_,
+                           (const double *)Yz, (const double *)wv, R, Sinv, gate);
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
       int bad = 0;
       HIP_CHECK(hipMemcpyAsync(&bad, status, sizeof(int), hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
@@ -2750,6 +2768,8 @@ class HipOps : public Ops {
   size_t ws_cold2_sz_ = 0;
   void *ws_cholm_ = nullptr;
   size_t ws_cholm_sz_ = 0;
+  void *ws_gsfb_ = nullptr;
+  size_t ws_gsfb_sz_ = 0;
 
   // Cold start by eigenvalue counting. trace(sign(G - sigma I)) says how many eigenvalues lie above
   // sigma — exactly, whatever the spectrum looks like — so the shift is placed by a few trials of

@@ -1793,7 +1793,11 @@ constexpr int kJacobiBigMax = 128;
 __global__ __launch_bounds__(1024) void k_jacobi_onesided(const double *__restrict__ H, int n,
                                                           double *__restrict__ V, double *__restrict__ Y,
                                                           double *__restrict__ ev,
-                                                          double *__restrict__ ev_host) {
+                                                          double *__restrict__ ev_host,
+                                                          const int *__restrict__ gate = nullptr) {
+  // (gate: the launch is a conditional one — it does nothing unless *gate is set; the R x R normal
+  // equations' eigen-route, wanted only when the elimination met a non-positive pivot)
+  if (gate && *gate == 0) return;
   extern __shared__ double lds[];
   const int ld = n + 1;
   double *W = lds;

@@ -1367,7 +1367,8 @@ __global__ __launch_bounds__(1024) void k_gram_system_mfma(const double *__restr
 // order): for symmetric S this IS the reference's untruncated V diag(1/sigma) U^T
 // (common.cxx:717-722) — the defined answer when S is not positive definite
 __global__ void k_eig_inverse(const double *__restrict__ Z, const double *__restrict__ w, int R,
-                              double *__restrict__ Sinv) {
+                              double *__restrict__ Sinv, const int *__restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;  // (conditional launch: see k_jacobi_onesided)
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < R * R; e += gridDim.x * blockDim.x) {
     const int i = e % R, j = e / R;
     double acc = 0;

@@ -996,14 +996,15 @@ def test_rank_stream_on_matrix_cores(pp, ctx, lens, R, dtype):
 def test_rank_above_64_non_spd_fallback(pp, monkeypatch):
     """R > 64 (the reference CLI's default is R = s/2): S^-1 by pivot-free Gauss-Jordan sweeps, and
     when a pivot is not positive the untruncated inverse through a full eigen-decomposition (the
-    reference's SVD_solve, common.cxx:710-725) instead of NaNs. (1) the eigen route, forced on an
-    SPD problem, reproduces the sweep route; (2) a rank-deficient problem (R above three of the
+    reference's SVD_solve, common.cxx:710-725) instead of NaNs — up to 128 columns by two conditional
+    launches on the stream (one-sided Jacobi of S, Z diag(1/w) Z^T: no host synchronisation), beyond by
+    the vendor solver. (1) both eigen routes, forced on an SPD problem, reproduce the sweep route; (2) a rank-deficient problem (R above three of the
     four mode extents, R = s/2 of the long one) ends without a NaN and fits as well as the oracle."""
     lens, R = [90, 85, 82], 80
     V = O.build_V(O.init_factors(lens, 12, 1))
     W, G = O.init_factors(lens, R, 2), O.init_factors(lens, R, 3)
     outs = []
-    for force in ("0", "1"):
+    for force in ("0", "1", "2"):     # block sweeps | vendor dsyevd (host route) | the conditional device route, ungated
         monkeypatch.setenv("PPALS_FORCE_EIGINV", force)
         c2 = pp.Context(0)
         t = pp.Tensor(c2, lens, 1).upload(V)
@@ -1017,6 +1018,7 @@ def test_rank_above_64_non_spd_fallback(pp, monkeypatch):
         t.close()
         c2.close()
     assert relerr(outs[1], outs[0]) < 1e-7 * np.linalg.cond(S)
+    assert relerr(outs[2], outs[0]) < 1e-7 * np.linalg.cond(S)
     monkeypatch.setenv("PPALS_FORCE_EIGINV", "0")
     lens, R = [140, 9, 8, 7], 70
     V = O.fill_uniform(int(np.prod(lens)), 5, lo=0.5, hi=1.0).reshape(lens, order="F")

@@ -2,6 +2,7 @@
 at s = 200: ms per sweep per schedule, the scans' share (HIP events on the engine's stream), parity of
 the factors against the closed form. Usage: r06_rank100.py [R=100] [s=200] [sweeps=6]"""
 import os
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # (BLAS worker threads disturb the host side of the timed loop)
 import sys
 import time
 
