@@ -1109,7 +1109,7 @@ def main():
         if args.schedule:
             cp.set_schedule(args.schedule)
         r = measure(cp, sub_steps, 2)
-        r["comm_plan"] = "reduce-scatter + row-block update + all-gather per mode"
+        r["comm_plan"] = "reduce-scatter + row-block update + all-gather per mode (the plan north_star names; the headline runs the default for these message sizes: one all-reduce + redundant fused update)"
         sub["reduce_scatter_plan"] = r
         if old is None:
             del os.environ["PPALS_COMM_SMALL_BYTES"]
