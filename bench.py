@@ -1068,6 +1068,28 @@ def main():
             del os.environ["PPALS_PLACE_TUNE"]
         else:
             os.environ["PPALS_PLACE_TUNE"] = old
+    if world == 1 and not args.schedule:
+        # cold (first sweep) beside the steady state — a fresh session on the resident
+        # tensor: session creation (second resident layout, workspaces), then the very first exact sweep
+        try:
+            t0 = time.perf_counter()
+            cpc = ppals.CP(ctx, V, R)
+            cpc.set_factors(W0, G0)
+            ctx.sync()
+            t1 = time.perf_counter()
+            cpc.sweeps_dt(1)
+            ctx.sync()
+            t2 = time.perf_counter()
+            cpc.sweeps_dt(1)
+            ctx.sync()
+            t3 = time.perf_counter()
+            sub["cold"] = {"session_create_ms": 1e3 * (t1 - t0), "first_sweep_ms": 1e3 * (t2 - t1),
+                           "second_sweep_ms": 1e3 * (t3 - t2), "steady_ms_per_step": head["ms_per_step"],
+                           "note": "fresh session on the resident tensor; the first sweep allocates the first-level "
+                                   "intermediate and packs its operands for the first time"}
+            cpc.close()
+        except Exception as e:  # reported, never required
+            sub["cold"] = {"error": str(e)}
     if world == 1 and not args.schedule and schedule == "msdt" and not hostsim:
         # wall time from session creation to 250 sweeps done (the reference's scripts run 250,
         # script/script_synthetic.py:18) with the online placement choice and without, same tensor,
